@@ -1,0 +1,62 @@
+import argparse
+import os
+import sys
+
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(REPO, "maua-style_amd")
+GOLDEN = os.path.join(REPO, "tests", "golden")
+for p in (REPO, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+torch.set_num_threads(1)  # thread count changes fp32 results; fixtures used 1
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu through gpurun)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def make_cfg(**over):
+    """Namespace with the reference's defaults for the fields the hot path reads (config.py:15-89)."""
+    d = dict(
+        model_file="vgg19", pooling="max", content_layers="relu4_2",
+        style_layers="relu1_1,relu2_1,relu3_1,relu4_1,relu5_1", tv_weight=1e-3, temporal_weight=50.0,
+        content_weight=5.0, style_weight=100.0, use_covariance=False, normalize_gradients=True,
+        video_style_factor=100.0, normalize_weights=False, optimizer="lbfgs", learning_rate=1.0,
+        lbfgs_num_correction=100, lbfgs_tolerance_change=-1, lbfgs_tolerance_grad=-1,
+        style_blend_weights=[1.0], shift_factor=0.0,
+    )
+    d.update(over)
+    return argparse.Namespace(**d)
+
+
+# flag sets of the golden single-feval variants (tools/make_golden.py gen_feval)
+FEVAL_VARIANTS = {
+    "default": {},
+    "no_grad_norm": dict(normalize_gradients=False),
+    "normalize_weights": dict(normalize_weights=True, temporal_weight=0.0),
+    "avgpool": dict(pooling="avg"),
+    "no_tv_no_vsf": dict(tv_weight=0.0, video_style_factor=0.0, temporal_weight=0.0),
+    "covariance": dict(use_covariance=True),
+    "layers_alt": dict(content_layers="relu3_2,relu4_2", style_layers="relu1_2,relu2_2,relu3_3"),
+    "weights_alt": dict(content_weight=7.5, style_weight=33.0, tv_weight=0.02),
+}
+NIN_LAYERS = dict(model_file="nin", style_layers="relu1,relu3,relu5,relu7,relu9,relu11", content_layers="relu8")
+
+
+def rel_l2(a, b):
+    a = torch.as_tensor(a).double().flatten()
+    b = torch.as_tensor(b).double().flatten()
+    return float((a - b).norm() / b.norm().clamp_min(1e-300))

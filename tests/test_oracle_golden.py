@@ -1,0 +1,185 @@
+"""Pin the CPU oracle to fixtures produced by the unmodified reference (tools/make_golden.py).
+
+Tolerances follow SURVEY.md §8(c): per-module losses <= 1e-5 relative, pixel gradient
+<= 1e-5 rel-L2 for a CPU restatement; trajectories are judged against the fp64 arbiter with
+the reference's own fp32 noise as the yardstick.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from conftest import FEVAL_VARIANTS, GOLDEN, NIN_LAYERS, make_cfg, rel_l2
+from oracle import OracleNet, build_spec, optimize
+from oracle.style_oracle import loss_order
+
+
+def gold(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def run_feval(cfg, content, styles, init, sd, dtype=torch.float32):
+    spec = build_spec(cfg)
+    net = OracleNet(spec, sd, dtype)
+    net.capture_content(content)
+    net.capture_style(styles, cfg.style_blend_weights)
+    if cfg.normalize_weights:
+        net.normalize_weights()
+    total, losses, grad = net.feval(init)
+    return spec, net, float(total), losses, grad
+
+
+def check_feval(g, spec, total, losses, grad, tol_loss=1e-5, tol_grad=1e-5):
+    order = loss_order(spec)
+    names = [spec[i].name for i in order]
+    assert names == list(g["loss_names"])
+    for i, want in zip(order, g["loss_values"]):
+        got = float(losses.get(i, 0.0))
+        assert abs(got - want) <= tol_loss * max(abs(want), 1e-12), (spec[i].name, got, want)
+    assert abs(total - float(g["total"])) <= tol_loss * abs(float(g["total"]))
+    assert rel_l2(grad, g["grad"]) <= tol_grad
+
+
+def test_synthetic_inputs_regenerate_identically():
+    g = gold("feval_vgg19_S32_default")
+    imgs = synth.images(32)
+    np.testing.assert_allclose(np.array([synth.checksum(t) for t in imgs]), g["input_checksums"], rtol=0, atol=0)
+    meta = json.load(open(os.path.join(GOLDEN, "META.json")))
+    sd = synth.vgg19_state_dict()
+    for k, want in meta["weights_checksum_vgg19"].items():
+        assert synth.checksum(sd[k]) == want
+
+
+@pytest.mark.parametrize("S,variant", [(32, v) for v in FEVAL_VARIANTS] + [(64, "default"), (64, "no_grad_norm")])
+def test_feval_matches_reference(S, variant):
+    g = gold(f"feval_vgg19_S{S}_{variant}")
+    cfg = make_cfg(**FEVAL_VARIANTS[variant])
+    content, style, init = synth.images(S)
+    spec, net, total, losses, grad = run_feval(cfg, content, [style], init, synth.vgg19_state_dict())
+    kinds = {"tv": "TVLoss", "temporal": "ContentLoss", "content": "ContentLoss", "style": "StyleLoss",
+             "conv": "Conv2d", "relu": "ReLU", "pool": "MaxPool2d" if cfg.pooling == "max" else "AvgPool2d"}
+    assert [kinds[l.kind] for l in spec] == list(g["module_types"])
+    check_feval(g, spec, total, losses, grad)
+    if "style_target_0" in g:
+        sidx = [i for i, l in enumerate(spec) if l.kind == "style"]
+        for k, i in enumerate(sidx):
+            assert rel_l2(net.targets[i], g[f"style_target_{k}"]) <= 1e-5
+        cidx = [i for i, l in enumerate(spec) if l.kind == "content"][0]
+        assert rel_l2(net.targets[cidx], g["content_target_0"]) <= 1e-6
+
+
+def test_feval_zero_bias_matches_survey_appendix():
+    g = gold("feval_vgg19_S64_zerobias")
+    content, style, init = synth.images(64)
+    spec, net, total, losses, grad = run_feval(make_cfg(), content, [style], init,
+                                               synth.vgg19_state_dict(bias_scale=0.0))
+    check_feval(g, spec, total, losses, grad)
+    assert abs(total - 1.872610e5) < 1.0  # SURVEY.md Appendix A anchor
+
+
+def test_feval_fp64_arbiter():
+    g = gold("feval_vgg19_S32_default_f64")
+    content, style, init = synth.images(32)
+    spec, net, total, losses, grad = run_feval(make_cfg(), content, [style], init, synth.vgg19_state_dict(),
+                                               dtype=torch.float64)
+    check_feval(g, spec, total, losses, grad, tol_loss=1e-10, tol_grad=1e-10)
+
+
+def test_feval_two_styles_nonsquare():
+    g = gold("feval_vgg19_40x56_twostyles")
+    gen = torch.Generator().manual_seed(11)
+    content = torch.rand(1, 3, 40, 56, generator=gen) * 255 - 120
+    s1 = torch.rand(1, 3, 48, 48, generator=gen) * 255 - 120
+    s2 = torch.rand(1, 3, 36, 60, generator=gen) * 255 - 120
+    init = torch.rand(1, 3, 40, 56, generator=gen) * 255 - 120
+    cfg = make_cfg(style_blend_weights=[0.25, 0.75])
+    np.testing.assert_allclose(g["blend"], cfg.style_blend_weights)
+    spec, net, total, losses, grad = run_feval(cfg, content, [s1, s2], init, synth.vgg19_state_dict())
+    check_feval(g, spec, total, losses, grad)
+
+
+def test_intermediate_features():
+    g = gold("feval_vgg19_S32_default")
+    content, style, init = synth.images(32)
+    net = OracleNet(build_spec(make_cfg()), synth.vgg19_state_dict())
+    acts, _ = net._forward(init)
+    # the reference reuses ONE MaxPool2d instance for every pool (models.py:119-127), so the hook the
+    # generator put on module 7 last fired for pool4 (module 34): "feat_7" holds pool4's output.
+    for idx, key in ((3, "feat_3"), (34, "feat_7"), (37, "feat_37")):
+        assert rel_l2(acts[idx], g[key]) <= 1e-6
+
+
+# ------------------------------------------------------------------------------------------
+# Trajectories.  fp32 L-BFGS is chaotic: the yardstick is the fp64 arbiter,
+#   relL2(oracle_f32, ref_f64) <= max(1e-3, 2 * relL2(ref_f32, ref_f64))        
+# and the oracle run in fp64 must reproduce the arbiter itself tightly.
+# ------------------------------------------------------------------------------------------
+TRAJ64 = [("lbfgs", n) for n in (1, 2, 3, 4, 5, 10, 20)] + [("adam", n) for n in (1, 5, 10, 20)]
+
+
+@pytest.mark.parametrize("opt,N", TRAJ64)
+def test_trajectory_vs_arbiter(opt, N):
+    g = gold("traj_vgg19_S64")
+    ref32, ref64 = g[f"{opt}_N{N}_f32"], g[f"{opt}_N{N}_f64"]
+    content, style, init = synth.images(64)
+    sd = synth.vgg19_state_dict()
+    cfg = make_cfg(optimizer=opt)
+    out64 = optimize(content, [style], init, N, cfg, sd, dtype=torch.float64)
+    assert rel_l2(out64, ref64) <= 1e-7, "fp64 oracle must reproduce the fp64 arbiter"
+    if N <= 10:
+        out32 = optimize(content, [style], init, N, cfg, sd, dtype=torch.float32)
+        floor = rel_l2(ref32, ref64)
+        assert rel_l2(out32, ref64) <= max(1e-3, 2 * floor), (rel_l2(out32, ref64), floor)
+
+
+def test_trajectory_variants_history_ring_and_adam_lr():
+    g = gold("traj_vgg19_S32_variants")
+    content, style, init = synth.images(32)
+    sd = synth.vgg19_state_dict()
+    out = optimize(content, [style], init, 12, make_cfg(lbfgs_num_correction=3), sd, dtype=torch.float64)
+    assert rel_l2(out, g["lbfgs_m3_N12_f64"]) <= 1e-7
+    out = optimize(content, [style], init, 8, make_cfg(optimizer="adam", learning_rate=2.5), sd, dtype=torch.float64)
+    assert rel_l2(out, g["adam_lr2.5_N8_f64"]) <= 1e-9
+    out = optimize(content, [style], init, 8, make_cfg(optimizer="adam", learning_rate=2.5), sd)
+    assert rel_l2(out, g["adam_lr2.5_N8_f32"]) <= max(1e-3, 2 * rel_l2(g["adam_lr2.5_N8_f32"], g["adam_lr2.5_N8_f64"]))
+
+
+def test_lbfgs_eval_counts_match_reference():
+    host = json.load(open(os.path.join(GOLDEN, "host_logic.json")))
+    from oracle import lbfgs_run, adam_run
+    x0 = torch.linspace(-1, 1, 50, dtype=torch.float64)
+
+    def fg(x):
+        return float(((x - 0.3) ** 4).sum() + (x * x).sum()), 4 * (x - 0.3) ** 3 + 2 * x
+    for n, want in host["lbfgs_fevals"].items():
+        assert lbfgs_run(fg, x0, int(n))[1] == want
+    for n, want in host["adam_fevals"].items():
+        assert adam_run(fg, x0, int(n))[1] == want
+
+
+# ------------------------------------------------------------------------------------------
+# NIN + covariance (BASELINE config 5)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,S,cov", [("feval_nin_S128_covariance", 128, True), ("feval_nin_S128_gram", 128, False),
+                                        ("feval_nin_S99_covariance", 99, True)])
+def test_nin_feval(name, S, cov):
+    g = gold(name)
+    cfg = make_cfg(use_covariance=cov, **NIN_LAYERS)
+    content, style, init = synth.images(S)
+    spec, net, total, losses, grad = run_feval(cfg, content, [style], init, synth.nin_state_dict())
+    check_feval(g, spec, total, losses, grad, tol_loss=2e-5, tol_grad=2e-5)
+    if "style_target_0" in g:
+        sidx = [i for i, l in enumerate(spec) if l.kind == "style"]
+        for k in range(3):
+            assert rel_l2(net.targets[sidx[k]], g[f"style_target_{k}"]) <= 1e-5
+
+
+def test_nin_adam_trajectory():
+    g = gold("traj_nin_S128")
+    cfg = make_cfg(use_covariance=True, optimizer="adam", **NIN_LAYERS)
+    content, style, init = synth.images(128)
+    out = optimize(content, [style], init, 5, cfg, synth.nin_state_dict(), dtype=torch.float64)
+    assert rel_l2(out, g["adam_N5_f64"]) <= 1e-9

@@ -1,0 +1,399 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference in this container.
+
+Build-container only: imports /root/reference (which never travels to the GPU box)
+with inert stubs for its absent third-party imports, following SURVEY.md §8(c) /
+Appendix A.  Nothing from the reference is copied; the fixtures hold inputs' seeds
+and the reference's numeric outputs.
+
+    python tools/make_golden.py [group ...]     # groups: feval traj nin hist host all
+
+Thread count changes fp32 results, so everything runs with
+torch.set_num_threads(1).
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+import tempfile
+import types
+
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(REPO, "tests", "golden")
+REF = "/root/reference"
+
+for _name in ["gdown", "skvideo", "skvideo.io", "torchvision", "torchvision.transforms", "ffmpeg"]:
+    sys.modules[_name] = types.ModuleType(_name)  # absent deps; none is on the hot path
+
+import importlib.util
+
+import numpy as np
+import torch
+
+_spec = importlib.util.spec_from_file_location("maua_synth", os.path.join(REPO, "maua-style_amd", "synth.py"))
+synth = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(synth)
+
+sys.path.insert(0, REF)
+import config as ref_config  # noqa: E402  (reference modules, unmodified)
+import loss as ref_loss  # noqa: E402
+import models as ref_models  # noqa: E402
+import optim as ref_optim  # noqa: E402
+import utils as ref_utils  # noqa: E402
+
+torch.set_num_threads(1)
+TMP = tempfile.mkdtemp(prefix="maua_golden_")
+VGG_PATH = os.path.join(TMP, "vgg19_synth.pth")  # path must contain "vgg19" (models.py:289)
+VGG_PATH_ZB = os.path.join(TMP, "vgg19_synth_zerobias.pth")
+NIN_PATH = os.path.join(TMP, "nin_synth.pth")
+SCALING = os.path.join(TMP, "scaling-cpu.json")
+torch.save(synth.vgg19_state_dict(), VGG_PATH)
+torch.save(synth.vgg19_state_dict(bias_scale=0.0), VGG_PATH_ZB)
+torch.save(synth.nin_state_dict(), NIN_PATH)
+with open(SCALING, "w") as f:  # defeats optim.py:93-108 forcing gpu "0"
+    json.dump({"100000": {"gpu": "c", "multidevice": False}}, f)
+
+
+def get_args(extra=(), model=VGG_PATH, optimizer="lbfgs", S=64, N=10):
+    argv = ["style.py", "--content", "c.png", "--style", "s.png", "--gpu", "c", "--backend", "mkl",
+            "--model_file", model, "--disable_check", "--scaling_args", SCALING,
+            "--ffmpeg_args", os.path.join(REF, "config", "ffmpeg-libx264.json"), "--optimizer", optimizer,
+            "--image_sizes", str(S), "--num_iters", str(N), "--seed", "0", "--no_hist_match"] + list(extra)
+    old = sys.argv
+    sys.argv = argv
+    try:
+        return ref_config.get_args()
+    finally:
+        sys.argv = old
+
+
+def quiet():
+    return contextlib.redirect_stdout(io.StringIO())  # tqdm writes to stdout (optim.py:19)
+
+
+def save(name, **arrays):
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"  wrote {os.path.relpath(path, REPO)}  ({os.path.getsize(path) / 1024:.0f} KB)")
+
+
+def single_feval(args, content, styles, init, double=False, want_feats=()):
+    """One forward+backward of the assembled loss network, reference code only."""
+    ref_optim.set_model_args(args, max(*init.shape))
+    with quiet():
+        net, losses = ref_models.load_model(args)
+    if double:
+        net.double()
+        args.dtype = torch.DoubleTensor
+    feats = {}
+    hooks = []
+    for idx, mod in enumerate(net):
+        if idx in want_feats:
+            hooks.append(mod.register_forward_hook(
+                lambda m, i, o, idx=idx: feats.__setitem__(idx, o.detach().clone())))
+    with quiet():
+        ref_optim.set_content_targets(net, content, args)
+        ref_optim.set_style_targets(net, styles, args)
+    for m in losses:
+        m.mode = "loss"
+    if args.normalize_weights:  # optim.py:176-178
+        for m in net.content_losses + net.style_losses + net.temporal_losses:
+            m.strength = m.strength / max(m.target.size())
+    feats.clear()
+    x = torch.nn.Parameter(init.clone().type(args.dtype))
+    net(x)
+    names, vals, total = [], [], 0
+    for m in losses:
+        names.append(m.name)
+        if isinstance(m.loss, int):
+            vals.append(0.0)
+            continue
+        vals.append(float(m.loss.detach()))
+        total = total + m.loss
+    total.backward()
+    for h in hooks:
+        h.remove()
+    out = dict(
+        loss_names=np.array(names), loss_values=np.array(vals, dtype=np.float64),
+        total=np.float64(float(total.detach())), grad=x.grad.detach().numpy().copy(),
+        module_types=np.array([type(m).__name__ for m in net]),
+        module_names=np.array([getattr(m, "name", "") for m in net]),
+    )
+    for idx, t in feats.items():
+        out[f"feat_{idx}"] = t.numpy().copy()
+    return out, net
+
+
+def gen_feval():
+    print("[feval] single forward/backward fixtures")
+    variants = {
+        "default": [],
+        "no_grad_norm": ["--no_grad_norm"],
+        # with the default temporal_weight the reference itself dies here with ZeroDivisionError
+        # (optim.py:178 divides by max(torch.Size([0])) of the empty temporal target)
+        "normalize_weights": ["--normalize_weights", "--temporal_weight", "0"],
+        "avgpool": ["--pooling", "avg"],
+        "no_tv_no_vsf": ["--tv_weight", "0", "--video_style_factor", "0", "--temporal_weight", "0"],
+        "covariance": ["--use_covariance"],
+        "layers_alt": ["--content_layers", "relu3_2,relu4_2", "--style_layers", "relu1_2,relu2_2,relu3_3"],
+        "weights_alt": ["--content_weight", "7.5", "--style_weight", "33", "--tv_weight", "0.02"],
+    }
+    for S in (32, 64):
+        content, style, init = synth.images(S)
+        for vname, extra in variants.items():
+            if S == 64 and vname not in ("default", "no_grad_norm"):
+                continue
+            args = get_args(extra, S=S)
+            want = (3, 7, 37) if (S == 32 and vname == "default") else ()
+            out, net = single_feval(args, content, [style], init, want_feats=want)
+            if S == 32 and vname in ("default", "covariance"):
+                for k, m in enumerate(net.style_losses):
+                    out[f"style_target_{k}"] = m.target.numpy().copy()
+                out["content_target_0"] = net.content_losses[0].target.numpy().copy()
+            out["input_checksums"] = np.array([synth.checksum(t) for t in (content, style, init)])
+            out["flags"] = np.array(extra)
+            save(f"feval_vgg19_S{S}_{vname}", **out)
+    # zero-bias recipe of SURVEY Appendix A: sanity anchor (total loss 1.872610e+05 at S=64)
+    content, style, init = synth.images(64)
+    out, _ = single_feval(get_args(S=64, model=VGG_PATH_ZB), content, [style], init)
+    print("    zero-bias S=64 total loss", out["total"], "(SURVEY Appendix A: 1.872610e+05)")
+    save("feval_vgg19_S64_zerobias", **out)
+    # fp64 arbiter for the default single feval
+    content, style, init = synth.images(32)
+    out, _ = single_feval(get_args(S=32), content, [style], init, double=True)
+    save("feval_vgg19_S32_default_f64", **out)
+    # two styles with blend weights, styles of other sizes than the content, non-square content
+    g = torch.Generator().manual_seed(11)
+    content = torch.rand(1, 3, 40, 56, generator=g) * 255 - 120
+    s1 = torch.rand(1, 3, 48, 48, generator=g) * 255 - 120
+    s2 = torch.rand(1, 3, 36, 60, generator=g) * 255 - 120
+    init = torch.rand(1, 3, 40, 56, generator=g) * 255 - 120
+    args = _get_args_two_styles(["--style_blend_weights", "0.3,0.9"], S=56)  # two names: len(style)==2
+    out, net = single_feval(args, content, [s1, s2], init)
+    out["blend"] = np.array(args.style_blend_weights)
+    save("feval_vgg19_40x56_twostyles", **out)
+
+
+def _get_args_two_styles(extra, S):
+    argv = ["style.py", "--content", "c.png", "--style", "s1.png", "s2.png", "--gpu", "c", "--backend", "mkl",
+            "--model_file", VGG_PATH, "--disable_check", "--scaling_args", SCALING,
+            "--ffmpeg_args", os.path.join(REF, "config", "ffmpeg-libx264.json"),
+            "--image_sizes", str(S), "--num_iters", "5", "--seed", "0", "--no_hist_match"] + list(extra)
+    old = sys.argv
+    sys.argv = argv
+    try:
+        return ref_config.get_args()
+    finally:
+        sys.argv = old
+
+
+def run_traj(S, N, opt, double, extra=(), model=VGG_PATH, net_cache={}):
+    args = get_args(extra, model=model, optimizer=opt, S=S, N=N)
+    content, style, init = synth.images(S)
+    key = (S, opt, double, tuple(extra), model)
+    ref_optim.set_model_args(args, S)
+    if key not in net_cache:
+        with quiet():
+            net, losses = ref_models.load_model(args)
+        if double:
+            net.double()
+        net_cache[key] = (net, losses)
+    net, losses = net_cache[key]
+    if double:
+        args.dtype = torch.DoubleTensor
+    with quiet():
+        out = ref_optim.optimize(content, [style], init.clone(), N, args, net, losses).detach()
+    return out
+
+
+def gen_traj():
+    print("[traj] optimizer trajectories (fp32 1-thread and fp64 arbiter)")
+    S = 64
+    res = {}
+    for opt, Ns in (("lbfgs", (1, 2, 3, 4, 5, 10, 20)), ("adam", (1, 5, 10, 20))):
+        for N in Ns:
+            for double in (False, True):
+                out = run_traj(S, N, opt, double)
+                key = f"{opt}_N{N}_{'f64' if double else 'f32'}"
+                res[key] = out.numpy().astype(np.float64 if double else np.float32)
+                init = synth.images(S)[2]
+                print(f"    {key}: moved {float((out.double() - init.double()).norm() / init.double().norm()):.4e}")
+    save(f"traj_vgg19_S{S}", **res)
+    # small history to exercise the L-BFGS ring eviction, and Adam with another lr
+    res = {}
+    for double in (False, True):
+        out = run_traj(32, 12, "lbfgs", double, extra=["--lbfgs_num_correction", "3"])
+        res[f"lbfgs_m3_N12_{'f64' if double else 'f32'}"] = out.numpy()
+        out = run_traj(32, 8, "adam", double, extra=["--learning_rate", "2.5"])
+        res[f"adam_lr2.5_N8_{'f64' if double else 'f32'}"] = out.numpy()
+    save("traj_vgg19_S32_variants", **res)
+
+
+def gen_nin():
+    print("[nin] NIN + covariance (BASELINE config 5 at small size)")
+    S = 128
+    extra = ["--style_layers", "relu1,relu3,relu5,relu7,relu9,relu11", "--content_layers", "relu8", "--use_covariance"]
+    content, style, init = synth.images(S)
+    args = get_args(extra, model=NIN_PATH, S=S)
+    out, net = single_feval(args, content, [style], init, want_feats=(3, 9))
+    for k, m in enumerate(net.style_losses[:3]):  # 96^2, 96^2, 256^2; the 384^2/1024^2 ones are bulky
+        out[f"style_target_{k}"] = m.target.numpy().copy()
+    save(f"feval_nin_S{S}_covariance", **out)
+    args = get_args(extra[:4], model=NIN_PATH, S=S)
+    out, net = single_feval(args, content, [style], init)
+    save(f"feval_nin_S{S}_gram", **out)
+    # odd size: exercises ceil-mode pooling with a partial last window
+    S2 = 99
+    content, style, init = synth.images(S2)
+    args = get_args(extra, model=NIN_PATH, S=S2)
+    out, net = single_feval(args, content, [style], init)
+    save(f"feval_nin_S{S2}_covariance", **out)
+    res = {}
+    for double in (False, True):
+        out = run_traj(S, 5, "adam", double, extra=extra, model=NIN_PATH)
+        res[f"adam_N5_{'f64' if double else 'f32'}"] = out.numpy()
+    save(f"traj_nin_S{S}", **res)
+
+
+def gen_hist():
+    print("[hist] utils.match_histogram via the harness-side symeig shim (SURVEY §8c)")
+    torch.symeig = lambda A, eigenvectors=True, upper=True: tuple(torch.linalg.eigh(A, UPLO="U" if upper else "L"))
+    g = torch.Generator().manual_seed(21)
+    target = torch.rand(1, 3, 24, 20, generator=g) * 255 - 120
+    src1 = torch.rand(1, 3, 16, 28, generator=g) * 200 - 90
+    src2 = torch.rand(1, 3, 18, 18, generator=g) * 120 - 30
+    res = {"target": target.numpy(), "src1": src1.numpy(), "src2": src2.numpy()}
+    for tag, srcs in (("one", [src1]), ("two", [src1, src2])):
+        torch.manual_seed(1234)
+        out = ref_utils.match_histogram(target.clone(), srcs, mode=True)
+        res[f"out_{tag}"] = out.numpy()
+        torch.manual_seed(1234)
+        out = ref_utils.match_histogram(target.clone(), srcs, mode="avg")
+        res[f"out_avg_{tag}"] = out.numpy()
+    res["out_off"] = ref_utils.match_histogram(target.clone(), [src1], mode=False).numpy()
+    save("match_histogram", **res)
+
+
+def gen_host():
+    print("[host] config defaults, net assembly dumps, scaling decisions")
+    host = {}
+
+    def ns_dump(args):
+        d = {}
+        for k, v in vars(args).items():
+            d[k] = v if isinstance(v, (int, float, str, bool, list, dict, type(None))) else repr(v)
+        return d
+
+    old_cwd = os.getcwd()
+    os.chdir(REF)  # default --ffmpeg_args / --scaling_args are relative paths
+    try:
+        for tag, argv in {
+            "defaults": ["--content", "a/b/cat.jpg", "--style", "x/s1.png", "y/s2.jpeg"],
+            "lists": ["--content", "c.png", "--style", "s.png", "--image_sizes", "128,256", "--num_iters", "7,5",
+                      "--style_blend_weights", "2,6", "--no_grad_norm", "--no_hist_match", "--gpu", "c"],
+            "gpu_multi": ["--content", "c.png", "--style", "s.png", "--gpu", "0,1", "--backend", "nn"],
+            "gpu_c_multi": ["--content", "c.png", "--style", "s.png", "--gpu", "c,0", "--backend", "mkl"],
+            "load_args_vid": ["--content", "v.mp4", "--style", "s.png", "--load_args", "config/args-vid.json",
+                              "--num_iters", "40,20,10,8,4"],
+        }.items():
+            sys.argv = ["style.py"] + argv
+            try:
+                host[f"args_{tag}"] = ns_dump(ref_config.get_args())
+            except Exception as e:  # pragma: no cover - recorded so the mirror can match the failure mode
+                host[f"args_{tag}"] = {"__error__": type(e).__name__, "__msg__": str(e)}
+            host[f"argv_{tag}"] = argv
+    finally:
+        os.chdir(old_cwd)
+    # set_model_args decisions with the stock scaling table
+    decisions = {}
+    for size in (256, 512, 1024, 1456, 1457, 2048, 2448, 2449, 3000, 3760, 5000, 6000):
+        for gpus in ("0", "0,1"):
+            a = types.SimpleNamespace(scaling_args=os.path.join(REF, "config", "scaling-img.json"), gpu=gpus,
+                                      model_file="vgg19", optimizer="lbfgs", multidevice=False)
+            ref_optim.set_model_args(a, size)
+            decisions[f"{size}|{gpus}"] = {k: v for k, v in vars(a).items() if k != "scaling_args"}
+    host["set_model_args"] = decisions
+    # assembled loss-network dumps
+    nets = {}
+    for tag, extra, model in (
+        ("default", [], VGG_PATH),
+        ("no_tv_temporal", ["--tv_weight", "0", "--temporal_weight", "0"], VGG_PATH),
+        ("conv_named", ["--content_layers", "conv2_2", "--style_layers", "conv1_1,relu3_1"], VGG_PATH),
+        ("deep", ["--content_layers", "relu5_2", "--style_layers", "relu5_4"], VGG_PATH),
+        ("nin", ["--style_layers", "relu1,relu3,relu5,relu7,relu9,relu11", "--content_layers", "relu8"], NIN_PATH),
+    ):
+        args = get_args(extra, model=model)
+        with quiet():
+            net, losses = ref_models.load_model(args)
+        mods = []
+        for m in net:
+            d = {"type": type(m).__name__, "name": getattr(m, "name", None)}
+            if isinstance(m, torch.nn.Conv2d):
+                d.update(cin=m.in_channels, cout=m.out_channels, k=list(m.kernel_size), stride=list(m.stride),
+                         pad=list(m.padding))
+            if isinstance(m, (torch.nn.MaxPool2d, torch.nn.AvgPool2d)):
+                d.update(k=m.kernel_size, stride=m.stride, pad=m.padding, ceil=m.ceil_mode)
+            if hasattr(m, "strength"):
+                d.update(strength=m.strength, normalize=getattr(m, "normalize", None))
+            mods.append(d)
+        nets[tag] = {"modules": mods, "losses": [m.name for m in losses],
+                     "content": [m.name for m in net.content_losses], "style": [m.name for m in net.style_losses],
+                     "tv": [m.name for m in net.tv_losses], "temporal": [m.name for m in net.temporal_losses]}
+    host["nets"] = nets
+    # L-BFGS eval counts: number of fevals for N iterations
+    counts = {}
+    for N in (1, 2, 3, 4, 5, 8):
+        args = get_args(S=32, N=N)
+        content, style, init = synth.images(32)
+        calls = [0]
+        ref_optim.set_model_args(args, 32)
+        with quiet():
+            net, losses = ref_models.load_model(args)
+        fwd = net.forward
+
+        def counting(x, fwd=fwd):
+            calls[0] += 1
+            return fwd(x)
+        net.forward = counting
+        with quiet():
+            ref_optim.optimize(content, [style], init.clone(), N, args, net, losses)
+        counts[str(N)] = calls[0] - 2  # minus the content and style capture passes
+    host["lbfgs_fevals"] = counts
+    counts = {}
+    for N in (1, 3):
+        args = get_args(S=32, N=N, optimizer="adam")
+        content, style, init = synth.images(32)
+        calls = [0]
+        with quiet():
+            net, losses = ref_models.load_model(args)
+        fwd = net.forward
+
+        def counting(x, fwd=fwd):
+            calls[0] += 1
+            return fwd(x)
+        net.forward = counting
+        with quiet():
+            ref_optim.optimize(content, [style], init.clone(), N, args, net, losses)
+        counts[str(N)] = calls[0] - 2
+    host["adam_fevals"] = counts
+    path = os.path.join(GOLD, "host_logic.json")
+    with open(path, "w") as f:
+        json.dump(host, f, indent=1, sort_keys=True, default=repr)
+    print(f"  wrote {os.path.relpath(path, REPO)}")
+
+
+GROUPS = {"feval": gen_feval, "traj": gen_traj, "nin": gen_nin, "hist": gen_hist, "host": gen_host}
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    want = sys.argv[1:] or ["all"]
+    if "all" in want:
+        want = list(GROUPS)
+    for gname in want:
+        GROUPS[gname]()
+    meta = {"torch": torch.__version__, "threads": 1, "numpy": np.__version__,
+            "weights_checksum_vgg19": {k: synth.checksum(v) for k, v in list(synth.vgg19_state_dict().items())[:4]}}
+    with open(os.path.join(GOLD, "META.json"), "w") as f:
+        json.dump(meta, f, indent=1)
