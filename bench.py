@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Benchmark of the image-optimisation hot path on MI355X.
+
+A "step" is one optimizer iteration of the reference's loop (reference optim.py:201-241): one function
+evaluation (VGG-19 forward, Gram/content/TV losses, backward to the pixels) plus one L-BFGS (or Adam) pixel
+update, on ONE synthetic 1024x1024 image per GPU (BASELINE.json metric: "optimizer iterations/sec at 1024x1024
+VGG-19").  With N GPUs every rank optimises its own image (independent frames, the natural shard axis), after
+one RCCL broadcast of the conv weights and style targets; there is no per-iteration collective (weak scaling).
+
+Before the timed region the L-BFGS history (100 pairs) is filled by running `history` real iterations, so the
+timed steps are steady-state iterations (the two-loop cost grows until the history is full).
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the MFMA implicit-GEMM convolution):
+algorithmic FLOPs per launch / average launch duration measured with HIP events on the launch stream, against
+the fp32 MFMA peak (157.3 TFLOP/s).  `cpu_baseline` times the CPU oracle on this host's cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [REPO, os.path.join(REPO, "maua-style_amd")]
+
+import torch  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+HBM_PEAK_GBS = 8000.0
+
+
+def algorithmic_work(S, history=100):
+    """FLOPs and bytes of one iteration at S x S (SURVEY.md Appendix B calculator, restated)."""
+    chans = [64, 64, "P", 128, 128, "P", 256, 256, 256, 256, "P", 512, 512, 512, 512, "P", 512]
+    names = ["conv1_1", "conv1_2", "pool1", "conv2_1", "conv2_2", "pool2", "conv3_1", "conv3_2", "conv3_3", "conv3_4",
+             "pool3", "conv4_1", "conv4_2", "conv4_3", "conv4_4", "pool4", "conv5_1"]
+    style, content = {"conv1_1", "conv2_1", "conv3_1", "conv4_1", "conv5_1"}, {"conv4_2"}
+    H = W = S
+    cin, macs, bf, bb, gram = 3, 0, 0, 0, 0
+    for n, c in zip(names, chans):
+        if c == "P":
+            bi, bo = cin * H * W * 4, cin * (H // 2) * (W // 2) * 4
+            bf += bi + bo
+            bb += bo + 2 * bi
+            H //= 2
+            W //= 2
+            continue
+        mac = 9 * cin * c * H * W
+        wb, ib, ob = (9 * cin * c + c) * 4, cin * H * W * 4, c * H * W * 4
+        macs += mac
+        bf += ib + wb + ob
+        bb += 2 * ob + wb + ib
+        if n in style:
+            gram += 2 * (2 * c * c * H * W)
+            bf += ob + c * c * 4
+            bb += ob + c * c * 4 + 2 * ob
+        if n in content:
+            bf += 2 * ob
+            bb += 4 * ob
+        cin = c
+    npx = 3 * S * S
+    return dict(flops=4 * macs + gram, bytes_feval=bf + bb, bytes_lbfgs=(4 * history + 10) * npx * 4)
+
+
+def cpu_baseline(S_full, optimizer):
+    """The CPU oracle (oracle/, a restatement of the reference's arithmetic on torch CPU ops) timed on this host:
+    a bounded sample at reduced size, scaled to S_full by the pixel ratio (the path is O(pixels))."""
+    import synth
+    from oracle import OracleNet, build_spec
+    from oracle.style_oracle import _LbfgsState, _lbfgs_step
+    import argparse as ap
+    cores = os.cpu_count() or 1
+    S = 256 if S_full >= 256 else S_full
+    cfg = ap.Namespace(model_file="vgg19", pooling="max", content_layers="relu4_2",
+                       style_layers="relu1_1,relu2_1,relu3_1,relu4_1,relu5_1", tv_weight=1e-3, temporal_weight=50.0,
+                       content_weight=5.0, style_weight=100.0, use_covariance=False, normalize_gradients=True,
+                       video_style_factor=100.0)
+    net = OracleNet(build_spec(cfg), synth.vgg19_state_dict())
+    content, style, init = synth.images(S)
+    net.capture_content(content)
+    net.capture_style([style], [1.0])
+    shape = init.shape
+    # thread count: MKL-DNN oversubscribes badly on many-core hosts; pick the fastest of a short sweep
+    best = (float("inf"), 1)
+    for k in sorted({min(cores, c) for c in (8, 16, 32, 64)}):
+        torch.set_num_threads(k)
+        t0 = time.perf_counter()
+        net.feval(init)
+        best = min(best, (time.perf_counter() - t0, k))
+    torch.set_num_threads(best[1])
+
+    def closure(x):
+        total, _, g = net.feval(x.reshape(shape))
+        return float(total), g.flatten()
+
+    iters = 4
+    st = _LbfgsState()
+    t0 = time.perf_counter()
+    _lbfgs_step(init.flatten().clone(), closure, st, iters, 100)
+    dt = time.perf_counter() - t0
+    scale = (S * S) / float(S_full * S_full)
+    return {"value": round(iters / dt * scale, 5), "unit": "iterations/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{iters} L-BFGS iterations of the CPU oracle at {S}x{S} in {dt:.1f} s, scaled by the pixel ratio "
+                      f"({S}^2/{S_full}^2) to {S_full}x{S_full}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--optimizer", default="lbfgs", choices=["lbfgs", "adam"])
+    ap.add_argument("--history", type=int, default=100)
+    ap.add_argument("--no_prefill", action="store_true", help="do not fill the L-BFGS history before timing")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--hip_graph", action="store_true", help="replay the function evaluation from a captured hipGraph")
+    a = ap.parse_args()
+
+    import config
+    import dist
+    import hip
+    import models
+    import optim
+    import synth
+
+    rank, local_rank, world = dist.init()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU implementation")
+    hip.lib()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    S = a.size
+
+    tmp = tempfile.mkdtemp(prefix="maua_bench_")
+    wfile = os.path.join(tmp, "vgg19_synth.pth")
+    torch.save(synth.vgg19_state_dict(), wfile)
+    scaling = os.path.join(tmp, "scaling.json")
+    with open(scaling, "w") as f:
+        json.dump({"100000": {"gpu": "0", "multidevice": False}}, f)
+    args = config.get_args(["--content", "c.png", "--style", "s.png", "--model_file", wfile, "--disable_check",
+                            "--scaling_args", scaling, "--optimizer", a.optimizer, "--image_sizes", str(S),
+                            "--num_iters", str(a.steps), "--seed", "0", "--no_hist_match", "--lbfgs_num_correction",
+                            str(a.history)])
+    args.hip_graph = a.hip_graph
+    optim.set_model_args(args, S)
+    net, losses = models.load_model(args)
+    dist.broadcast_network(net, src=0)  # one RCCL broadcast of the replica (no-op at N=1)
+
+    content, style, _ = synth.images(S)
+    init = synth.images(S, seed=100 + rank)[2]  # every rank optimises its own image
+    optim.set_content_targets(net, synth.images(S, seed=200 + rank)[0] if world > 1 else content, args)
+    if rank == 0:
+        optim.set_style_targets(net, [style], args)
+    dist.broadcast_style_targets(net, src=0)
+    for m in net.style_losses:
+        m.mode = "none"
+    for m in losses:
+        m.mode = "loss"
+
+    opt = optim.PixelOptimizer(net, losses, init, args)
+    prefill = 0 if (a.no_prefill or a.optimizer != "lbfgs") else a.history
+    for _ in range(prefill + a.warmup):
+        opt.step()
+    torch.cuda.synchronize()
+
+    timer = []
+    if opt.engine is not None and not a.hip_graph:
+        opt.engine.timer = timer
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        opt.step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = dist.max_over_ranks(time.perf_counter() - t0)
+    if opt.engine is not None:
+        opt.engine.timer = None
+
+    if rank != 0:
+        return
+    status = opt.state.status() if a.optimizer == "lbfgs" else {}
+    work = algorithmic_work(S, a.history)
+    ms = elapsed / a.steps * 1e3
+    # dominant kernel: the MFMA convolution (forward + backward-data launches)
+    conv = [(fl, e0.elapsed_time(e1)) for tag, fl, nb, e0, e1 in timer if tag.startswith("conv")]
+    roofline = None
+    if conv:
+        tot_fl, tot_ms = sum(c[0] for c in conv), sum(c[1] for c in conv)
+        achieved = tot_fl / (tot_ms * 1e-3) / 1e12
+        by_tag = {}
+        for tag, fl, nb, e0, e1 in timer:
+            d = by_tag.setdefault(tag, [0, 0.0, 0, 0])
+            d[0] += 1
+            d[1] += e0.elapsed_time(e1)
+            d[2] += fl
+            d[3] += nb
+        roofline = {"bound": "mfma", "kernel": "conv_mfma_kernel (fwd + bwd-data)", "achieved": round(achieved, 2),
+                    "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "traffic": None, "launches": len(conv), "avg_launch_ms": round(tot_ms / len(conv), 4),
+                    "flops_per_launch_avg": tot_fl / len(conv),
+                    "per_kernel_ms_per_step": {k: round(v[1] / a.steps, 4) for k, v in by_tag.items()},
+                    "per_kernel_tflops": {k: round(v[2] / (v[1] * 1e-3) / 1e12, 2) for k, v in by_tag.items() if v[1] > 0},
+                    "per_kernel_alg_gbs": {k: round(v[3] / (v[1] * 1e-3) / 1e9, 1) for k, v in by_tag.items() if v[1] > 0}}
+    out = {
+        "metric": "optimizer iterations/sec at 1024x1024 VGG-19" if S == 1024 else f"optimizer iterations/sec at {S}x{S} VGG-19",
+        "value": round(a.steps * world / elapsed, 4), "unit": "iterations/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{S}x{S} single-scale VGG-19 Gram style transfer, {a.optimizer.upper()}"
+                               f"{' history ' + str(a.history) + ' (full)' if prefill else ''}, one image per GPU, "
+                               "content 5 / style 100 / tv 1e-3, normalize_gradients, seeded synthetic weights and images",
+                   "image_size": S, "optimizer": a.optimizer, "lbfgs_history_len": status.get("history_len"),
+                   "parallelism": f"frames x{world} (replicas, one broadcast, no per-iteration collective)",
+                   "hip_graph": bool(a.hip_graph)},
+        "model_flops_per_step": work["flops"],
+        "whole_step": {"tflops": round(work["flops"] / (ms * 1e-3) / 1e12, 2),
+                       "frac_fp32_mfma_peak": round(work["flops"] / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                       "alg_gbs": round((work["bytes_feval"] + (work["bytes_lbfgs"] if a.optimizer == "lbfgs" else 0)) / (ms * 1e-3) / 1e9, 1),
+                       "frac_hbm_peak": round((work["bytes_feval"] + (work["bytes_lbfgs"] if a.optimizer == "lbfgs" else 0)) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        "roofline": roofline,
+    }
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(S, a.optimizer)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

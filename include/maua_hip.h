@@ -1,0 +1,138 @@
+/*
+ * maua_hip.h - C ABI of libmaua_hip.so: the MI355X (gfx950) kernels behind the maua-style
+ * image-optimisation hot path.
+ *
+ * The reference (JCBrouwer/maua-style) has no FFI layer: its boundary is the Python surface of
+ * optim.py / loss.py / models.py and every FLOP is a PyTorch op.  Each entry point below replaces
+ * the torch op(s) the reference issues at the cited lines (paths relative to the reference root).
+ * The host side (the Python modules in maua-style_amd/) binds these symbols with ctypes; see INTEGRATION.md for the
+ * stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every pointer is a caller-allocated DEVICE pointer (e.g. torch.Tensor.data_ptr() of a
+ *    contiguous fp32 ROCm tensor) unless a parameter says "host"; the library never allocates,
+ *    frees or retains caller memory;
+ *  - tensors are float32, NCHW, contiguous;
+ *  - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream); all work is enqueued
+ *    asynchronously on it, nothing synchronises, so calls can be captured into a hipGraph;
+ *  - return value: 0 = ok, <0 = invalid argument / unsupported shape (MAUA_E_*), >0 = hipError_t
+ *    of the failed launch; maua_last_error() gives a thread-local message;
+ *  - no global mutable state besides that message: thread-safe across streams;
+ *  - reductions are fixed-order (no float atomics): reruns are bit-identical, like the reference
+ *    at a fixed thread count.
+ */
+#ifndef MAUA_HIP_H
+#define MAUA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* maua_stream_t; /* hipStream_t */
+
+#define MAUA_OK 0
+#define MAUA_E_INVAL (-1)       /* null pointer, non-positive size, bad flag */
+#define MAUA_E_UNSUPPORTED (-2) /* shape outside what the kernels implement */
+#define MAUA_E_WORKSPACE (-3)   /* workspace too small */
+
+int maua_abi_version(void);
+const char* maua_last_error(void);
+
+/* ---- convolution: nn.Conv2d (+ nn.ReLU(inplace)) forward, models.py:129-130 (VGG), :83-110 (NIN);
+ *      backward-data = autograd of the same (optim.py:213), weights frozen (models.py:444) ---------- */
+
+/* Re-layout OIHW weights (state-dict order) into the two filter banks the kernels read:
+ *   wf[ky*KW+kx][ci][co] = w[co][ci][ky][kx]                      (forward)
+ *   wb[(KH-1-ky)*KW+(KW-1-kx)][co][ci] = w[co][ci][ky][kx]        (backward-data, stride 1)
+ * Each bank has cout*cin*kh*kw floats.  Either destination may be NULL. */
+int maua_conv_pack_filters(const float* w_oihw, float* wf, float* wb, int cout, int cin, int kh, int kw,
+                           maua_stream_t stream);
+
+/* y[n][co][oy][ox] = act( bias[co] + sum_{ci,ky,kx} x[n][ci][oy*s-p+ky][ox*s-p+kx] * w[co][ci][ky][kx] ) (+ y if accumulate)
+ *  wf: forward bank from maua_conv_pack_filters.  in_mask (nullable, same shape as x): x is read as
+ *  x * (in_mask > 0) - the fused threshold_backward of the ReLU in front of a backward-data pass.
+ *  bias nullable.  relu: 0/1.  accumulate: 0/1 (add into y instead of overwriting).
+ *  stride 1 with k in {1,3,5} runs on the fp32 MFMA path; other geometry on the direct path. */
+int maua_conv2d_fwd(const float* x, const float* in_mask, const float* wf, const float* bias, float* y, int n, int cin,
+                    int h, int w, int cout, int kh, int kw, int stride, int pad, int relu, int accumulate,
+                    maua_stream_t stream);
+
+/* gx = conv_transpose(gy * (mask > 0), w): gradient w.r.t. the conv input.  gy/out_mask: [n][cout][oh][ow] (mask nullable,
+ * it is the saved ReLU output of this conv), gx: [n][cin][h][w].  wb: backward bank (stride 1) or the OIHW weights
+ * themselves (stride > 1, direct path: pass w_oihw and wb = NULL). */
+int maua_conv2d_bwd_data(const float* gy, const float* out_mask, const float* wb, const float* w_oihw, float* gx, int n,
+                         int cin, int h, int w, int cout, int kh, int kw, int stride, int pad, int accumulate,
+                         maua_stream_t stream);
+
+/* ---- ReLU on its own (module path; the engine fuses it into the convs): models.py:130 ------------- */
+int maua_relu_fwd(float* x_inplace, int64_t count, maua_stream_t stream);
+int maua_relu_bwd(const float* gy, const float* y, float* gx, int64_t count, maua_stream_t stream);
+
+/* ---- pooling: nn.MaxPool2d / nn.AvgPool2d, models.py:119-123 (2x2 s2), :77-80 (3x3 s2 ceil) ------- */
+int maua_pool_out_size(int in, int k, int stride, int ceil_mode);
+/* mode: 0 = max (first maximum in scan order wins, NaN propagates), 1 = avg (divisor = window clipped to the input). */
+int maua_pool2d_fwd(const float* x, float* y, int n, int c, int h, int w, int k, int stride, int ceil_mode, int mode,
+                    maua_stream_t stream);
+/* gx[n][c][h][w] (overwritten): gather form, recomputes each window's argmax from x (no index tensor, no atomics). */
+int maua_pool2d_bwd(const float* gy, const float* x, float* gx, int n, int c, int h, int w, int k, int stride,
+                    int ceil_mode, int mode, maua_stream_t stream);
+
+/* ---- Gram / covariance matrix: loss.GramMatrix.forward, loss.py:67-91 (torch.mm at :91) ----------- */
+/* gram[C][C] = scale * Fc Fc^T with Fc = f[C][hw] (minus row means when `center` != 0, loss.py:87-89).
+ * row_mean_out (nullable unless center): receives the C row means.  Split-K over hw with a fixed-order reduction.
+ * workspace: maua_gram_workspace_bytes(C, hw) bytes. */
+size_t maua_gram_workspace_bytes(int c, int64_t hw);
+int maua_gram_fwd(const float* f, float* gram, float* row_mean_out, int c, int64_t hw, float scale, int center,
+                  void* workspace, size_t workspace_bytes, maua_stream_t stream);
+
+/* ---- MSE forward + backward in one pass: nn.MSELoss at loss.py:56 (content) and :154/:178 (style) - */
+/* loss_out[0] = loss_scale * sum((x - target)^2) ; grad (nullable) (+)= grad_scale * (x - target).
+ * Used for ContentLoss on feature maps (grad accumulates into the feature gradient) and for StyleLoss on C x C
+ * Gram matrices (grad = the matrix D fed to maua_gram_bwd).  workspace: maua_reduce_workspace_bytes(count). */
+size_t maua_reduce_workspace_bytes(int64_t count);
+int maua_mse_fwd_bwd(const float* x, const float* target, float* grad, int64_t count, float loss_scale, float grad_scale,
+                     int accumulate, float* loss_out, void* workspace, size_t workspace_bytes, maua_stream_t stream);
+
+/* Backward of the Gram loss into the feature map: gf[C][hw] (+)= D[C][C] (symmetric) * (f - mean) ;
+ * autograd of torch.mm(x, x.t()) at loss.py:91 with the MSE gradient D (scaled by the caller). */
+int maua_gram_bwd(const float* d_sym, const float* f, const float* row_mean, float* gf, int c, int64_t hw, int accumulate,
+                  void* workspace, size_t workspace_bytes, maua_stream_t stream);
+
+/* ---- total variation: loss.TVLoss.forward, loss.py:224-233, and its autograd ---------------------- */
+/* loss_out[0] = strength * (sum|dy| + sum|dx|); grad (+)= strength * d/dx.  workspace as for the MSE. */
+int maua_tv_fwd_bwd(const float* x, float* grad, int n, int c, int h, int w, float strength, int accumulate,
+                    float* loss_out, void* workspace, size_t workspace_bytes, maua_stream_t stream);
+
+/* ---- small vector helpers used by the host engine -------------------------------------------------- */
+int maua_fill(float* x, int64_t count, float value, maua_stream_t stream);
+int maua_axpy(float* y, const float* x, float alpha, int64_t count, maua_stream_t stream); /* y += alpha x */
+/* out[0] = sum_i in[i] over `count` device floats, fixed order (sums the per-module loss slots, optim.py:207-211). */
+int maua_sum_small(const float* in, int count, float* out, maua_stream_t stream);
+
+/* ---- Adam pixel update: torch.optim.Adam([pastiche], lr) as built at optim.py:192-196 ------------- */
+/* One step of the single-tensor update (betas 0.9/0.999, eps 1e-8 by default); `step` is 1-based. */
+int maua_adam_step(float* x, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, int step, float lr,
+                   float beta1, float beta2, float eps, maua_stream_t stream);
+
+/* ---- L-BFGS pixel update: torch.optim.LBFGS as configured at optim.py:180-191 --------------------- */
+/* Device-resident state: `state` is an opaque caller-allocated buffer of maua_lbfgs_state_bytes(count, history)
+ * bytes holding the (s, y) history slab [2*history][count], the previous gradient, the direction, the Gram matrix of
+ * the history and all scalars.  maua_lbfgs_init zeroes the bookkeeping (not the slab).
+ * maua_lbfgs_iterate consumes the gradient of the current x and moves x, replicating one trip of the loop in
+ * LBFGS.step without line search: first call d = -g, t = min(1, 1/|g|_1) * lr; later calls push the curvature pair when
+ * y.s > 1e-10, run the two-loop recursion (evaluated in the coefficient space of the stored vectors), t = lr; stop
+ * (x left untouched, status flag raised) when g.d > -tolerance_change.  No host synchronisation.
+ * maua_lbfgs_status copies {n_iter, history_len, stopped, last g.d, last t} (5 floats) to a device buffer. */
+size_t maua_lbfgs_state_bytes(int64_t count, int history);
+int maua_lbfgs_init(void* state, size_t state_bytes, int64_t count, int history, maua_stream_t stream);
+int maua_lbfgs_iterate(void* state, float* x, const float* grad, int64_t count, int history, float lr,
+                       float tolerance_change, maua_stream_t stream);
+int maua_lbfgs_status(const void* state, int64_t count, int history, float* out5, maua_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAUA_HIP_H */

@@ -1,0 +1,66 @@
+"""Compile csrc/*.hip into libmaua_hip.so (gfx950 code objects only, built in-tree).
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the resulting
+.so travels to the GPU box with the repo snapshot.
+"""
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmaua_hip.so")
+STAMP = os.path.join(HERE, "csrc", ".build_stamp")
+ARCH = "gfx950"
+
+
+def _sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _digest():
+    h = hashlib.sha256()
+    inc = os.path.join(os.path.dirname(HERE), "include", "maua_hip.h")
+    for p in _sources() + [os.path.join(CSRC, "common.hpp"), inc]:
+        with open(p, "rb") as f:
+            h.update(p.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=False):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read().strip() == dig:
+        return LIB
+    objs = []
+    objdir = os.path.join(HERE, "csrc", "build")
+    os.makedirs(objdir, exist_ok=True)
+    procs = []
+    for src in _sources():
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+        if verbose:
+            cmd.insert(4, "-Rpass-analysis=kernel-resource-usage")
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write(f"hipcc failed on {src}:\n{out}\n")
+        elif verbose and out:
+            sys.stderr.write(out)
+    if failed:
+        raise RuntimeError("libmaua_hip.so: compilation failed")
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(dig)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

@@ -1,0 +1,87 @@
+// Shared helpers for libmaua_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/maua_hip.h"
+
+namespace maua {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return MAUA_OK;
+}
+
+#define MAUA_REQUIRE(cond, code, ...)  \
+    do {                               \
+        if (!(cond)) {                 \
+            maua::set_error(__VA_ARGS__); \
+            return (code);             \
+        }                              \
+    } while (0)
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Sum over a workgroup of up to 1024 threads; result valid in thread 0.  `scratch` holds >= 16 doubles.
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = wave_sum(v);
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int i = 0; i < nw; ++i) r += scratch[i];
+    }
+    __syncthreads();
+    return r;
+}
+
+// Fixed-order second stage: one workgroup sums `n` per-block partials (doubles) in index order.
+__global__ void finish_sum_kernel(const double* __restrict__ partial, int n, float scale, float* __restrict__ out);
+
+// Arguments of the MFMA implicit-GEMM convolution (conv_mfma.hip); also used by gram.hip for gf += D F.
+struct ConvArgs {
+    const float* x;
+    const float* mask;  // nullable: x is read as x * (mask > 0)
+    const float* w;     // [KS*KS][Cin][Cout]
+    const float* bias;  // nullable, [Cout]
+    float* y;
+    int Cin, H, W, Cout, OH, OW, pad;
+    int tiles_x;
+    int relu, accumulate;
+};
+int conv_mfma_dispatch(const ConvArgs& a, int ks, int n, hipStream_t stream);
+int conv_direct_fwd(const float* x, const float* mask, const float* wf, const float* bias, float* y, int n, int cin, int h,
+                    int w, int cout, int oh, int ow, int kh, int kw, int stride, int pad, int relu, int accumulate,
+                    hipStream_t stream);
+int conv_direct_bwd(const float* gy, const float* mask, const float* w_oihw, float* gx, int n, int cin, int h, int w,
+                    int cout, int oh, int ow, int kh, int kw, int stride, int pad, int accumulate, hipStream_t stream);
+
+inline int reduce_blocks(int64_t count, int per_block) {
+    int64_t b = (count + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return (int)b;
+}
+
+}  // namespace maua

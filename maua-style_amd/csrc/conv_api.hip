@@ -1,0 +1,80 @@
+// C-ABI entry points of the convolution family: route to the MFMA implicit-GEMM path (stride 1, k in {1,3,5}) or
+// to the direct path (everything else).
+#include "common.hpp"
+
+using namespace maua;
+
+static inline bool mfma_geometry(int kh, int kw, int stride) {
+    return stride == 1 && kh == kw && (kh == 1 || kh == 3 || kh == 5);
+}
+
+extern "C" {
+
+int maua_conv2d_fwd(const float* x, const float* in_mask, const float* wf, const float* bias, float* y, int n, int cin,
+                    int h, int w, int cout, int kh, int kw, int stride, int pad, int relu, int accumulate,
+                    maua_stream_t stream) {
+    MAUA_REQUIRE(x && wf && y, MAUA_E_INVAL, "conv2d_fwd: null pointer");
+    MAUA_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0, MAUA_E_INVAL,
+                 "conv2d_fwd: bad dims n=%d cin=%d cout=%d h=%d w=%d k=%dx%d s=%d p=%d", n, cin, cout, h, w, kh, kw, stride,
+                 pad);
+    const int oh = (h + 2 * pad - kh) / stride + 1, ow = (w + 2 * pad - kw) / stride + 1;
+    MAUA_REQUIRE(h + 2 * pad >= kh && w + 2 * pad >= kw, MAUA_E_UNSUPPORTED, "conv2d_fwd: input %dx%d smaller than filter", h,
+                 w);
+    MAUA_REQUIRE((int64_t)h * w < (1ll << 31) && (int64_t)oh * ow < (1ll << 31), MAUA_E_UNSUPPORTED,
+                 "conv2d_fwd: plane too large");
+    if (mfma_geometry(kh, kw, stride)) {
+        ConvArgs a{};
+        a.x = x;
+        a.mask = in_mask;
+        a.w = wf;
+        a.bias = bias;
+        a.y = y;
+        a.Cin = cin;
+        a.H = h;
+        a.W = w;
+        a.Cout = cout;
+        a.OH = oh;
+        a.OW = ow;
+        a.pad = pad;
+        a.relu = relu;
+        a.accumulate = accumulate;
+        return conv_mfma_dispatch(a, kh, n, (hipStream_t)stream);
+    }
+    return conv_direct_fwd(x, in_mask, wf, bias, y, n, cin, h, w, cout, oh, ow, kh, kw, stride, pad, relu, accumulate,
+                           (hipStream_t)stream);
+}
+
+int maua_conv2d_bwd_data(const float* gy, const float* out_mask, const float* wb, const float* w_oihw, float* gx, int n,
+                         int cin, int h, int w, int cout, int kh, int kw, int stride, int pad, int accumulate,
+                         maua_stream_t stream) {
+    MAUA_REQUIRE(gy && gx && (wb || w_oihw), MAUA_E_INVAL, "conv2d_bwd_data: null pointer");
+    MAUA_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0, MAUA_E_INVAL,
+                 "conv2d_bwd_data: bad dims");
+    const int oh = (h + 2 * pad - kh) / stride + 1, ow = (w + 2 * pad - kw) / stride + 1;
+    MAUA_REQUIRE(h + 2 * pad >= kh && w + 2 * pad >= kw, MAUA_E_UNSUPPORTED, "conv2d_bwd_data: input smaller than filter");
+    if (mfma_geometry(kh, kw, stride) && wb) {
+        // gx = conv(gy masked, flipped/transposed bank) with padding k-1-p: a forward conv over the gradient
+        ConvArgs a{};
+        a.x = gy;
+        a.mask = out_mask;
+        a.w = wb;
+        a.bias = nullptr;
+        a.y = gx;
+        a.Cin = cout;
+        a.H = oh;
+        a.W = ow;
+        a.Cout = cin;
+        a.OH = h;
+        a.OW = w;
+        a.pad = kh - 1 - pad;
+        a.relu = 0;
+        a.accumulate = accumulate;
+        MAUA_REQUIRE(a.pad >= 0, MAUA_E_UNSUPPORTED, "conv2d_bwd_data: pad %d > k-1", pad);
+        return conv_mfma_dispatch(a, kh, n, (hipStream_t)stream);
+    }
+    MAUA_REQUIRE(w_oihw, MAUA_E_INVAL, "conv2d_bwd_data: the direct path needs the OIHW weights");
+    return conv_direct_bwd(gy, out_mask, w_oihw, gx, n, cin, h, w, cout, oh, ow, kh, kw, stride, pad, accumulate,
+                           (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,229 @@
+// Gram / covariance matrix G = scale * Fc Fc^T of a feature map F[C][HW] (reference loss.py:67-91) as a symmetric
+// rank-HW update on the fp32 matrix cores, and its backward gf (+)= D (F - mean) through the 1x1 path of
+// conv_mfma.hip.
+//
+// Forward: the (C/64)(C/64+1)/2 upper-triangular 64x64 tiles are split along HW over `ksplit` workgroups each
+// (split-K); every workgroup writes its partial tile to a slab and a second kernel adds the slabs in index order,
+// scales, and mirrors the result - a deterministic reduction without float atomics.
+#include "common.hpp"
+
+namespace maua {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+
+constexpr int GT = 64;       // tile edge (channels)
+constexpr int GK = 64;       // pixels per stage
+constexpr int GLD = GK + 1;  // padded LDS row: lanes of one 32-group hit distinct banks
+
+__global__ void __launch_bounds__(256)
+row_mean_kernel(const float* __restrict__ f, float* __restrict__ mean, int64_t HW) {
+    __shared__ double scratch[16];
+    const float* row = f + (int64_t)blockIdx.x * HW;
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < HW; i += blockDim.x) acc += (double)row[i];
+    acc = block_sum(acc, scratch);
+    if (threadIdx.x == 0) mean[blockIdx.x] = (float)(acc / (double)HW);
+}
+
+__global__ void __launch_bounds__(256)
+gram_partial_kernel(const float* __restrict__ f, const float* __restrict__ mean, float* __restrict__ partial, int C,
+                    int64_t HW, int ksplit, int64_t chunk) {
+    __shared__ float At[GT * GLD];
+    __shared__ float Bt[GT * GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i32 = lane & 31, half = lane >> 5;
+    const int wi = wave >> 1, wj = wave & 1;
+    // decode the upper-triangular tile pair
+    int pair = blockIdx.x, ti = 0;
+    const int ntile = (C + GT - 1) / GT;
+    while (pair >= ntile - ti) {
+        pair -= ntile - ti;
+        ++ti;
+    }
+    const int tj = ti + pair;
+    const bool diag = ti == tj;
+    const int ks = blockIdx.y;
+    const int64_t p_begin = (int64_t)ks * chunk;
+    const int64_t p_end = min(HW, p_begin + chunk);
+
+    constexpr int NL = GT * GK / 256;  // 16 loads per tile per thread
+    float ra[NL], rb[NL];
+    auto load_stage = [&](int64_t p0) {
+#pragma unroll
+        for (int q = 0; q < NL; ++q) {
+            const int e = tid + 256 * q;
+            const int r = e / GK, c = e - r * GK;
+            const int64_t pp = p0 + c;
+            const int rowa = ti * GT + r, rowb = tj * GT + r;
+            float va = 0.f, vb = 0.f;
+            if (pp < p_end) {
+                if (rowa < C) va = f[(int64_t)rowa * HW + pp] - (mean ? mean[rowa] : 0.f);
+                if (!diag && rowb < C) vb = f[(int64_t)rowb * HW + pp] - (mean ? mean[rowb] : 0.f);
+            }
+            ra[q] = va;
+            rb[q] = vb;
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int q = 0; q < NL; ++q) {
+            const int e = tid + 256 * q;
+            const int r = e / GK, c = e - r * GK;
+            At[r * GLD + c] = ra[q];
+            if (!diag) Bt[r * GLD + c] = rb[q];
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    if (p_begin < p_end) {
+        load_stage(p_begin);
+        for (int64_t p0 = p_begin; p0 < p_end; p0 += GK) {
+            __syncthreads();  // previous stage fully consumed
+            store_stage();
+            __syncthreads();
+            if (p0 + GK < p_end) load_stage(p0 + GK);
+            const float* bt = diag ? At : Bt;
+#pragma unroll
+            for (int kk = 0; kk < GK / 2; ++kk) {
+                const float a = At[(wi * 32 + i32) * GLD + 2 * kk + half];
+                const float b = bt[(wj * 32 + i32) * GLD + 2 * kk + half];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+        }
+    }
+    float* out = partial + ((int64_t)blockIdx.x * ksplit + ks) * (GT * GT);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        out[row * GT + wj * 32 + i32] = acc[r];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+gram_finish_kernel(const float* __restrict__ partial, float* __restrict__ gram, int C, int ksplit, float scale) {
+    // grid = (tile pairs, 16): every thread owns ONE element of the 64x64 tile and adds its `ksplit` slab values in
+    // index order (fixed order -> deterministic); consecutive threads read consecutive addresses of each slab.
+    int pair = blockIdx.x, ti = 0;
+    const int ntile = (C + GT - 1) / GT;
+    while (pair >= ntile - ti) {
+        pair -= ntile - ti;
+        ++ti;
+    }
+    const int tj = ti + pair;
+    const float* base = partial + (int64_t)blockIdx.x * ksplit * (GT * GT);
+    const int e = blockIdx.y * 256 + threadIdx.x;
+    double sd = 0.0;  // up to ~800 slabs: fp64 keeps the split-K sum exact to fp32 rounding
+    int k = 0;
+    for (; k + 4 <= ksplit; k += 4) {
+        const float v0 = base[(int64_t)(k + 0) * (GT * GT) + e], v1 = base[(int64_t)(k + 1) * (GT * GT) + e];
+        const float v2 = base[(int64_t)(k + 2) * (GT * GT) + e], v3 = base[(int64_t)(k + 3) * (GT * GT) + e];
+        sd += (double)v0;
+        sd += (double)v1;
+        sd += (double)v2;
+        sd += (double)v3;
+    }
+    for (; k < ksplit; ++k) sd += (double)base[(int64_t)k * (GT * GT) + e];
+    const float s = (float)(sd * (double)scale);
+    const int gi = ti * GT + e / GT, gj = tj * GT + e % GT;
+    if (gi < C && gj < C) {
+        gram[(int64_t)gi * C + gj] = s;
+        if (ti != tj) gram[(int64_t)gj * C + gi] = s;
+    }
+}
+
+// bias[c] = - sum_k D[k][c] * mean[k]   (the centering term of gf = D (F - mean 1^T))
+__global__ void center_bias_kernel(const float* __restrict__ d, const float* __restrict__ mean, float* __restrict__ bias,
+                                   int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int k = 0; k < C; ++k) s = fmaf(d[(int64_t)k * C + c], mean[k], s);
+    bias[c] = -s;
+}
+
+static void gram_plan(int c, int64_t hw, int* npairs, int* ksplit, int64_t* chunk) {
+    const int ntile = (c + GT - 1) / GT;
+    *npairs = ntile * (ntile + 1) / 2;
+    int64_t want = (768 + *npairs - 1) / *npairs;
+    const int64_t stages = (hw + GK - 1) / GK;
+    if (want > stages) want = stages;
+    if (want < 1) want = 1;
+    int64_t ch = ((hw + want - 1) / want + GK - 1) / GK * GK;
+    *chunk = ch;
+    *ksplit = (int)((hw + ch - 1) / ch);
+}
+
+}  // namespace maua
+
+using namespace maua;
+
+extern "C" {
+
+size_t maua_gram_workspace_bytes(int c, int64_t hw) {
+    if (c <= 0 || hw <= 0) return 0;
+    int npairs, ksplit;
+    int64_t chunk;
+    gram_plan(c, hw, &npairs, &ksplit, &chunk);
+    return (size_t)npairs * ksplit * GT * GT * sizeof(float) + (size_t)((c + 63) / 64 * 64) * sizeof(float);
+}
+
+int maua_gram_fwd(const float* f, float* gram, float* row_mean_out, int c, int64_t hw, float scale, int center,
+                  void* workspace, size_t workspace_bytes, maua_stream_t stream) {
+    MAUA_REQUIRE(f && gram && workspace && c > 0 && hw > 0, MAUA_E_INVAL, "gram_fwd: bad args");
+    MAUA_REQUIRE(!center || row_mean_out, MAUA_E_INVAL, "gram_fwd: center needs row_mean_out");
+    MAUA_REQUIRE(workspace_bytes >= maua_gram_workspace_bytes(c, hw), MAUA_E_WORKSPACE, "gram_fwd: workspace %zu < %zu",
+                 workspace_bytes, maua_gram_workspace_bytes(c, hw));
+    int npairs, ksplit;
+    int64_t chunk;
+    gram_plan(c, hw, &npairs, &ksplit, &chunk);
+    hipStream_t s = (hipStream_t)stream;
+    if (center) {
+        hipLaunchKernelGGL(row_mean_kernel, dim3(c), dim3(256), 0, s, f, row_mean_out, hw);
+        int rc = check_launch("row_mean_kernel");
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(gram_partial_kernel, dim3(npairs, ksplit), dim3(256), 0, s, f, center ? row_mean_out : nullptr,
+                       (float*)workspace, c, hw, ksplit, chunk);
+    int rc = check_launch("gram_partial_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(gram_finish_kernel, dim3(npairs, GT * GT / 256), dim3(256), 0, s, (const float*)workspace, gram, c, ksplit, scale);
+    return check_launch("gram_finish_kernel");
+}
+
+int maua_gram_bwd(const float* d_sym, const float* f, const float* row_mean, float* gf, int c, int64_t hw, int accumulate,
+                  void* workspace, size_t workspace_bytes, maua_stream_t stream) {
+    MAUA_REQUIRE(d_sym && f && gf && c > 0 && hw > 0, MAUA_E_INVAL, "gram_bwd: bad args");
+    MAUA_REQUIRE(hw < (1ll << 31), MAUA_E_UNSUPPORTED, "gram_bwd: plane too large");
+    float* bias = nullptr;
+    if (row_mean) {
+        MAUA_REQUIRE(workspace && workspace_bytes >= (size_t)c * sizeof(float), MAUA_E_WORKSPACE,
+                     "gram_bwd: workspace too small for the centering bias");
+        bias = (float*)workspace;
+        hipLaunchKernelGGL(center_bias_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_sym, row_mean,
+                           bias, c);
+        int rc = check_launch("center_bias_kernel");
+        if (rc) return rc;
+    }
+    ConvArgs a{};
+    a.x = f;
+    a.mask = nullptr;
+    a.w = d_sym;  // symmetric: [k][c] layout == [c][k]
+    a.bias = bias;
+    a.y = gf;
+    a.Cin = c;
+    a.Cout = c;
+    a.H = 1;
+    a.W = (int)hw;
+    a.OH = 1;
+    a.OW = (int)hw;
+    a.pad = 0;
+    a.relu = 0;
+    a.accumulate = accumulate;
+    return conv_mfma_dispatch(a, 1, 1, (hipStream_t)stream);
+}
+
+}  // extern "C"

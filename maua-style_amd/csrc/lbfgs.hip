@@ -1,0 +1,435 @@
+// Device-resident L-BFGS for the pixel update (torch.optim.LBFGS as configured at reference optim.py:180-191:
+// lr 1, no line search, history 100, tolerances -1).
+//
+// The two-loop recursion of torch/optim/lbfgs.py walks the history sequentially: ~4m dependent dot/axpy launches and
+// 4-5 host synchronisations per iteration.  Here the same recursion is evaluated in the coefficient space of the
+// stored vectors ("vector-free" form): with the basis B = [s_0..s_m, y_0..y_m, g] and its Gram matrix M = B^T B,
+// every dot product of the recursion is a row of M times the coefficient vector, so one iteration needs
+//   1. ONE sweep over the history slab that (a) forms the new pair y = g - g_prev, s = t*d exactly as the reference
+//      does (fp32, elementwise) and (b) computes the dots of every stored vector with (s, y, g)   [lbfgs_pair_dots]
+//   2. a fixed-order reduction of the per-workgroup partials                                        [lbfgs_finish_dots]
+//   3. the recursion on (2m+3) coefficients in fp64 by one wave, incl. the y.s > 1e-10 test, the ring
+//      update, H_diag = ys/yy, t, g.d and the stop test g.d > -tolerance_change                     [lbfgs_coeffs]
+//   4. ONE more sweep: d = B * coeff, x += t*d                                                      [lbfgs_combine]
+// = 2 passes over the slab (the algorithmic 4m*n*4 bytes), 4 launches, no host sync, no float atomics.
+#include "common.hpp"
+
+namespace maua {
+
+struct LbfgsHeader {
+    int n_iter;     // completed calls of iterate
+    int len;        // pairs in the ring
+    int head;       // physical slot of the oldest pair
+    int stopped;    // raised by the g.d test; iterate() becomes a no-op for x
+    int cand;       // physical slot the next pair is written to (always free: the ring has history+1 slots)
+    int pad0;
+    float t;        // step length of the LAST move (s = t*d)
+    float gtd;
+    double h_diag;
+    double reserved[4];
+};
+
+constexpr int LB_EPT = 8;             // elements per thread in the sweeps
+constexpr int LB_WG = 256 * LB_EPT;   // elements per workgroup
+
+struct LbfgsLayout {
+    int m1, nb_ids, nwg;
+    size_t off_coef, off_dots, off_M, off_partial, off_gprev, off_d, off_S, off_Y, total;
+};
+
+static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static LbfgsLayout lbfgs_layout(int64_t count, int history) {
+    LbfgsLayout L;
+    L.m1 = history + 1;
+    L.nb_ids = 2 * L.m1 + 1;
+    L.nwg = (int)((count + LB_WG - 1) / LB_WG);
+    size_t o = align256(sizeof(LbfgsHeader));
+    L.off_coef = o;
+    o = align256(o + sizeof(float) * L.nb_ids);
+    L.off_dots = o;
+    o = align256(o + sizeof(double) * 4 * L.nb_ids);
+    L.off_M = o;
+    o = align256(o + sizeof(double) * (size_t)L.nb_ids * L.nb_ids);
+    L.off_partial = o;
+    o = align256(o + sizeof(float) * 4 * (size_t)L.nb_ids * L.nwg);
+    L.off_gprev = o;
+    o = align256(o + sizeof(float) * count);
+    L.off_d = o;
+    o = align256(o + sizeof(float) * count);
+    L.off_S = o;
+    o = align256(o + sizeof(float) * count * L.m1);
+    L.off_Y = o;
+    o = align256(o + sizeof(float) * count * L.m1);
+    L.total = o;
+    return L;
+}
+
+__global__ void lbfgs_init_kernel(LbfgsHeader* h, double* M, int nb_ids, float* coef) {
+    const int64_t tot = (int64_t)nb_ids * nb_ids;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) M[i] = 0.0;
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < nb_ids; i += blockDim.x) coef[i] = 0.f;
+        if (threadIdx.x == 0) {
+            h->n_iter = 0;
+            h->len = 0;
+            h->head = 0;
+            h->stopped = 0;
+            h->cand = 0;
+            h->pad0 = 0;
+            h->t = 0.f;
+            h->gtd = 0.f;
+            h->h_diag = 1.0;
+        }
+    }
+}
+
+__device__ __forceinline__ void wave_reduce3_store(float a, float b, float c, float* dst, int lane) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_down(a, off, 64);
+        b += __shfl_down(b, off, 64);
+        c += __shfl_down(c, off, 64);
+    }
+    if (lane == 0) {
+        dst[0] = a;
+        dst[1] = b;
+        dst[2] = c;
+    }
+}
+
+// Sweep 1.  ids: s-slot p -> p, y-slot p -> m1 + p, g -> 2*m1.  partial[wg][id][4] = per-workgroup dots of vector id
+// with (s_new, y_new, g) and, for id == g only, sum|g| in the 4th slot.
+__global__ void __launch_bounds__(256)
+lbfgs_pair_dots_kernel(const LbfgsHeader* __restrict__ hdr, const float* __restrict__ g, float* __restrict__ g_prev,
+                       const float* __restrict__ d, float* __restrict__ S, float* __restrict__ Y,
+                       float* __restrict__ partial, int64_t n, int m1) {
+    extern __shared__ float lds[];  // [4 waves][nb_ids][4]
+    const int nb_ids = 2 * m1 + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 4 * nb_ids * 4; i += 256) lds[i] = 0.f;
+    __syncthreads();
+    float* mine = lds + (size_t)wave * nb_ids * 4;
+
+    const bool first = hdr->n_iter == 0;
+    const int cand = hdr->cand, len = hdr->len, head = hdr->head;
+    const float t = hdr->t;
+    const int64_t base = (int64_t)blockIdx.x * LB_WG + tid;
+    float gv[LB_EPT], sv[LB_EPT], yv[LB_EPT];
+#pragma unroll
+    for (int k = 0; k < LB_EPT; ++k) {
+        const int64_t e = base + 256 * k;
+        gv[k] = sv[k] = yv[k] = 0.f;
+        if (e < n) {
+            gv[k] = g[e];
+            if (!first) {
+                yv[k] = gv[k] - g_prev[e];  // y = flat_grad.sub(prev_flat_grad)
+                sv[k] = d[e] * t;           // s = d.mul(t)
+                S[(int64_t)cand * n + e] = sv[k];
+                Y[(int64_t)cand * n + e] = yv[k];
+            }
+            g_prev[e] = gv[k];
+        }
+    }
+    // stored pairs
+    for (int i = 0; i < len; ++i) {
+        const int p = (head + i) % m1;
+        const float* sp = S + (int64_t)p * n;
+        const float* yp = Y + (int64_t)p * n;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < LB_EPT; ++k) {
+            const int64_t e = base + 256 * k;
+            if (e < n) {
+                const float s_ = sp[e], y_ = yp[e];
+                a0 = fmaf(s_, sv[k], a0);
+                a1 = fmaf(s_, yv[k], a1);
+                a2 = fmaf(s_, gv[k], a2);
+                b0 = fmaf(y_, sv[k], b0);
+                b1 = fmaf(y_, yv[k], b1);
+                b2 = fmaf(y_, gv[k], b2);
+            }
+        }
+        wave_reduce3_store(a0, a1, a2, mine + 4 * p, lane);
+        wave_reduce3_store(b0, b1, b2, mine + 4 * (m1 + p), lane);
+    }
+    // the candidate pair and g itself, from registers
+    {
+        float ss = 0.f, sy = 0.f, sg = 0.f, yy = 0.f, yg = 0.f, gg = 0.f, g1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < LB_EPT; ++k) {
+            ss = fmaf(sv[k], sv[k], ss);
+            sy = fmaf(sv[k], yv[k], sy);
+            sg = fmaf(sv[k], gv[k], sg);
+            yy = fmaf(yv[k], yv[k], yy);
+            yg = fmaf(yv[k], gv[k], yg);
+            gg = fmaf(gv[k], gv[k], gg);
+            g1 += fabsf(gv[k]);
+        }
+        wave_reduce3_store(ss, sy, sg, mine + 4 * cand, lane);
+        wave_reduce3_store(sy, yy, yg, mine + 4 * (m1 + cand), lane);
+        wave_reduce3_store(sg, yg, gg, mine + 4 * (2 * m1), lane);
+        g1 = wave_sum(g1);
+        if (lane == 0) mine[4 * (2 * m1) + 3] = g1;
+    }
+    __syncthreads();
+    float* out = partial + (size_t)blockIdx.x * nb_ids * 4;
+    for (int i = tid; i < nb_ids * 4; i += 256)
+        out[i] = (lds[i] + lds[nb_ids * 4 + i]) + (lds[2 * nb_ids * 4 + i] + lds[3 * nb_ids * 4 + i]);
+}
+
+// One workgroup per id: dots[id][c] = sum over workgroups of partial[wg][id][c], fixed order, fp64.
+__global__ void __launch_bounds__(256)
+lbfgs_finish_dots_kernel(const float* __restrict__ partial, double* __restrict__ dots, int nwg, int nb_ids) {
+    __shared__ double scratch[16];
+    const int id = blockIdx.x;
+    double a[4] = {0, 0, 0, 0};
+    for (int w = threadIdx.x; w < nwg; w += blockDim.x) {
+        const float* p = partial + ((size_t)w * nb_ids + id) * 4;
+        a[0] += p[0];
+        a[1] += p[1];
+        a[2] += p[2];
+        a[3] += p[3];
+    }
+    for (int c = 0; c < 4; ++c) {
+        const double v = block_sum(a[c], scratch);
+        if (threadIdx.x == 0) dots[id * 4 + c] = v;
+    }
+}
+
+// The recursion in coefficient space, one wave.  delta lives in LDS (fp64); M rows are read from global memory.
+__global__ void __launch_bounds__(64)
+lbfgs_coeffs_kernel(LbfgsHeader* __restrict__ hdr, const double* __restrict__ dots, double* __restrict__ M,
+                    float* __restrict__ coef, int m1, int history, float lr, float tol_change) {
+    extern __shared__ double sh[];  // delta[nb_ids], alpha[m1]
+    const int nb_ids = 2 * m1 + 1, gid = 2 * m1;
+    double* delta = sh;
+    double* alpha = sh + nb_ids;
+    const int lane = threadIdx.x;
+    int len = hdr->len, head = hdr->head, cand = hdr->cand;
+    const bool first = hdr->n_iter == 0;
+    double h_diag = hdr->h_diag;
+    if (hdr->stopped) return;
+
+    // 1. curvature test and ring update (lbfgs.py: `if ys > 1e-10`)
+    const double ys = dots[(m1 + cand) * 4 + 0];  // y_new . s_new
+    const double yy = dots[(m1 + cand) * 4 + 1];
+    const bool commit = !first && (float)ys > 1e-10f;
+    if (commit) {
+        if (len == history) head = (head + 1) % m1;  // drop the oldest
+        else ++len;
+        h_diag = (double)((float)ys / (float)yy);
+    }
+    // 2. refresh M: columns of s_new / y_new (when committed) and of g
+    for (int i = lane; i < nb_ids; i += 64) {
+        const double ds = dots[i * 4 + 0], dy = dots[i * 4 + 1], dg = dots[i * 4 + 2];
+        if (commit) {
+            M[(size_t)i * nb_ids + cand] = ds;
+            M[(size_t)cand * nb_ids + i] = ds;
+            M[(size_t)i * nb_ids + m1 + cand] = dy;
+            M[(size_t)(m1 + cand) * nb_ids + i] = dy;
+        }
+        M[(size_t)i * nb_ids + gid] = dg;
+        M[(size_t)gid * nb_ids + i] = dg;
+        delta[i] = 0.0;
+    }
+    __syncthreads();
+    __threadfence_block();
+    if (lane == 0) delta[gid] = -1.0;  // q = -g
+    __syncthreads();
+
+    // Rows of M do not depend on delta, so the row (and rho) of step i+1 is fetched while step i is reduced:
+    // the dependent chain per step is one wave reduction + one LDS update, not a global-memory round trip.
+    constexpr int NQ = 8;  // nb_ids <= 512  (history <= 254)
+    auto load_row = [&](int row, int rho_row, int rho_col, double (&r)[NQ], double& rho_den) {
+        const double* mr = M + (size_t)row * nb_ids;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int jdx = lane + 64 * q;
+            r[q] = jdx < nb_ids ? mr[jdx] : 0.0;
+        }
+        rho_den = M[(size_t)rho_row * nb_ids + rho_col];
+    };
+    auto dot_row = [&](const double (&r)[NQ]) {
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int jdx = lane + 64 * q;
+            if (jdx < nb_ids) acc += delta[jdx] * r[q];
+        }
+        acc = wave_sum(acc);
+        return __shfl(acc, 0, 64);
+    };
+
+    double cur[NQ], nxt[NQ], den_cur = 1.0, den_nxt = 1.0;
+    if (!first && len > 0) {
+        {
+            const int p = (head + len - 1) % m1;
+            load_row(p, m1 + p, p, cur, den_cur);
+        }
+        for (int i = len - 1; i >= 0; --i) {  // newest -> oldest
+            const int p = (head + i) % m1;
+            if (i > 0) {
+                const int pn = (head + i - 1) % m1;
+                load_row(pn, m1 + pn, pn, nxt, den_nxt);
+            } else {
+                const int pn = head % m1;  // first row of the second loop: y_oldest
+                load_row(m1 + pn, m1 + pn, pn, nxt, den_nxt);
+            }
+            const double al = dot_row(cur) * (1.0 / den_cur);  // al[i] = old_stps[i].dot(q) * ro[i]
+            if (lane == 0) {
+                alpha[i] = al;
+                delta[m1 + p] -= al;  // q.add_(old_dirs[i], alpha=-al[i])
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) cur[q] = nxt[q];
+            den_cur = den_nxt;
+        }
+    }
+    if (!first) {
+        for (int jdx = lane; jdx < nb_ids; jdx += 64) delta[jdx] *= h_diag;  // r = q * H_diag
+        __syncthreads();
+        for (int i = 0; i < len; ++i) {  // oldest -> newest
+            const int p = (head + i) % m1;
+            if (i + 1 < len) {
+                const int pn = (head + i + 1) % m1;
+                load_row(m1 + pn, m1 + pn, pn, nxt, den_nxt);
+            }
+            const double be = dot_row(cur) * (1.0 / den_cur);  // be_i = old_dirs[i].dot(r) * ro[i]
+            if (lane == 0) delta[p] += alpha[i] - be;          // r.add_(old_stps[i], alpha=al[i]-be_i)
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) cur[q] = nxt[q];
+            den_cur = den_nxt;
+        }
+    }
+    double gden;
+    load_row(gid, gid, gid, cur, gden);
+    const double gtd = dot_row(cur);  // g . d
+    for (int jdx = lane; jdx < nb_ids; jdx += 64) coef[jdx] = (float)delta[jdx];
+    if (lane == 0) {
+        float t = lr;
+        if (first) {
+            const double g1 = dots[gid * 4 + 3];
+            const float inv = (float)(1.0 / g1);
+            t = (inv < 1.f ? inv : 1.f) * lr;  // min(1., 1./|g|_1) * lr
+        }
+        hdr->len = len;
+        hdr->head = head;
+        hdr->cand = (head + len) % m1;  // next free slot
+        hdr->h_diag = h_diag;
+        hdr->gtd = (float)gtd;
+        hdr->t = t;
+        if ((float)gtd > -tol_change) hdr->stopped = 1;  // `if gtd > -tolerance_change: break`
+        hdr->n_iter = hdr->n_iter + 1;
+    }
+}
+
+// Sweep 2: d = sum_id coef[id] * b_id ; x += t * d unless stopped.
+__global__ void __launch_bounds__(256)
+lbfgs_combine_kernel(const LbfgsHeader* __restrict__ hdr, const float* __restrict__ coef, const float* __restrict__ g,
+                     const float* __restrict__ S, const float* __restrict__ Y, float* __restrict__ d, float* __restrict__ x,
+                     int64_t n, int m1) {
+    const int len = hdr->len, head = hdr->head, stopped = hdr->stopped;
+    const float t = hdr->t;
+    const int64_t base = (int64_t)blockIdx.x * LB_WG + threadIdx.x;
+    float acc[LB_EPT];
+    const float cg = coef[2 * m1];
+#pragma unroll
+    for (int k = 0; k < LB_EPT; ++k) {
+        const int64_t e = base + 256 * k;
+        acc[k] = e < n ? cg * g[e] : 0.f;
+    }
+    for (int i = 0; i < len; ++i) {
+        const int p = (head + i) % m1;
+        const float cs = coef[p], cy = coef[m1 + p];
+        const float* sp = S + (int64_t)p * n;
+        const float* yp = Y + (int64_t)p * n;
+#pragma unroll
+        for (int k = 0; k < LB_EPT; ++k) {
+            const int64_t e = base + 256 * k;
+            if (e < n) acc[k] = fmaf(cy, yp[e], fmaf(cs, sp[e], acc[k]));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < LB_EPT; ++k) {
+        const int64_t e = base + 256 * k;
+        if (e < n) {
+            d[e] = acc[k];
+            if (!stopped) x[e] = fmaf(t, acc[k], x[e]);  // p.add_(d, alpha=t)
+        }
+    }
+}
+
+__global__ void lbfgs_status_kernel(const LbfgsHeader* __restrict__ hdr, float* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        out[0] = (float)hdr->n_iter;
+        out[1] = (float)hdr->len;
+        out[2] = (float)hdr->stopped;
+        out[3] = hdr->gtd;
+        out[4] = hdr->t;
+    }
+}
+
+}  // namespace maua
+
+using namespace maua;
+
+extern "C" {
+
+size_t maua_lbfgs_state_bytes(int64_t count, int history) {
+    if (count <= 0 || history <= 0) return 0;
+    return lbfgs_layout(count, history).total;
+}
+
+int maua_lbfgs_init(void* state, size_t state_bytes, int64_t count, int history, maua_stream_t stream) {
+    MAUA_REQUIRE(state && count > 0 && history > 0, MAUA_E_INVAL, "lbfgs_init: bad args");
+    const LbfgsLayout L = lbfgs_layout(count, history);
+    MAUA_REQUIRE(state_bytes >= L.total, MAUA_E_WORKSPACE, "lbfgs_init: state %zu < %zu bytes", state_bytes, L.total);
+    char* b = (char*)state;
+    hipLaunchKernelGGL(lbfgs_init_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, (LbfgsHeader*)b,
+                       (double*)(b + L.off_M), L.nb_ids, (float*)(b + L.off_coef));
+    return check_launch("lbfgs_init_kernel");
+}
+
+int maua_lbfgs_iterate(void* state, float* x, const float* grad, int64_t count, int history, float lr,
+                       float tolerance_change, maua_stream_t stream) {
+    MAUA_REQUIRE(state && x && grad && count > 0 && history > 0, MAUA_E_INVAL, "lbfgs_iterate: bad args");
+    const LbfgsLayout L = lbfgs_layout(count, history);
+    char* b = (char*)state;
+    LbfgsHeader* hdr = (LbfgsHeader*)b;
+    float* coef = (float*)(b + L.off_coef);
+    double* dots = (double*)(b + L.off_dots);
+    double* M = (double*)(b + L.off_M);
+    float* partial = (float*)(b + L.off_partial);
+    float* g_prev = (float*)(b + L.off_gprev);
+    float* d = (float*)(b + L.off_d);
+    float* S = (float*)(b + L.off_S);
+    float* Y = (float*)(b + L.off_Y);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds1 = sizeof(float) * 4 * L.nb_ids * 4;
+    MAUA_REQUIRE(lds1 <= 64 * 1024, MAUA_E_UNSUPPORTED, "lbfgs_iterate: history %d too large", history);
+    hipLaunchKernelGGL(lbfgs_pair_dots_kernel, dim3(L.nwg), dim3(256), lds1, s, hdr, grad, g_prev, d, S, Y, partial, count,
+                       L.m1);
+    int rc = check_launch("lbfgs_pair_dots_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(lbfgs_finish_dots_kernel, dim3(L.nb_ids), dim3(256), 0, s, partial, dots, L.nwg, L.nb_ids);
+    rc = check_launch("lbfgs_finish_dots_kernel");
+    if (rc) return rc;
+    const size_t lds3 = sizeof(double) * (L.nb_ids + L.m1);
+    hipLaunchKernelGGL(lbfgs_coeffs_kernel, dim3(1), dim3(64), lds3, s, hdr, dots, M, coef, L.m1, history, lr,
+                       tolerance_change);
+    rc = check_launch("lbfgs_coeffs_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(lbfgs_combine_kernel, dim3(L.nwg), dim3(256), 0, s, hdr, coef, grad, S, Y, d, x, count, L.m1);
+    return check_launch("lbfgs_combine_kernel");
+}
+
+int maua_lbfgs_status(const void* state, int64_t count, int history, float* out5, maua_stream_t stream) {
+    MAUA_REQUIRE(state && out5 && count > 0 && history > 0, MAUA_E_INVAL, "lbfgs_status: bad args");
+    hipLaunchKernelGGL(lbfgs_status_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const LbfgsHeader*)state, out5);
+    return check_launch("lbfgs_status_kernel");
+}
+
+}  // extern "C"

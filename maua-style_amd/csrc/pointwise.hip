@@ -1,0 +1,335 @@
+// Bandwidth-bound pieces of the hot path: ReLU, pooling, filter re-layout, MSE and TV losses with their
+// gradients, small vector helpers.  All reductions are two-stage with a fixed summation order.
+#include <stdarg.h>
+
+#include "common.hpp"
+
+namespace maua {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+__global__ void finish_sum_kernel(const double* __restrict__ partial, int n, float scale, float* __restrict__ out) {
+    __shared__ double scratch[16];
+    // each thread sums a fixed strided subset in order, then a fixed-shape tree: deterministic
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) v += partial[i];
+    v = block_sum(v, scratch);
+    if (threadIdx.x == 0) out[0] = (float)(v * (double)scale);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ void pack_filters_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wb, int cout,
+                                    int cin, int kh, int kw) {
+    const int64_t total = (int64_t)cout * cin * kh * kw;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = e;
+        const int kx = (int)(r % kw);
+        r /= kw;
+        const int ky = (int)(r % kh);
+        r /= kh;
+        const int ci = (int)(r % cin);
+        const int co = (int)(r / cin);
+        const float v = w[e];
+        if (wf) wf[((int64_t)(ky * kw + kx) * cin + ci) * cout + co] = v;
+        if (wb) wb[((int64_t)((kh - 1 - ky) * kw + (kw - 1 - kx)) * cout + co) * cin + ci] = v;
+    }
+}
+
+__global__ void relu_fwd_kernel(float* __restrict__ x, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        x[i] = x[i] > 0.f ? x[i] : 0.f;
+}
+
+__global__ void relu_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y, float* __restrict__ gx,
+                                int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        gx[i] = y[i] > 0.f ? gy[i] : 0.f;
+}
+
+__global__ void fill_kernel(float* __restrict__ x, int64_t n, float v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] = v;
+}
+
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = fmaf(a, x[i], y[i]);
+}
+
+__global__ void sum_small_kernel(const float* __restrict__ in, int n, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += in[i];  // same left-to-right order as `total_loss += mod.loss`
+        out[0] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Pooling.  Window of output (oy, ox): rows [oy*s, min(oy*s+k, H)), cols likewise (pad = 0 everywhere in the
+// reference).  Max: first maximum in row-major scan order, NaN wins (ATen's max_pool2d rule).
+__device__ __forceinline__ int window_argmax(const float* __restrict__ plane, int H, int W, int oy, int ox, int k, int s) {
+    const int y0 = oy * s, x0 = ox * s;
+    const int y1 = min(y0 + k, H), x1 = min(x0 + k, W);
+    int best = y0 * W + x0;
+    float bv = plane[best];
+    for (int yy = y0; yy < y1; ++yy)
+        for (int xx = x0; xx < x1; ++xx) {
+            const float v = plane[yy * W + xx];
+            if (v > bv || v != v) {
+                bv = v;
+                best = yy * W + xx;
+            }
+        }
+    return best;
+}
+
+__global__ void pool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t planes, int H, int W, int OH,
+                                int OW, int k, int s, int mode) {
+    const int64_t total = planes * OH * OW;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(e % OW);
+        const int oy = (int)((e / OW) % OH);
+        const int64_t pl = e / ((int64_t)OW * OH);
+        const float* plane = x + pl * H * W;
+        if (mode == 0) {
+            y[e] = plane[window_argmax(plane, H, W, oy, ox, k, s)];
+        } else {
+            const int y0 = oy * s, x0 = ox * s, y1 = min(y0 + k, H), x1 = min(x0 + k, W);
+            float acc = 0.f;
+            for (int yy = y0; yy < y1; ++yy)
+                for (int xx = x0; xx < x1; ++xx) acc += plane[yy * W + xx];
+            y[e] = acc / (float)((y1 - y0) * (x1 - x0));
+        }
+    }
+}
+
+__global__ void pool_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x, float* __restrict__ gx,
+                                int64_t planes, int H, int W, int OH, int OW, int k, int s, int mode) {
+    const int64_t total = planes * H * W;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int ix = (int)(e % W);
+        const int iy = (int)((e / W) % H);
+        const int64_t pl = e / ((int64_t)W * H);
+        const float* plane = x + pl * H * W;
+        const float* gplane = gy + pl * OH * OW;
+        // output windows that contain (iy, ix)
+        const int oy_lo = max(0, (iy - k + s) / s), oy_hi = min(OH - 1, iy / s);
+        const int ox_lo = max(0, (ix - k + s) / s), ox_hi = min(OW - 1, ix / s);
+        float acc = 0.f;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy)
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                if (oy * s > iy || oy * s + k <= iy || ox * s > ix || ox * s + k <= ix) continue;
+                if (mode == 0) {
+                    if (window_argmax(plane, H, W, oy, ox, k, s) == iy * W + ix) acc += gplane[oy * OW + ox];
+                } else {
+                    const int y0 = oy * s, x0 = ox * s, y1 = min(y0 + k, H), x1 = min(x0 + k, W);
+                    acc += gplane[oy * OW + ox] / (float)((y1 - y0) * (x1 - x0));
+                }
+            }
+        gx[e] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// MSE: partial[b] = sum over the block's elements of (x-t)^2 (double); grad (+)= gs * (x - t).
+__global__ void __launch_bounds__(256)
+mse_kernel(const float* __restrict__ x, const float* __restrict__ t, float* __restrict__ grad, int64_t n, float gs,
+           int accumulate, double* __restrict__ partial) {
+    __shared__ double scratch[16];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = x[i] - t[i];
+        acc += (double)d * (double)d;
+        if (grad) grad[i] = accumulate ? fmaf(gs, d, grad[i]) : gs * d;
+    }
+    acc = block_sum(acc, scratch);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+// TV: loss = strength * (sum |x[y+1]-x[y]| + sum |x[x+1]-x[x]|); d/dx via sign() of the four neighbours' differences.
+__global__ void __launch_bounds__(256)
+tv_kernel(const float* __restrict__ x, float* __restrict__ grad, int64_t planes, int H, int W, float strength,
+          int accumulate, double* __restrict__ partial) {
+    __shared__ double scratch[16];
+    const int64_t total = planes * H * W;
+    double acc = 0.0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int ix = (int)(e % W);
+        const int iy = (int)((e / W) % H);
+        const float c = x[e];
+        float g = 0.f;
+        auto sgn = [](float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); };
+        if (iy + 1 < H) {
+            const float d = x[e + W] - c;  // this element is the "upper" one of the pair: d/dc = -sign(d)
+            acc += fabs((double)d);
+            g -= sgn(d);
+        }
+        if (iy > 0) g += sgn(c - x[e - W]);
+        if (ix + 1 < W) {
+            const float d = x[e + 1] - c;
+            acc += fabs((double)d);
+            g -= sgn(d);
+        }
+        if (ix > 0) g += sgn(c - x[e - 1]);
+        if (grad) grad[e] = accumulate ? fmaf(strength, g, grad[e]) : strength * g;
+    }
+    acc = block_sum(acc, scratch);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Adam, single-tensor form of torch.optim.Adam: exp_avg.lerp_(g, 1-b1); exp_avg_sq = b2*v + (1-b2) g*g;
+// denom = sqrt(v)/sqrt(1-b2^t) + eps; x -= lr/(1-b1^t) * m/denom.
+__global__ void adam_kernel(float* __restrict__ x, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, int64_t n, float one_minus_b1, float b2, float one_minus_b2,
+                            float sqrt_bc2, float step_size, float eps) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = m[i] + one_minus_b1 * (gi - m[i]);
+        const float vi = v[i] * b2 + one_minus_b2 * (gi * gi);
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / sqrt_bc2 + eps;
+        x[i] = x[i] + (-step_size * mi) / denom;  // addcdiv_(exp_avg, denom, value=-step_size)
+    }
+}
+
+static inline int ew_grid(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace maua
+
+using namespace maua;
+
+extern "C" {
+
+int maua_abi_version(void) { return 1; }
+const char* maua_last_error(void) { return maua::g_err; }
+
+int maua_conv_pack_filters(const float* w, float* wf, float* wb, int cout, int cin, int kh, int kw, maua_stream_t stream) {
+    MAUA_REQUIRE(w && (wf || wb) && cout > 0 && cin > 0 && kh > 0 && kw > 0, MAUA_E_INVAL, "conv_pack_filters: bad args");
+    const int64_t total = (int64_t)cout * cin * kh * kw;
+    hipLaunchKernelGGL(pack_filters_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w, wf, wb, cout, cin,
+                       kh, kw);
+    return check_launch("pack_filters_kernel");
+}
+
+int maua_relu_fwd(float* x, int64_t count, maua_stream_t stream) {
+    MAUA_REQUIRE(x && count > 0, MAUA_E_INVAL, "relu_fwd: bad args");
+    hipLaunchKernelGGL(relu_fwd_kernel, dim3(ew_grid(count)), dim3(256), 0, (hipStream_t)stream, x, count);
+    return check_launch("relu_fwd_kernel");
+}
+
+int maua_relu_bwd(const float* gy, const float* y, float* gx, int64_t count, maua_stream_t stream) {
+    MAUA_REQUIRE(gy && y && gx && count > 0, MAUA_E_INVAL, "relu_bwd: bad args");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(count)), dim3(256), 0, (hipStream_t)stream, gy, y, gx, count);
+    return check_launch("relu_bwd_kernel");
+}
+
+int maua_pool_out_size(int in, int k, int stride, int ceil_mode) {
+    // ATen pooling_output_shape with pad 0, dilation 1: floor/ceil((in - k) / stride) + 1, and in ceil mode the last
+    // window must start inside the input.
+    if (in <= 0 || k <= 0 || stride <= 0 || in < k) return 0;
+    int o = (in - k + (ceil_mode ? stride - 1 : 0)) / stride + 1;
+    if (ceil_mode && (o - 1) * stride >= in) --o;
+    return o;
+}
+
+int maua_pool2d_fwd(const float* x, float* y, int n, int c, int h, int w, int k, int stride, int ceil_mode, int mode,
+                    maua_stream_t stream) {
+    MAUA_REQUIRE(x && y && n > 0 && c > 0 && h > 0 && w > 0 && k > 0 && stride > 0 && (mode == 0 || mode == 1),
+                 MAUA_E_INVAL, "pool2d_fwd: bad args");
+    const int oh = maua_pool_out_size(h, k, stride, ceil_mode), ow = maua_pool_out_size(w, k, stride, ceil_mode);
+    MAUA_REQUIRE(oh > 0 && ow > 0, MAUA_E_UNSUPPORTED, "pool2d_fwd: input %dx%d smaller than window %d", h, w, k);
+    const int64_t total = (int64_t)n * c * oh * ow;
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, (int64_t)n * c, h, w,
+                       oh, ow, k, stride, mode);
+    return check_launch("pool_fwd_kernel");
+}
+
+int maua_pool2d_bwd(const float* gy, const float* x, float* gx, int n, int c, int h, int w, int k, int stride,
+                    int ceil_mode, int mode, maua_stream_t stream) {
+    MAUA_REQUIRE(gy && x && gx && n > 0 && c > 0 && h > 0 && w > 0 && k > 0 && stride > 0 && (mode == 0 || mode == 1),
+                 MAUA_E_INVAL, "pool2d_bwd: bad args");
+    const int oh = maua_pool_out_size(h, k, stride, ceil_mode), ow = maua_pool_out_size(w, k, stride, ceil_mode);
+    MAUA_REQUIRE(oh > 0 && ow > 0, MAUA_E_UNSUPPORTED, "pool2d_bwd: input %dx%d smaller than window %d", h, w, k);
+    const int64_t total = (int64_t)n * c * h * w;
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, gy, x, gx, (int64_t)n * c,
+                       h, w, oh, ow, k, stride, mode);
+    return check_launch("pool_bwd_kernel");
+}
+
+size_t maua_reduce_workspace_bytes(int64_t count) { return (size_t)reduce_blocks(count, 1024) * sizeof(double); }
+
+int maua_mse_fwd_bwd(const float* x, const float* target, float* grad, int64_t count, float loss_scale, float grad_scale,
+                     int accumulate, float* loss_out, void* workspace, size_t workspace_bytes, maua_stream_t stream) {
+    MAUA_REQUIRE(x && target && loss_out && workspace && count > 0, MAUA_E_INVAL, "mse_fwd_bwd: bad args");
+    const int nb = reduce_blocks(count, 1024);
+    MAUA_REQUIRE(workspace_bytes >= nb * sizeof(double), MAUA_E_WORKSPACE, "mse_fwd_bwd: workspace %zu < %zu",
+                 workspace_bytes, nb * sizeof(double));
+    hipLaunchKernelGGL(mse_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, target, grad, count, grad_scale,
+                       accumulate, (double*)workspace);
+    int rc = check_launch("mse_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, nb,
+                       loss_scale, loss_out);
+    return check_launch("finish_sum_kernel");
+}
+
+int maua_tv_fwd_bwd(const float* x, float* grad, int n, int c, int h, int w, float strength, int accumulate,
+                    float* loss_out, void* workspace, size_t workspace_bytes, maua_stream_t stream) {
+    MAUA_REQUIRE(x && loss_out && workspace && n > 0 && c > 0 && h > 0 && w > 0, MAUA_E_INVAL, "tv_fwd_bwd: bad args");
+    const int64_t count = (int64_t)n * c * h * w;
+    const int nb = reduce_blocks(count, 1024);
+    MAUA_REQUIRE(workspace_bytes >= nb * sizeof(double), MAUA_E_WORKSPACE, "tv_fwd_bwd: workspace too small");
+    hipLaunchKernelGGL(tv_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, grad, (int64_t)n * c, h, w, strength,
+                       accumulate, (double*)workspace);
+    int rc = check_launch("tv_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, nb, strength,
+                       loss_out);
+    return check_launch("finish_sum_kernel");
+}
+
+int maua_fill(float* x, int64_t count, float value, maua_stream_t stream) {
+    MAUA_REQUIRE(x && count > 0, MAUA_E_INVAL, "fill: bad args");
+    hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(count)), dim3(256), 0, (hipStream_t)stream, x, count, value);
+    return check_launch("fill_kernel");
+}
+
+int maua_axpy(float* y, const float* x, float alpha, int64_t count, maua_stream_t stream) {
+    MAUA_REQUIRE(x && y && count > 0, MAUA_E_INVAL, "axpy: bad args");
+    hipLaunchKernelGGL(axpy_kernel, dim3(ew_grid(count)), dim3(256), 0, (hipStream_t)stream, y, x, alpha, count);
+    return check_launch("axpy_kernel");
+}
+
+int maua_sum_small(const float* in, int count, float* out, maua_stream_t stream) {
+    MAUA_REQUIRE(in && out && count > 0, MAUA_E_INVAL, "sum_small: bad args");
+    hipLaunchKernelGGL(sum_small_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, in, count, out);
+    return check_launch("sum_small_kernel");
+}
+
+int maua_adam_step(float* x, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, int step, float lr,
+                   float beta1, float beta2, float eps, maua_stream_t stream) {
+    MAUA_REQUIRE(x && grad && exp_avg && exp_avg_sq && count > 0 && step >= 1, MAUA_E_INVAL, "adam_step: bad args");
+    // scalar prep in double on the host like torch's python-float arithmetic (bias corrections are python floats)
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const float step_size = (float)((double)lr / bc1);
+    const float sqrt_bc2 = (float)sqrt(bc2);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(count)), dim3(256), 0, (hipStream_t)stream, x, grad, exp_avg, exp_avg_sq,
+                       count, (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2), sqrt_bc2, step_size,
+                       eps);
+    return check_launch("adam_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,121 @@
+"""Multi-GPU layout: independent frames / images sharded over one process per GPU.
+
+The hot path does not shard inside one image (it would need a halo exchange at all 13 convs and an all-reduce
+of five Gram matrices per iteration - SURVEY.md §8e), and the reference has no distributed code at all.  What
+shards naturally is the list of independent optimisation problems: video frames without optical flow
+(style.vid_img minus flow) or separate images.  Each rank therefore owns a contiguous block of frames and a
+full replica of the network; the only communication is ONE broadcast at start-up (conv weights, and the style
+Gram targets computed once on rank 0) over RCCL/xGMI - `backend="nccl"` on ROCm - and nothing per iteration.
+On CPU-only hosts the same code runs over gloo (tests/test_dist_cpu.py).
+"""
+import os
+
+import torch
+import torch.distributed as td
+
+
+def env_rank():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init(backend=None):
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun's env).
+    Returns (rank, local_rank, world).  One process per GPU; the device is chosen before any collective."""
+    rank, local_rank, world = env_rank()
+    if world > 1 and not td.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        td.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank if local_rank < torch.cuda.device_count() else 0)
+    return rank, local_rank, world
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous block [lo, hi) of `n_items` owned by `rank`: the first n % world ranks get one extra item."""
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_owner(index, n_items, world):
+    for r in range(world):
+        lo, hi = shard_range(n_items, r, world)
+        if lo <= index < hi:
+            return r
+    raise IndexError(index)
+
+
+def broadcast_tensors(tensors, src=0):
+    """Broadcast a list of same-dtype tensors as ONE flat buffer (one collective instead of one per layer)."""
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+        return
+    tensors = [t for t in tensors if t is not None and t.numel() > 0]
+    if not tensors:
+        return
+    flat = torch.cat([t.detach().reshape(-1) for t in tensors])
+    td.broadcast(flat, src=src)
+    off = 0
+    with torch.no_grad():
+        for t in tensors:
+            n = t.numel()
+            t.copy_(flat[off:off + n].reshape(t.shape))
+            off += n
+
+
+def broadcast_network(net, src=0):
+    """Rank `src`'s conv weights/biases -> every rank (51.8 MB for VGG-19 through conv5_1)."""
+    broadcast_tensors([p.data for p in net.parameters()], src)
+
+
+def broadcast_style_targets(net, src=0):
+    """Style Gram targets captured on rank `src` -> every rank (2.4 MB for the default five layers), so the style
+    forward passes run once per job instead of once per rank (and once per frame, as the reference does:
+    style.py:178 keeps the hoisting commented out)."""
+    world = td.get_world_size() if (td.is_available() and td.is_initialized()) else 1
+    if world == 1:
+        return
+    for mod in net.style_losses:
+        for name in ("target", "video_target"):
+            t = getattr(mod, name)
+            shape = torch.tensor(list(t.shape) + [0] * (4 - t.dim()), dtype=torch.int64, device=_coll_device())
+            td.broadcast(shape, src=src)
+            dims = [int(v) for v in shape.tolist() if v > 0]
+            if td.get_rank() != src:
+                t = torch.empty(dims, dtype=torch.float32, device=_coll_device()) if dims else torch.Tensor()
+                setattr(mod, name, t)
+    broadcast_tensors([getattr(m, n) for m in net.style_losses for n in ("target", "video_target")], src)
+
+
+def _coll_device():
+    return torch.device("cuda", torch.cuda.current_device()) if td.get_backend() == "nccl" else torch.device("cpu")
+
+
+def barrier():
+    if td.is_available() and td.is_initialized() and td.get_world_size() > 1:
+        td.barrier()
+
+
+def max_over_ranks(value):
+    """max of a python float over all ranks (used for the benchmark's wall time)."""
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=_coll_device())
+    td.all_reduce(t, op=td.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_frames(local, n_items):
+    """Collect {index: CPU tensor} dictionaries on rank 0 (final outputs; the reference writes files instead)."""
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+        return local
+    out = [None] * td.get_world_size()
+    td.all_gather_object(out, local)
+    merged = {}
+    for d in out:
+        merged.update(d)
+    assert len(merged) == n_items
+    return merged

@@ -1,0 +1,286 @@
+"""Fused function evaluation for the image-optimisation loop.
+
+`StyleEngine` compiles the loss network that models.load_model assembled into a flat plan and evaluates
+`feval(x) -> loss slots, d loss / d x` (reference optim.py:201-238: zero_grad, net(pastiche), sum of
+module losses, backward) as a fixed chain of libmaua_hip kernels on torch's current stream:
+
+  forward   conv+bias+ReLU fused (one MFMA kernel per conv layer), pools, Gram matrices of the style layers;
+  losses    one fused MSE kernel per loss gives the scalar and the gradient seed (Gram difference D / feature
+            difference) - the 6-7 `.item()` syncs per iteration of the reference are gone, scalars stay on
+            the device in `slots`;
+  backward  hand-derived (no autograd): the Gram backward D*F accumulates into the feature gradient, every
+            conv's backward-data applies the ReLU mask of its own output while it stages the gradient tile,
+            pool backward recomputes the argmax, TV adds its sign gradient at the pixels.
+
+Gradient weights follow the reference's ScaleGradients quirk (loss.py:10-20): with
+`normalize` the *gradient* of a loss term is weighted by strength^2 while the *reported* loss uses strength.
+Activations and gradient buffers are allocated once per image size and reused by every iteration, so an
+iteration allocates nothing and can be captured into a hipGraph (`capture=True`).
+"""
+import torch
+
+import hip
+import loss as loss_mod
+import models as models_mod
+
+
+class UnsupportedNet(RuntimeError):
+    """The module sequence contains something the fused plan does not cover (callers fall back to running the
+    modules one by one, which still executes on the GPU through the same kernels)."""
+
+
+def _scale_grad_coeff(incoming, strength):
+    # backward of ScaleGradients for a scalar: g / (|g| + 1e-8) * strength^2
+    g = float(incoming)
+    return g / (abs(g) + 1e-8) * strength * strength
+
+
+class _Step:
+    __slots__ = ("kind", "mod", "relu", "src", "dst", "slot", "k", "stride", "pad", "ceil", "mode")
+
+    def __init__(self, kind, mod=None):
+        self.kind, self.mod, self.relu = kind, mod, False
+        self.src = self.dst = self.slot = None
+
+
+class StyleEngine:
+    def __init__(self, net, losses):
+        self.net, self.losses = net, list(losses)
+        self.slot_of = {id(m): i for i, m in enumerate(self.losses)}
+        self.steps = self._plan(list(net))
+        self.shape = None
+        self.graph = None
+        self.timer = None  # bench.py: list receiving (tag, algorithmic flops, bytes, start event, end event) per launch
+
+    # -- planning --------------------------------------------------------------------------------------
+    def _plan(self, mods):
+        steps, act = [], 0  # act = index of the current activation (0 = the image)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, loss_mod.TVLoss):
+                if act != 0:
+                    raise UnsupportedNet("TVLoss away from the pixels")
+                s = _Step("tv", m)
+                s.src = act
+            elif isinstance(m, loss_mod.ContentLoss):
+                s = _Step("content", m)
+                s.src = act
+            elif isinstance(m, loss_mod.StyleLoss):
+                s = _Step("style", m)
+                s.src = act
+            elif isinstance(m, models_mod.Conv2d):
+                s = _Step("conv", m)
+                s.k, s.stride, s.pad = m.kernel_size[0], m.stride[0], m.padding[0]
+                if m.kernel_size[0] != m.kernel_size[1] or m.stride[0] != m.stride[1] or m.padding[0] != m.padding[1]:
+                    raise UnsupportedNet("non-square convolution")
+                if i + 1 < len(mods) and isinstance(mods[i + 1], models_mod.ReLU):
+                    s.relu = True
+                    i += 1
+                elif i + 1 < len(mods) and isinstance(mods[i + 1], (loss_mod.ContentLoss, loss_mod.StyleLoss)):
+                    # the reference's in-place ReLU makes this layout fail in autograd; nothing to be faithful to
+                    raise UnsupportedNet("loss module on a conv output (pre-ReLU)")
+                s.src, act = act, act + 1
+                s.dst = act
+            elif isinstance(m, models_mod.ReLU):
+                s = _Step("relu", m)
+                s.src = s.dst = act
+            elif isinstance(m, models_mod._Pool2d):
+                s = _Step("pool", m)
+                s.k, s.stride = models_mod._as_int(m.kernel_size), models_mod._as_int(m.stride)
+                s.ceil, s.mode = bool(m.ceil_mode), m.mode
+                s.src, act = act, act + 1
+                s.dst = act
+            else:
+                raise UnsupportedNet(f"module {type(m).__name__}")
+            if s.kind in ("tv", "content", "style"):
+                s.slot = self.slot_of.get(id(m))
+                if s.slot is None:
+                    raise UnsupportedNet("loss module missing from the losses list")
+            steps.append(s)
+            i += 1
+        return steps
+
+    # -- buffers ---------------------------------------------------------------------------------------
+    def _prepare(self, x):
+        if self.shape == tuple(x.shape):
+            return
+        if x.shape[0] != 1:
+            raise UnsupportedNet("the fused plan optimises one frame per call (B = 1), like img_img / vid_img")
+        dev = x.device
+        self.shape = tuple(x.shape)
+        self.graph = None
+        shapes = {0: tuple(x.shape)}
+        for s in self.steps:
+            n, c, h, w = shapes[s.src]
+            if s.kind == "conv":
+                oh, ow = hip.conv_out_hw(h, w, s.k, s.stride, s.pad)
+                shapes[s.dst] = (n, s.mod.out_channels, oh, ow)
+            elif s.kind == "pool":
+                shapes[s.dst] = (n, c, hip.pool_out_size(h, s.k, s.stride, s.ceil), hip.pool_out_size(w, s.k, s.stride, s.ceil))
+        self.act = {k: (None if k == 0 else torch.empty(v, device=dev)) for k, v in shapes.items()}
+        self.gbuf = {k: torch.empty(v, device=dev) for k, v in shapes.items()}
+        self.slots = torch.zeros(max(len(self.losses), 1), device=dev)
+        self.total = torch.zeros(1, device=dev)
+        self.gram, self.dmat, self.mean = {}, {}, {}
+        ws = hip.reduce_workspace_bytes(max(t.numel() for t in self.gbuf.values()))
+        for s in self.steps:
+            if s.kind == "style":
+                c = shapes[s.src][1]
+                hw = shapes[s.src][2] * shapes[s.src][3]
+                self.gram[id(s)] = torch.empty(c, c, device=dev)
+                self.dmat[id(s)] = torch.empty(c, c, device=dev)
+                self.mean[id(s)] = torch.empty(c, device=dev) if s.mod.use_covariance else None
+                ws = max(ws, hip.gram_workspace_bytes(c, hw), 4 * c + 256)
+        self.ws = torch.empty(ws, dtype=torch.uint8, device=dev)
+        self.x_static = torch.empty(self.shape, device=dev)
+
+    # -- one evaluation --------------------------------------------------------------------------------
+    def _coefficients(self, s):
+        """(reported-loss weight, gradient weight) of a loss step for B = 1."""
+        m = s.mod
+        st = m.strength
+        if s.kind == "content":
+            return st, (_scale_grad_coeff(st, st) if m.normalize else st)
+        vsf = m.video_style_factor
+        dyn = vsf > 0
+        lw = st + (vsf * st if dyn else 0.0)
+        if m.normalize:
+            gw = _scale_grad_coeff(st, st) + (_scale_grad_coeff(vsf * st, st) if dyn else 0.0)
+        else:
+            gw = lw
+        return lw, gw
+
+    def _active(self, s, shapes_src):
+        m = s.mod
+        if s.kind == "tv":
+            return True
+        if m.mode != "loss":
+            return False
+        if s.kind == "content":
+            if m.target.nelement() == 0:
+                return False  # temporal module without a target (loss.py:46-47) or never captured
+            if tuple(m.target.shape[1:]) != tuple(shapes_src[1:]):
+                return False  # loss.py:44
+            if m.weights is not None:
+                raise UnsupportedNet("weighted (temporal) ContentLoss runs on the module path")
+            return True
+        if m.target.nelement() == 0:
+            raise RuntimeError(f"{m.name}: style target not captured")
+        if m.video_style_factor > 0 and m.video_target.nelement() != 0 and m.video_target.shape != m.target.shape:
+            raise UnsupportedNet("dynamic style target of another shape")
+        return True
+
+    def _timed(self, tag, flops, nbytes, fn):
+        """Run one kernel launch; when a timer list is attached, bracket it with events on the launch stream."""
+        if self.timer is None:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self.timer.append((tag, flops, nbytes, e0, e1))
+        return out
+
+    @staticmethod
+    def _conv_work(s, in_shape, out_shape, backward):
+        """Algorithmic FLOPs and bytes of one conv launch (SURVEY.md Appendix B accounting)."""
+        _, cin, h, w = in_shape
+        _, cout, oh, ow = out_shape
+        flops = 2 * cin * cout * s.k * s.k * oh * ow
+        wbytes = (cin * cout * s.k * s.k + cout) * 4
+        ib, ob = cin * h * w * 4, cout * oh * ow * 4
+        nbytes = (ob + ob + wbytes + ib) if backward else (ib + wbytes + ob)
+        return flops, nbytes
+
+    def _run(self, x):
+        a, g = self.act, self.gbuf
+        a[0] = x
+        hip.fill_(self.slots, 0.0)
+        # ---------------- forward
+        for s in self.steps:
+            if s.kind == "conv":
+                wf, _ = s.mod.banks()
+                fl, nb = self._conv_work(s, a[s.src].shape, a[s.dst].shape, False)
+                self._timed("conv_fwd", fl, nb, lambda: hip.conv2d_fwd(
+                    a[s.src], wf, s.mod.bias_device(), s.k, s.stride, s.pad, s.relu, out=a[s.dst]))
+            elif s.kind == "relu":
+                hip.relu_(a[s.src])
+            elif s.kind == "pool":
+                hip.pool2d_fwd(a[s.src], s.k, s.stride, s.ceil, s.mode, out=a[s.dst])
+            elif s.kind == "style" and self._active(s, a[s.src].shape):
+                f = a[s.src]
+                c, n = f.shape[1], f[0].nelement()
+                lw, gw = self._coefficients(s)
+                self._timed("gram_fwd", 2 * c * c * (n // c), n * 4 + c * c * 4, lambda: hip.gram_fwd(
+                    f, 1.0 / n, s.mod.use_covariance, out=self.gram[id(s)], mean_out=self.mean[id(s)], workspace=self.ws))
+                # loss = lw * mean((G-T)^2); D = gw * (2/C^2) * (2/n) * (G - T)   (dG/dF = (D + D^T) F / n, D symmetric)
+                hip.mse_fwd_bwd(self.gram[id(s)], s.mod.target, self.dmat[id(s)], lw / (c * c), gw * 4.0 / (c * c) / n,
+                                False, self.slots[s.slot:s.slot + 1], workspace=self.ws)
+        # ---------------- backward
+        cur = None  # activation index whose gradient buffer currently holds d loss / d act
+        for s in reversed(self.steps):
+            if s.kind == "style":
+                if self._active(s, a[s.src].shape):
+                    f = a[s.src]
+                    c, n = f.shape[1], f[0].nelement()
+                    acc = cur == s.src
+                    self._timed("gram_bwd", 2 * c * c * (n // c), n * 4 * 3 + c * c * 4, lambda: hip.gram_bwd(
+                        self.dmat[id(s)], f, self.mean[id(s)], g[s.src], acc, workspace=self.ws))
+                    cur = s.src
+            elif s.kind == "content":
+                if self._active(s, a[s.src].shape):
+                    lw, gw = self._coefficients(s)
+                    n = a[s.src].nelement()
+                    hip.mse_fwd_bwd(a[s.src], s.mod.target, g[s.src], lw / n, gw * 2.0 / n, cur == s.src,
+                                    self.slots[s.slot:s.slot + 1], workspace=self.ws)
+                    cur = s.src
+            elif s.kind == "tv":
+                hip.tv_fwd_bwd(a[0], g[0], s.mod.strength, cur == 0, self.slots[s.slot:s.slot + 1], workspace=self.ws)
+                cur = 0
+            elif cur is None:
+                continue  # nothing flows through layers behind the last loss
+            elif s.kind == "conv":
+                assert cur == s.dst
+                _, wb = s.mod.banks()
+                fl, nb = self._conv_work(s, a[s.src].shape, a[s.dst].shape, True)
+                self._timed("conv_bwd", fl, nb, lambda: hip.conv2d_bwd_data(
+                    g[s.dst], a[s.dst] if s.relu else None, wb, s.mod.weight.detach(), a[s.src].shape, s.k, s.stride,
+                    s.pad, out=g[s.src]))
+                cur = s.src
+            elif s.kind == "relu":
+                hip.relu_bwd(g[s.src], a[s.src], out=g[s.src])
+            elif s.kind == "pool":
+                assert cur == s.dst
+                hip.pool2d_bwd(g[s.dst], a[s.src], s.k, s.stride, s.ceil, s.mode, out=g[s.src])
+                cur = s.src
+        if cur != 0:
+            hip.fill_(g[0], 0.0)
+        hip.sum_small(self.slots, self.total)
+
+    def feval(self, x, capture=False):
+        """Evaluate at `x` (1,3,H,W fp32 on the GPU).  Returns (per-module loss slots in `losses` order, total
+        loss, gradient) - device tensors owned by the engine, overwritten by the next call; no host sync."""
+        self._prepare(x)
+        if not capture:
+            self._run(x)
+            return self.slots, self.total, self.gbuf[0]
+        if self.graph is None:
+            self.x_static.copy_(x)
+            self._run(self.x_static)  # warm-up outside capture (filter banks, lazy init)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._run(self.x_static)
+        self.x_static.copy_(x)
+        self.graph.replay()
+        return self.slots, self.total, self.gbuf[0]
+
+    def saved_bytes(self):
+        """Bytes held by activations + gradient buffers for the current shape."""
+        tot = 0
+        for d in (self.act, self.gbuf):
+            for t in d.values():
+                if t is not None:
+                    tot += t.numel() * 4
+        return tot

@@ -1,0 +1,279 @@
+"""ctypes binding of libmaua_hip.so (declared in include/maua_hip.h).
+
+There is NO fallback: if the library cannot be loaded, or a kernel reports an error, a
+`HipError` is raised.  Tensors handed to the wrappers must be contiguous float32 ROCm
+tensors; every call is enqueued on torch's current stream.
+"""
+import ctypes
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmaua_hip.so")
+
+c_f = ctypes.c_float
+c_i = ctypes.c_int
+c_i64 = ctypes.c_int64
+c_p = ctypes.c_void_p
+c_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/maua_hip.h one to one
+SIGNATURES = {
+    "maua_abi_version": (c_i, []),
+    "maua_last_error": (ctypes.c_char_p, []),
+    "maua_conv_pack_filters": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "maua_conv2d_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "maua_conv2d_bwd_data": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "maua_relu_fwd": (c_i, [c_p, c_i64, c_p]),
+    "maua_relu_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_p]),
+    "maua_pool_out_size": (c_i, [c_i, c_i, c_i, c_i]),
+    "maua_pool2d_fwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "maua_pool2d_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "maua_gram_workspace_bytes": (c_sz, [c_i, c_i64]),
+    "maua_gram_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i64, c_f, c_i, c_p, c_sz, c_p]),
+    "maua_reduce_workspace_bytes": (c_sz, [c_i64]),
+    "maua_mse_fwd_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_f, c_f, c_i, c_p, c_p, c_sz, c_p]),
+    "maua_gram_bwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i64, c_i, c_p, c_sz, c_p]),
+    "maua_tv_fwd_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_p, c_sz, c_p]),
+    "maua_fill": (c_i, [c_p, c_i64, c_f, c_p]),
+    "maua_axpy": (c_i, [c_p, c_p, c_f, c_i64, c_p]),
+    "maua_sum_small": (c_i, [c_p, c_i, c_p, c_p]),
+    "maua_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_f, c_f, c_f, c_f, c_p]),
+    "maua_lbfgs_state_bytes": (c_sz, [c_i64, c_i]),
+    "maua_lbfgs_init": (c_i, [c_p, c_sz, c_i64, c_i, c_p]),
+    "maua_lbfgs_iterate": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_f, c_f, c_p]),
+    "maua_lbfgs_status": (c_i, [c_p, c_i64, c_i, c_p, c_p]),
+}
+
+
+class HipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libmaua_hip.so once; raise HipError when it is missing (no CPU path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipError(
+                f"{LIB_PATH} not found: build it with `python maua-style_amd/build_native.py` "
+                "(this package has no CPU or PyTorch fallback)")
+        try:
+            L = ctypes.CDLL(LIB_PATH)
+        except OSError as e:
+            raise HipError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the .so is stale: also loud
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = lib().maua_last_error().decode(errors="replace")
+        raise HipError(f"{what} failed (rc={rc}): {msg}")
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipError("libmaua_hip needs ROCm device tensors (got a CPU tensor): there is no CPU path")
+    if t.dtype != torch.float32 and t.dtype != torch.uint8 and t.dtype != torch.float64:
+        raise HipError(f"unsupported dtype {t.dtype}")
+    if not t.is_contiguous():
+        raise HipError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32(t, name):
+    if t is not None and t.dtype != torch.float32:
+        raise HipError(f"{name}: expected float32, got {t.dtype}")
+    return t
+
+
+# ------------------------------------------------------------------------------------------
+# thin, shape-aware wrappers
+# ------------------------------------------------------------------------------------------
+def conv_pack_filters(w):
+    """OIHW weights -> (forward bank [taps][cin][cout], backward bank [taps][cout][cin])."""
+    cout, cin, kh, kw = w.shape
+    wf = torch.empty(kh * kw, cin, cout, device=w.device, dtype=torch.float32)
+    wb = torch.empty(kh * kw, cout, cin, device=w.device, dtype=torch.float32)
+    _check(lib().maua_conv_pack_filters(_ptr(_f32(w, "w")), _ptr(wf), _ptr(wb), cout, cin, kh, kw, _stream()),
+           "maua_conv_pack_filters")
+    return wf, wb
+
+
+def conv_out_hw(h, w, k, stride, pad):
+    if stride <= 0 or k <= 0 or pad < 0:
+        raise HipError(f"conv geometry k={k} stride={stride} pad={pad} is invalid")
+    if h + 2 * pad < k or w + 2 * pad < k:
+        raise HipError(f"conv input {h}x{w} (pad {pad}) smaller than the {k}x{k} filter")
+    return (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+
+
+def conv2d_fwd(x, wf, bias, k, stride, pad, relu, out=None, in_mask=None, accumulate=False):
+    n, cin, h, w = x.shape
+    cout = wf.shape[2]
+    oh, ow = conv_out_hw(h, w, k, stride, pad)
+    if out is None:
+        out = torch.empty(n, cout, oh, ow, device=x.device, dtype=torch.float32)
+    _check(lib().maua_conv2d_fwd(_ptr(_f32(x, "x")), _ptr(in_mask), _ptr(wf), _ptr(bias), _ptr(out), n, cin, h, w, cout,
+                                 k, k, stride, pad, int(relu), int(accumulate), _stream()), "maua_conv2d_fwd")
+    return out
+
+
+def conv2d_bwd_data(gy, out_mask, wb, w_oihw, in_shape, k, stride, pad, out=None, accumulate=False):
+    n, cin, h, w = in_shape
+    cout = gy.shape[1]
+    if out is None:
+        out = torch.empty(n, cin, h, w, device=gy.device, dtype=torch.float32)
+    _check(lib().maua_conv2d_bwd_data(_ptr(_f32(gy, "gy")), _ptr(out_mask), _ptr(wb), _ptr(w_oihw), _ptr(out), n, cin, h,
+                                      w, cout, k, k, stride, pad, int(accumulate), _stream()), "maua_conv2d_bwd_data")
+    return out
+
+
+def relu_(x):
+    _check(lib().maua_relu_fwd(_ptr(_f32(x, "x")), x.numel(), _stream()), "maua_relu_fwd")
+    return x
+
+
+def relu_bwd(gy, y, out=None):
+    if out is None:
+        out = torch.empty_like(gy)
+    _check(lib().maua_relu_bwd(_ptr(gy), _ptr(y), _ptr(out), gy.numel(), _stream()), "maua_relu_bwd")
+    return out
+
+
+def pool_out_size(n, k, stride, ceil_mode):
+    return lib().maua_pool_out_size(n, k, stride, int(ceil_mode))
+
+
+def pool2d_fwd(x, k, stride, ceil_mode, mode, out=None):
+    n, c, h, w = x.shape
+    oh, ow = pool_out_size(h, k, stride, ceil_mode), pool_out_size(w, k, stride, ceil_mode)
+    if out is None:
+        out = torch.empty(n, c, oh, ow, device=x.device, dtype=torch.float32)
+    _check(lib().maua_pool2d_fwd(_ptr(_f32(x, "x")), _ptr(out), n, c, h, w, k, stride, int(ceil_mode),
+                                 0 if mode == "max" else 1, _stream()), "maua_pool2d_fwd")
+    return out
+
+
+def pool2d_bwd(gy, x, k, stride, ceil_mode, mode, out=None):
+    n, c, h, w = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    _check(lib().maua_pool2d_bwd(_ptr(_f32(gy, "gy")), _ptr(x), _ptr(out), n, c, h, w, k, stride, int(ceil_mode),
+                                 0 if mode == "max" else 1, _stream()), "maua_pool2d_bwd")
+    return out
+
+
+def gram_workspace_bytes(c, hw):
+    return lib().maua_gram_workspace_bytes(c, hw)
+
+
+def reduce_workspace_bytes(count):
+    return lib().maua_reduce_workspace_bytes(count)
+
+
+def _ws(workspace, need, device):
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=device)
+    return workspace
+
+
+def gram_fwd(f, scale, center=False, out=None, mean_out=None, workspace=None):
+    """f: (1,C,H,W) or (C,HW).  Returns (gram CxC, row means or None)."""
+    c = f.shape[1] if f.dim() == 4 else f.shape[0]
+    hw = f.numel() // c
+    if out is None:
+        out = torch.empty(c, c, device=f.device, dtype=torch.float32)
+    if center and mean_out is None:
+        mean_out = torch.empty(c, device=f.device, dtype=torch.float32)
+    need = gram_workspace_bytes(c, hw)
+    workspace = _ws(workspace, need, f.device)
+    _check(lib().maua_gram_fwd(_ptr(_f32(f, "f")), _ptr(out), _ptr(mean_out) if center else None, c, hw, float(scale),
+                               int(center), workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                               _stream()), "maua_gram_fwd")
+    return out, (mean_out if center else None)
+
+
+def gram_bwd(d_sym, f, row_mean, gf, accumulate, workspace=None):
+    c = d_sym.shape[0]
+    hw = f.numel() // c
+    workspace = _ws(workspace, 4 * c + 256, f.device)
+    _check(lib().maua_gram_bwd(_ptr(_f32(d_sym, "d")), _ptr(f), _ptr(row_mean), _ptr(gf), c, hw, int(accumulate),
+                               workspace.data_ptr(), workspace.numel() * workspace.element_size(), _stream()),
+           "maua_gram_bwd")
+    return gf
+
+
+def mse_fwd_bwd(x, target, grad, loss_scale, grad_scale, accumulate, loss_out, workspace=None):
+    n = x.numel()
+    workspace = _ws(workspace, reduce_workspace_bytes(n), x.device)
+    _check(lib().maua_mse_fwd_bwd(_ptr(_f32(x, "x")), _ptr(_f32(target, "target")), _ptr(grad), n, float(loss_scale),
+                                  float(grad_scale), int(accumulate), _ptr(loss_out), workspace.data_ptr(),
+                                  workspace.numel() * workspace.element_size(), _stream()), "maua_mse_fwd_bwd")
+    return loss_out
+
+
+def tv_fwd_bwd(x, grad, strength, accumulate, loss_out, workspace=None):
+    n, c, h, w = x.shape
+    workspace = _ws(workspace, reduce_workspace_bytes(x.numel()), x.device)
+    _check(lib().maua_tv_fwd_bwd(_ptr(_f32(x, "x")), _ptr(grad), n, c, h, w, float(strength), int(accumulate),
+                                 _ptr(loss_out), workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                                 _stream()), "maua_tv_fwd_bwd")
+    return loss_out
+
+
+def fill_(x, value):
+    _check(lib().maua_fill(_ptr(x), x.numel(), float(value), _stream()), "maua_fill")
+    return x
+
+
+def axpy_(y, x, alpha):
+    _check(lib().maua_axpy(_ptr(y), _ptr(x), float(alpha), x.numel(), _stream()), "maua_axpy")
+    return y
+
+
+def sum_small(slots, out):
+    _check(lib().maua_sum_small(_ptr(slots), slots.numel(), _ptr(out), _stream()), "maua_sum_small")
+    return out
+
+
+def adam_step(x, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    _check(lib().maua_adam_step(_ptr(x), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), x.numel(), int(step), float(lr),
+                                beta1, beta2, eps, _stream()), "maua_adam_step")
+
+
+class LbfgsState:
+    """Device-resident L-BFGS state (history slab + bookkeeping) for one flat fp32 vector."""
+
+    def __init__(self, count, history, device):
+        self.count, self.history = int(count), int(history)
+        nbytes = lib().maua_lbfgs_state_bytes(self.count, self.history)
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self._status = torch.zeros(5, dtype=torch.float32, device=device)
+        _check(lib().maua_lbfgs_init(self.buf.data_ptr(), nbytes, self.count, self.history, _stream()), "maua_lbfgs_init")
+
+    def iterate(self, x, grad, lr=1.0, tolerance_change=-1.0):
+        _check(lib().maua_lbfgs_iterate(self.buf.data_ptr(), _ptr(x), _ptr(grad), self.count, self.history, float(lr),
+                                        float(tolerance_change), _stream()), "maua_lbfgs_iterate")
+
+    def status(self):
+        """Host copy of {n_iter, history_len, stopped, g.d, t} - this one synchronises."""
+        _check(lib().maua_lbfgs_status(self.buf.data_ptr(), self.count, self.history, _ptr(self._status), _stream()),
+               "maua_lbfgs_status")
+        n_iter, hlen, stopped, gtd, t = self._status.tolist()
+        return dict(n_iter=int(n_iter), history_len=int(hlen), stopped=bool(stopped), gtd=gtd, t=t)

@@ -1,0 +1,374 @@
+"""Feature networks and loss-network assembly with the reference's names (reference models.py).
+
+`load_model(args) -> (net, losses)` builds the same module sequence as the reference
+(models.py:351-453): optional TVLoss and temporal ContentLoss on the pixels, then the conv / ReLU / pool
+stack of VGG or NIN with ContentLoss / StyleLoss modules inserted after the named layers, truncated after
+the last requested relu layer, parameters frozen, loss lists monkey-patched onto the net.
+
+Differences that follow from being MI355X-native:
+  * Conv2d / ReLU / MaxPool2d / AvgPool2d here are thin nn.Modules over libmaua_hip kernels (hip.py) with HIP
+    backward passes; they only accept ROCm tensors (there is no CPU compute path);
+  * only the `features` stack is materialised - the reference instantiates VGG's 25088x4096 classifier just
+    to drop it (models.py:16-28, :357), which dominates its start-up time;
+  * nothing is downloaded (no network): `--model_file` must name an existing .pth whose path contains the
+    architecture keyword, exactly the rule the reference uses to pick the architecture (models.py:246-341);
+  * the layer-split `ModelParallel` wrappers (models.py:456-566) exist to fit 11 GB cards and are not
+    provided; `--gpu a,b` raises.
+"""
+import copy
+from os import path
+
+import torch
+import torch.nn as nn
+
+import hip
+from loss import ContentLoss, GramMatrix, ScaleGradients, StyleLoss, TVLoss  # noqa: F401  (re-exported like `from loss import *`)
+
+# --------------------------------------------------------------------------------------------------
+# HIP-backed layers
+# --------------------------------------------------------------------------------------------------
+
+
+class _ConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mod):
+        wf, _ = mod.banks()
+        ctx.mod, ctx.in_shape = mod, x.shape
+        return hip.conv2d_fwd(x.contiguous(), wf, mod.bias_device(), mod.kernel_size[0], mod.stride[0], mod.padding[0],
+                              False)
+
+    @staticmethod
+    def backward(ctx, gy):
+        mod = ctx.mod
+        _, wb = mod.banks()
+        gx = hip.conv2d_bwd_data(gy.contiguous(), None, wb, mod.weight.detach(), ctx.in_shape, mod.kernel_size[0],
+                                 mod.stride[0], mod.padding[0])
+        return gx, None
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d whose forward/backward-data run in libmaua_hip (square kernels, symmetric stride/padding)."""
+
+    def reset_parameters(self):  # weights always come from a state dict; skip the random init
+        pass
+
+    def banks(self):
+        """(forward bank [taps][cin][cout], backward bank [taps][cout][cin]) cached per weight version."""
+        key = (self.weight.data_ptr(), self.weight._version, self.weight.device)
+        if getattr(self, "_bank_key", None) != key:
+            self._banks = hip.conv_pack_filters(self.weight.detach().contiguous())
+            self._bank_key = key
+        return self._banks
+
+    def bias_device(self):
+        return None if self.bias is None else self.bias.detach()
+
+    def forward(self, x):
+        return _ConvFn.apply(x, self)
+
+
+class _ReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        hip.relu_(x)
+        ctx.mark_dirty(x)
+        ctx.save_for_backward(x)
+        return x
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        return hip.relu_bwd(gy.contiguous(), y)
+
+
+class ReLU(nn.Module):
+    """In-place ReLU, like the reference's nn.ReLU(inplace=True) (models.py:130)."""
+
+    def __init__(self, inplace=True):
+        super().__init__()
+        self.inplace = inplace
+
+    def forward(self, x):
+        if not self.inplace:
+            x = x.clone()
+        elif x.requires_grad and x.is_leaf:
+            x = x.clone()
+        return _ReluFn.apply(x)
+
+
+class _PoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, stride, ceil, mode):
+        xc = x.contiguous()
+        ctx.save_for_backward(xc)
+        ctx.cfg = (k, stride, ceil, mode)
+        return hip.pool2d_fwd(xc, k, stride, ceil, mode)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (xc,) = ctx.saved_tensors
+        k, stride, ceil, mode = ctx.cfg
+        return hip.pool2d_bwd(gy.contiguous(), xc, k, stride, ceil, mode), None, None, None, None
+
+
+def _as_int(v):
+    return int(v[0]) if isinstance(v, (tuple, list)) else int(v)
+
+
+class _Pool2d(nn.Module):
+    mode = "max"
+
+    def __init__(self, kernel_size, stride=None, padding=0, ceil_mode=False):
+        super().__init__()
+        if _as_int(padding) != 0:
+            raise ValueError("pooling with padding is not used by any supported network")
+        self.kernel_size, self.stride = kernel_size, (stride if stride is not None else kernel_size)
+        self.padding, self.ceil_mode = padding, ceil_mode
+
+    def forward(self, x):
+        return _PoolFn.apply(x, _as_int(self.kernel_size), _as_int(self.stride), bool(self.ceil_mode), self.mode)
+
+    def extra_repr(self):
+        return f"kernel_size={self.kernel_size}, stride={self.stride}, ceil_mode={self.ceil_mode}"
+
+
+class MaxPool2d(_Pool2d):
+    mode = "max"
+
+
+class AvgPool2d(_Pool2d):
+    mode = "avg"
+
+
+# --------------------------------------------------------------------------------------------------
+# Architectures (reference models.py:16-139)
+# --------------------------------------------------------------------------------------------------
+channel_list = {
+    "VGG-16p": [24, 22, "P", 41, 51, "P", 108, 89, 111, "P", 184, 276, 228, "P", 512, 512, 512, "P"],
+    "VGG-16": [64, 64, "P", 128, 128, "P", 256, 256, 256, "P", 512, 512, 512, "P", 512, 512, 512, "P"],
+    "VGG-19": [64, 64, "P", 128, 128, "P", 256, 256, 256, 256, "P", 512, 512, 512, 512, "P", 512, 512, 512, 512, "P"],
+}
+
+
+def _pool_layer(pooling, *a, **kw):
+    if pooling == "max":
+        return MaxPool2d(*a, **kw)
+    if pooling == "avg":
+        return AvgPool2d(*a, **kw)
+    raise ValueError("Unrecognized pooling argseter")
+
+
+def build_sequential(channels, pooling):
+    """conv3x3(pad 1)+ReLU stacks separated by ONE shared 2x2 pooling module, as in the reference
+    (models.py:116-132)."""
+    pool2d = _pool_layer(pooling, kernel_size=2, stride=2)
+    layers, cin = [], 3
+    for c in channels:
+        if c == "P":
+            layers.append(pool2d)
+        else:
+            layers += [Conv2d(cin, c, kernel_size=3, padding=1), ReLU(inplace=True)]
+            cin = c
+    return nn.Sequential(*layers)
+
+
+class _FeatureNet(nn.Module):
+    def __init__(self, features):
+        super().__init__()
+        self.features = features
+
+
+class VGG(_FeatureNet):
+    pass
+
+
+class VGG_SOD(_FeatureNet):
+    pass
+
+
+class VGG_FCN32S(_FeatureNet):
+    pass
+
+
+class VGG_PRUNED(_FeatureNet):
+    pass
+
+
+class NIN(nn.Module):
+    """Network-in-Network feature stack (reference models.py:74-113); the trailing 1000-way conv, global
+    pooling and softmax are kept so that state-dict indices line up, load_model never reaches them."""
+
+    def __init__(self, pooling):
+        super().__init__()
+        pool2d = _pool_layer(pooling, (3, 3), (2, 2), (0, 0), ceil_mode=True)
+        spec = [(3, 96, 11, 4, 0), (96, 96, 1, 1, 0), (96, 96, 1, 1, 0), "P",
+                (96, 256, 5, 1, 2), (256, 256, 1, 1, 0), (256, 256, 1, 1, 0), "P",
+                (256, 384, 3, 1, 1), (384, 384, 1, 1, 0), (384, 384, 1, 1, 0), "P", "D",
+                (384, 1024, 3, 1, 1), (1024, 1024, 1, 1, 0), (1024, 1000, 1, 1, 0)]
+        layers = []
+        for s in spec:
+            if s == "P":
+                layers.append(pool2d)
+            elif s == "D":
+                layers.append(nn.Dropout(0.5))
+            else:
+                cin, cout, k, stride, pad = s
+                layers += [Conv2d(cin, cout, (k, k), (stride, stride), (pad, pad)), ReLU(inplace=True)]
+        layers += [nn.AvgPool2d((6, 6), (1, 1), (0, 0), ceil_mode=True), nn.Softmax()]
+        self.features = nn.Sequential(*layers)
+
+
+def _vgg_layer_names(channels):
+    conv, relu, pool, block, i = [], [], [], 1, 1
+    for c in channels:
+        if c == "P":
+            pool.append(f"pool{block}")
+            block, i = block + 1, 1
+        else:
+            conv.append(f"conv{block}_{i}")
+            relu.append(f"relu{block}_{i}")
+            i += 1
+    return {"C": conv, "R": relu, "P": pool}
+
+
+vgg16_dict = _vgg_layer_names(channel_list["VGG-16"])
+vgg19_dict = _vgg_layer_names(channel_list["VGG-19"])
+nin_dict = {
+    "C": ["conv1", "cccp1", "cccp2", "conv2", "cccp3", "cccp4", "conv3", "cccp5", "cccp6", "conv4-1024", "cccp7-1024",
+          "cccp8-1024"],
+    "R": [f"relu{i}" for i in range(1, 13)],
+    "P": [f"pool{i}" for i in range(1, 5)],
+    "D": ["drop"],
+}
+
+# keyword in --model_file -> (wrapper class, channel list, layer-name table, default file); checked in this order
+_VGG_VARIANTS = [
+    ("prun", VGG_PRUNED, "VGG-16p", vgg16_dict, "modelzoo/vgg16-prune.pth"),
+    ("nyud", VGG_FCN32S, "VGG-16", vgg16_dict, "modelzoo/nyud-fcn32s-color-heavy.pth"),
+    ("fcn32s", VGG_FCN32S, "VGG-16", vgg16_dict, "modelzoo/fcn32s-heavy-pascal.pth"),
+    ("sod", VGG_SOD, "VGG-16", vgg16_dict, "modelzoo/vgg16-sod.pth"),
+    ("vgg19", VGG, "VGG-19", vgg19_dict, "modelzoo/vgg19.pth"),
+    ("vgg16", VGG, "VGG-16", vgg16_dict, "modelzoo/vgg16.pth"),
+]
+
+
+def _load_features(cnn, model_file, strict):
+    """load_state_dict for the `features.*` keys only (this build has no classifier to receive the rest)."""
+    sd = torch.load(model_file, map_location="cpu")
+    feats = {k: v for k, v in sd.items() if k.startswith("features.")}
+    own = cnn.state_dict()
+    if strict:
+        missing = [k for k in own if k not in feats]
+        unexpected = [k for k in feats if k not in own]
+        if missing or unexpected:
+            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing}, unexpected {unexpected}")
+    cnn.load_state_dict({k: v for k, v in feats.items() if k in own}, strict=False)
+
+
+def select_model(model_file, pooling, verbose, disable_check):
+    """Pick the architecture from keywords in `model_file` and load its weights (reference models.py:246-347).
+    Returns (cnn with a `.features` Sequential, layer-name table)."""
+    vgg_keywords = ["fcn32s", "prun", "sod", "vgg", "nyud"]
+    if any(k in model_file for k in vgg_keywords):
+        for key, cls, chans, table, default in _VGG_VARIANTS:
+            if key in model_file:
+                if verbose:
+                    print(("VGG-19" if chans == "VGG-19" else "VGG-16") + " Architecture Detected")
+                cnn, layer_list = cls(build_sequential(channel_list[chans], pooling)), table
+                break
+        else:
+            raise ValueError("VGG architecture not recognized.")
+    elif "nin" in model_file:
+        if verbose:
+            print("NIN Architecture Detected")
+        if pooling not in ("max", "avg"):
+            raise ValueError("Unrecognized pooling argseter")
+        cnn, layer_list, default = NIN(pooling), nin_dict, "modelzoo/nin.pth"
+    else:
+        raise ValueError("Model architecture not recognized.")
+    if not path.exists(model_file):
+        model_file = default
+        if not path.exists(model_file):
+            raise FileNotFoundError(
+                f"model weights not found at {model_file}: this build has no network access and never downloads; "
+                "pass --model_file <path to a .pth whose name contains the architecture keyword>")
+    _load_features(cnn, model_file, strict=(not disable_check))
+    if verbose:
+        print("Successfully loaded " + str(model_file))
+    return cnn, layer_list
+
+
+def assemble(features, layer_list, args):
+    """Insert the loss modules into the feature stack and truncate it (reference models.py:359-451).
+    Pure module plumbing - no tensor is touched, so it also runs without a GPU."""
+    content_layers = args.content_layers.split(",")
+    style_layers = args.style_layers.split(",")
+    features = copy.deepcopy(features)
+    content_losses, style_losses, tv_losses, temporal_losses = [], [], [], []
+    next_content_idx, next_style_idx = 1, 1
+    net = nn.Sequential()
+    c, r = 0, 0
+
+    def add(mod, prefix, bucket):
+        mod.name = f"{prefix} {len(net)}"
+        net.add_module(str(len(net)), mod)
+        bucket.append(mod)
+
+    if args.tv_weight > 0:
+        add(TVLoss(args.tv_weight), "tv", tv_losses)
+    if args.temporal_weight > 0:
+        add(ContentLoss(args.temporal_weight, args.normalize_gradients), "temporal", temporal_losses)
+
+    def add_named(layer_name, index):
+        found_content = found_style = False
+        if layer_name in content_layers:
+            if args.verbose:
+                print("Setting up content layer " + str(index) + ": " + str(layer_name))
+            add(ContentLoss(args.content_weight, args.normalize_gradients), "cont", content_losses)
+            found_content = True
+        if layer_name in style_layers:
+            if args.verbose:
+                print("Setting up style layer " + str(index) + ": " + str(layer_name))
+            add(StyleLoss(args.style_weight, args.use_covariance, args.normalize_gradients,
+                          video_style_factor=args.video_style_factor, shift_factor=args.shift_factor),
+                "style", style_losses)
+            found_style = True
+        return found_content, found_style
+
+    for i, layer in enumerate(list(features), 1):
+        if not (next_content_idx <= len(content_layers) or next_style_idx <= len(style_layers)):
+            continue
+        if isinstance(layer, nn.Conv2d):
+            net.add_module(str(len(net)), layer)
+            add_named(layer_list["C"][c], i)
+            c += 1
+        if isinstance(layer, ReLU):
+            net.add_module(str(len(net)), layer)
+            fc, fs = add_named(layer_list["R"][r], i)
+            next_content_idx += int(fc)  # only relu-named layers count towards "done"
+            next_style_idx += int(fs)
+            r += 1
+        if isinstance(layer, _Pool2d):
+            net.add_module(str(len(net)), layer)
+
+    for param in net.parameters():
+        param.requires_grad = False
+    net.content_losses = content_losses
+    net.style_losses = style_losses
+    net.tv_losses = tv_losses
+    net.temporal_losses = temporal_losses
+    return net, content_losses + style_losses + tv_losses + temporal_losses
+
+
+def load_model(args):
+    """Build the loss network for `args` on the current ROCm device (reference models.py:351-453)."""
+    cnn, layer_list = select_model(str(args.model_file).lower(), args.pooling, args.verbose, args.disable_check)
+    if getattr(args, "multidevice", False):
+        raise NotImplementedError(
+            "layer-split multi-GPU (--gpu a,b / --multidevice_strategy) is a memory workaround for 11 GB cards and is "
+            "not part of the MI355X build; shard frames/images across GPUs instead (dist.py)")
+    if "c" in str(args.gpu).lower():
+        raise RuntimeError("--gpu c: this build computes on MI355X through libmaua_hip only; there is no CPU path")
+    hip.lib()  # fail here, loudly, when the HIP library is missing
+    cnn = cnn.cuda()
+    return assemble(cnn.features, layer_list, args)

@@ -1,0 +1,219 @@
+"""The optimisation core with the reference's entry points (reference optim.py).
+
+`optimize(content, styles, init, num_iters, args, net=None, losses=None)` keeps the reference's contract
+(optim.py:111-255): per-size model selection through the scaling table, target capture, L-BFGS or Adam on
+the pixels, CPU fp32 result of init's shape.  What changed is where the loop runs: the image, the network,
+every activation, the L-BFGS history and all scalars live on the MI355X; one iteration is a fixed chain of
+libmaua_hip kernels (engine.StyleEngine for the function evaluation, hip.LbfgsState / hip.adam_step for the
+update) with no host synchronisation - the reference's per-module `.item()` reads (optim.py:210) and
+torch.optim.LBFGS's four host round trips per iteration are gone.  The loss is read back only when
+`--print_iter` fires.
+"""
+import json
+import sys
+
+import torch as th
+import tqdm
+
+import config as config_mod
+import engine as engine_mod
+import hip
+import models
+
+PBAR = tqdm.tqdm(file=sys.stdout, smoothing=0.1, disable=not sys.stdout.isatty())
+
+
+def _describe(text, args):
+    if not args.verbose:
+        PBAR.set_description(text)
+
+
+def _device_image(image, args):
+    return image.to(device="cuda", dtype=th.float32).contiguous()
+
+
+def set_content_targets(net, content_image, args):
+    """One forward pass with the content modules in 'capture' mode (reference optim.py:22-32)."""
+    _describe("Capturing content targets...", args)
+    for mod in net.content_losses:
+        mod.mode = "capture"
+    with th.no_grad():
+        net(_device_image(content_image, args))
+    for mod in net.content_losses:
+        mod.mode = "none"
+
+
+def set_temporal_targets(net, warp_image, warp_weights=None, args=None):
+    """Capture the warped previous frame as pixel-level target, optionally weighted (reference optim.py:35-47)."""
+    _describe("Capturing temporal targets...", args)
+    for mod in net.temporal_losses:
+        mod.mode = "capture"
+        if warp_weights is not None:
+            mod.weights = _device_image(warp_weights, args)
+    with th.no_grad():
+        net(_device_image(warp_image, args))
+    for mod in net.temporal_losses:
+        mod.mode = "none"
+
+
+def set_style_targets(net, style_images, args):
+    """Accumulate blend-weighted Gram targets over the style images (reference optim.py:50-66)."""
+    _describe("Capturing style targets...", args)
+    for mod in net.style_losses:
+        mod.reset_targets()
+        mod.mode = "capture"
+    for i, image in enumerate(style_images):
+        for mod in net.style_losses:
+            mod.blend_weight = args.style_blend_weights[i]
+        with th.no_grad():
+            net(_device_image(image, args))
+    for mod in net.style_losses:
+        mod.mode = "none"
+
+
+def set_style_video_targets(net, style_videos, args):
+    """Window-averaged video style targets (reference optim.py:69-90); img_vid only, outside this build."""
+    raise NotImplementedError("video style targets belong to the img_vid workflow, which this build does not cover")
+
+
+def set_model_args(args, current_size):
+    """Copy onto `args` every key of the first scaling-table entry whose size bound covers `current_size` and
+    that does not need more GPUs than --gpu lists (reference optim.py:93-108).  Like the reference, when no
+    entry qualifies the LAST entry is applied after a warning."""
+    with open(config_mod._resolve(args.scaling_args), "r") as f:
+        scaling = json.load(f)
+    found, params = False, {}
+    for size, params in scaling.items():
+        if int(size) < current_size:
+            continue
+        if len(args.gpu.split(",")) < len(params["gpu"].split(",")):
+            continue
+        found = True
+        break
+    if not found:
+        print("Warning: no model configuration found for this size, out of memory error is likely...")
+    for key, value in params.items():
+        args.__dict__[key] = value
+
+
+def lbfgs_moves(num_iters):
+    """Number of (evaluate, move) pairs torch.optim.LBFGS performs under the reference's driver
+    (`LBFGS(max_iter=N)`, max_eval = 5N//4, `while i[0] <= 1: step(feval)`, optim.py:180-191, 240-241):
+    N >= 4 -> N; N in {2, 3} stop one move early on max_eval; N = 1 runs step() twice."""
+    if num_iters <= 0:
+        return 0
+    if num_iters == 1:
+        return 2
+    if num_iters in (2, 3):
+        return num_iters - 1
+    return num_iters
+
+
+class PixelOptimizer:
+    """The iteration loop for one image: fused feval + device-side optimizer step."""
+
+    def __init__(self, net, losses, init, args):
+        self.args = args
+        try:
+            self.engine = getattr(net, "_maua_engine", None) or engine_mod.StyleEngine(net, losses)
+            net._maua_engine = self.engine
+        except engine_mod.UnsupportedNet:
+            self.engine = None
+        self.net, self.losses = net, losses
+        self.x = _device_image(init, args).clone()
+        self.kind = args.optimizer
+        self.step_count = 0
+        if self.kind == "lbfgs":
+            self.state = hip.LbfgsState(self.x.numel(), int(args.lbfgs_num_correction), self.x.device)
+        elif self.kind == "adam":
+            self.m, self.v = th.zeros_like(self.x), th.zeros_like(self.x)
+        else:
+            raise ValueError(f"unknown optimizer {self.kind}")
+        self.use_graph = bool(getattr(args, "hip_graph", False))
+
+    def feval(self):
+        """(loss slots, total, gradient) at the current image - device tensors, no sync."""
+        if self.engine is not None:
+            try:
+                return self.engine.feval(self.x, capture=self.use_graph)
+            except engine_mod.UnsupportedNet:
+                self.engine = None
+        return self._feval_modules()
+
+    def _feval_modules(self):
+        """Module-by-module evaluation with autograd (still HIP kernels): covers layouts outside the fused plan,
+        e.g. the weighted temporal ContentLoss."""
+        x = self.x.detach().requires_grad_(True)
+        self.net(x)
+        total = 0
+        slots = th.zeros(max(len(self.losses), 1), device=x.device)
+        for idx, mod in enumerate(self.losses):
+            if isinstance(mod.loss, int) and mod.loss == 0:
+                continue
+            slots[idx] = mod.loss.detach()
+            total = total + mod.loss
+        total.backward()
+        for mod in self.losses:
+            mod.loss = 0
+        return slots, total.detach().reshape(1), x.grad.contiguous()
+
+    def step(self):
+        """One iteration: evaluate, then move."""
+        slots, total, grad = self.feval()
+        self.step_count += 1
+        a = self.args
+        if self.kind == "lbfgs":
+            self.state.iterate(self.x, grad, 1.0, float(a.lbfgs_tolerance_change))
+        else:
+            hip.adam_step(self.x, grad, self.m, self.v, self.step_count, float(a.learning_rate))
+        return slots, total
+
+
+def optimize(content, styles, init, num_iters, args, net=None, losses=None):
+    """Optimise `init` towards `content` / `styles`; returns a CPU fp32 tensor shaped like `init`."""
+    if "_vid" in args.transfer_type:
+        raise NotImplementedError("img_vid (sliding style-video windows) is outside this build's scope")
+    if init.shape[0] != 1:
+        raise NotImplementedError("one frame per call (the reference's img_img / vid_img call pattern)")
+
+    if net is None or losses is None:
+        set_model_args(args, max(*init.shape))
+        net, losses = models.load_model(args)
+
+    if not args.verbose:
+        PBAR.reset()
+        PBAR.total = num_iters
+        PBAR.refresh()
+
+    set_content_targets(net, content, args)
+    set_style_targets(net, styles, args)
+    for mod in losses:
+        mod.mode = "loss"
+
+    if args.normalize_weights:  # once per call, strengths are not reset (optim.py:176-178)
+        for mod in net.content_losses + net.style_losses + net.temporal_losses:
+            mod.strength = mod.strength / max(mod.target.size())
+
+    opt = PixelOptimizer(net, losses, init, args)
+    if args.optimizer == "lbfgs":
+        _describe("Running optimization with L-BFGS", args)
+        steps = lbfgs_moves(num_iters)
+    else:
+        _describe("Running optimization with ADAM", args)
+        steps = num_iters + 1  # `while i[0] <= iters` with i starting at 0 (optim.py:240)
+
+    for i in range(1, steps + 1):
+        slots, total = opt.step()
+        if not args.verbose and not (args.optimizer == "adam" and i == 1):
+            PBAR.update(1)
+        if args.print_iter > 0 and i % args.print_iter == 0 and args.verbose:
+            print(f"Iteration {i} / {args.num_iters}, Loss: {float(total)}")
+        if args.save_iter > 0 and (i % args.save_iter == 0 or i == num_iters):
+            import load
+            load.save_tensor_to_file(opt.x.detach().cpu(), args, i if i != num_iters else None, opt.x.size(3))
+        if args.optimizer == "lbfgs" and i % 25 == 0 and opt.state.status()["stopped"]:
+            break  # g.d > -tolerance_change: the reference breaks out of LBFGS.step here
+
+    for mod in losses:
+        mod.loss = 0
+    return opt.x.detach().cpu()

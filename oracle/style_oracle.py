@@ -414,7 +414,7 @@ def _lbfgs_step(x, closure, st, max_iter, history, lr=1.0, tol_grad=-1.0, tol_ch
     return x
 
 
-def lbfgs_run(fg, x0, num_iters, history=100, tol_grad=-1.0, tol_change=-1.0, trace=None):
+def lbfgs_run(fg, x0, num_iters, history=100, tol_grad=-1.0, tol_change=-1.0, trace=None, stats=None):
     """The reference's L-BFGS driver: `LBFGS(max_iter=num_iters)` and `while i[0] <= 1: step(feval)`
     (optim.py:180-191, 240-241) where i[0] counts fevals - so num_iters == 1 runs step() twice.
     fg(x_flat) -> (loss: float, grad_flat)."""
@@ -429,6 +429,8 @@ def lbfgs_run(fg, x0, num_iters, history=100, tol_grad=-1.0, tol_change=-1.0, tr
     x = x0.clone().flatten()
     while calls[0] <= 1:
         x = _lbfgs_step(x, closure, st, num_iters, history, 1.0, tol_grad, tol_change, trace)
+    if stats is not None:
+        stats.update(history_len=len(st.Y), n_iter=st.n_iter, func_evals=st.func_evals)
     return x.reshape(x0.shape), calls[0]
 
 

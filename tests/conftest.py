@@ -60,3 +60,41 @@ def rel_l2(a, b):
     a = torch.as_tensor(a).double().flatten()
     b = torch.as_tensor(b).double().flatten()
     return float((a - b).norm() / b.norm().clamp_min(1e-300))
+
+
+VARIANT_FLAGS = {  # CLI spelling of FEVAL_VARIANTS (what tools/make_golden.py passed to the reference)
+    "default": [],
+    "no_grad_norm": ["--no_grad_norm"],
+    "normalize_weights": ["--normalize_weights", "--temporal_weight", "0"],
+    "avgpool": ["--pooling", "avg"],
+    "no_tv_no_vsf": ["--tv_weight", "0", "--video_style_factor", "0", "--temporal_weight", "0"],
+    "covariance": ["--use_covariance"],
+    "layers_alt": ["--content_layers", "relu3_2,relu4_2", "--style_layers", "relu1_2,relu2_2,relu3_3"],
+    "weights_alt": ["--content_weight", "7.5", "--style_weight", "33", "--tv_weight", "0.02"],
+}
+NIN_FLAGS = ["--style_layers", "relu1,relu3,relu5,relu7,relu9,relu11", "--content_layers", "relu8"]
+
+
+@pytest.fixture(scope="session")
+def weight_files(tmp_path_factory):
+    """Seeded synthetic checkpoints saved under names that carry the architecture keyword."""
+    import synth
+    d = tmp_path_factory.mktemp("weights")
+    paths = {"vgg19": str(d / "vgg19_synth.pth"), "nin": str(d / "nin_synth.pth")}
+    torch.save(synth.vgg19_state_dict(), paths["vgg19"])
+    torch.save(synth.nin_state_dict(), paths["nin"])
+    return paths
+
+
+def product_args(weight_files, extra=(), model="vgg19", optimizer="lbfgs", S=64, N=10, styles=("s.png",)):
+    """Namespace built by the product's own config.get_args, the way a user would call style.py."""
+    import json
+    import config
+    scaling = os.path.join(os.path.dirname(weight_files["vgg19"]), "scaling-test.json")
+    if not os.path.exists(scaling):
+        with open(scaling, "w") as f:
+            json.dump({"100000": {"gpu": "0", "multidevice": False}}, f)
+    argv = ["--content", "c.png", "--style", *styles, "--model_file", weight_files[model], "--disable_check",
+            "--scaling_args", scaling, "--optimizer", optimizer, "--image_sizes", str(S), "--num_iters", str(N),
+            "--seed", "0", "--no_hist_match"] + list(extra)
+    return config.get_args(argv)

@@ -1,0 +1,85 @@
+"""The C-ABI library builds for gfx950, loads without a GPU and exports every symbol include/maua_hip.h declares."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import PKG, REPO
+
+HEADER = os.path.join(REPO, "include", "maua_hip.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(maua_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    import build_native
+    return build_native.build()
+
+
+def test_header_symbols_exported(libpath):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", libpath], text=True)
+    exported = set(re.findall(r" T (maua_[a-z0-9_]+)", out))
+    want = declared_symbols()
+    assert len(want) >= 24
+    missing = [s for s in want if s not in exported]
+    assert not missing, f"declared in maua_hip.h but not exported: {missing}"
+    extra = sorted(exported - set(want))
+    assert not extra, f"exported but not declared in maua_hip.h: {extra}"
+
+
+def test_binding_table_matches_header(libpath):
+    import hip
+    assert sorted(hip.SIGNATURES) == declared_symbols()
+    L = hip.lib()  # dlopen + argtypes for every symbol; no compute call
+    assert L.maua_abi_version() == 1
+
+
+def test_host_only_entry_points(libpath):
+    import hip
+    L = hip.lib()
+    # pooling output sizes = ATen's pooling_output_shape (floor and ceil mode, last window must start inside)
+    import torch.nn.functional as F
+    import torch
+    for n in range(2, 40):
+        for k, s in ((2, 2), (3, 2), (3, 1), (5, 3)):
+            if n < k:
+                continue
+            for ceil in (False, True):
+                want = F.max_pool2d(torch.zeros(1, 1, n, n), k, s, 0, ceil_mode=ceil).shape[-1]
+                assert L.maua_pool_out_size(n, k, s, int(ceil)) == want, (n, k, s, ceil)
+    assert L.maua_pool_out_size(1, 2, 2, 0) == 0
+    assert L.maua_gram_workspace_bytes(64, 1 << 20) > 0
+    assert L.maua_gram_workspace_bytes(0, 5) == 0
+    assert L.maua_lbfgs_state_bytes(3 * 64 * 64, 100) > 2 * 101 * 3 * 64 * 64 * 4
+    assert L.maua_reduce_workspace_bytes(10) >= 8
+
+
+def test_invalid_arguments_are_rejected_without_touching_the_gpu(libpath):
+    import hip
+    L = hip.lib()
+    assert L.maua_conv2d_fwd(None, None, None, None, None, 1, 3, 8, 8, 4, 3, 3, 1, 1, 0, 0, None) == -1
+    assert b"null" in L.maua_last_error()
+    assert L.maua_fill(None, 10, 0.0, None) == -1
+    assert L.maua_lbfgs_iterate(None, None, None, 10, 5, 1.0, -1.0, None) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    import hip
+    monkeypatch.setattr(hip, "_lib", None)
+    monkeypatch.setattr(hip, "LIB_PATH", os.path.join(PKG, "no_such_lib.so"))
+    with pytest.raises(hip.HipError):
+        hip.lib()
+
+
+def test_cpu_tensors_are_refused(libpath):
+    import torch
+    import hip
+    with pytest.raises(hip.HipError):
+        hip.relu_(torch.zeros(4))

@@ -1,0 +1,298 @@
+"""Per-kernel parity of libmaua_hip.so (through the C ABI) against the CPU oracle's arithmetic.
+
+fp32 tolerance: rel-L2 <= 2e-5 for contractions (the summation order differs from MKL-DNN's; K up to
+9*512), exact equality where the op is a selection (pooling forward, ReLU).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import hip as h
+    h.lib()
+    return h
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+CONV_CASES = [
+    # cin, cout, H, W, k, stride, pad
+    (3, 64, 37, 45, 3, 1, 1),
+    (64, 64, 32, 32, 3, 1, 1),
+    (64, 128, 16, 24, 3, 1, 1),
+    (128, 256, 8, 8, 3, 1, 1),
+    (512, 512, 4, 4, 3, 1, 1),
+    (256, 512, 2, 2, 3, 1, 1),
+    (20, 40, 13, 70, 3, 1, 1),       # ragged channel counts (not multiples of the tiles)
+    (64, 3, 33, 31, 3, 1, 1),        # narrow output (shape of conv1_1's backward-data)
+    (96, 96, 30, 30, 1, 1, 0),
+    (384, 1024, 7, 7, 1, 1, 0),
+    (96, 256, 15, 17, 5, 1, 2),
+    (3, 96, 99, 99, 11, 4, 0),
+    (3, 96, 128, 128, 11, 4, 0),
+    (8, 16, 9, 9, 3, 1, 0),          # no padding
+]
+
+
+@pytest.mark.parametrize("cin,cout,H,W,k,stride,pad", CONV_CASES)
+@pytest.mark.parametrize("relu", [False, True])
+def test_conv_fwd(hip, cin, cout, H, W, k, stride, pad, relu):
+    x = rnd(2, cin, H, W, seed=1)
+    w = rnd(cout, cin, k, k, seed=2, scale=math.sqrt(2.0 / (k * k * cin)))
+    b = rnd(cout, seed=3, scale=0.1)
+    ref = F.conv2d(x, w, b, stride=stride, padding=pad)
+    if relu:
+        ref = torch.relu(ref)
+    wf, _ = hip.conv_pack_filters(dev(w))
+    y = hip.conv2d_fwd(dev(x), wf, dev(b), k, stride, pad, relu)
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape
+    assert rel_l2(y.cpu(), ref) <= TOL
+
+
+@pytest.mark.parametrize("cin,cout,H,W,k,stride,pad", CONV_CASES)
+@pytest.mark.parametrize("masked", [False, True])
+def test_conv_bwd_data(hip, cin, cout, H, W, k, stride, pad, masked):
+    x = rnd(1, cin, H, W, seed=1)
+    w = rnd(cout, cin, k, k, seed=2, scale=math.sqrt(2.0 / (k * k * cin)))
+    y = torch.relu(F.conv2d(x, w, None, stride=stride, padding=pad))
+    gy = rnd(*y.shape, seed=4)
+    g_in = gy * (y > 0) if masked else gy
+    ref = torch.nn.grad.conv2d_input(x.shape, w, g_in, stride=stride, padding=pad)
+    _, wb = hip.conv_pack_filters(dev(w))
+    gx = hip.conv2d_bwd_data(dev(gy), dev(y) if masked else None, wb, dev(w), x.shape, k, stride, pad)
+    torch.cuda.synchronize()
+    assert rel_l2(gx.cpu(), ref) <= TOL
+    # accumulate flag adds into the destination
+    base = rnd(*x.shape, seed=5)
+    gx2 = hip.conv2d_bwd_data(dev(gy), dev(y) if masked else None, wb, dev(w), x.shape, k, stride, pad,
+                              out=dev(base.clone()), accumulate=True)
+    torch.cuda.synchronize()
+    assert rel_l2(gx2.cpu(), ref + base) <= TOL
+
+
+def test_conv_rejects_bad_arguments(hip):
+    x = dev(rnd(1, 3, 8, 8))
+    wf, _ = hip.conv_pack_filters(dev(rnd(4, 3, 3, 3)))
+    with pytest.raises(hip.HipError):
+        hip.conv2d_fwd(x, wf, None, 3, 0, 1, False)  # stride 0
+    with pytest.raises(hip.HipError):
+        hip.conv2d_fwd(torch.zeros(1, 3, 8, 8), wf, None, 3, 1, 1, False)  # CPU tensor: no CPU path
+    small = dev(rnd(1, 3, 2, 2))
+    with pytest.raises(hip.HipError):
+        hip.conv2d_fwd(small, wf, None, 3, 1, 0, False)  # input smaller than the filter
+
+
+@pytest.mark.parametrize("C,H,W,k,s,ceil", [(64, 32, 32, 2, 2, False), (5, 7, 9, 2, 2, False), (96, 30, 30, 3, 2, True),
+                                            (16, 31, 29, 3, 2, True), (8, 63, 63, 3, 2, True), (4, 3, 3, 3, 2, True)])
+@pytest.mark.parametrize("mode", ["max", "avg"])
+def test_pool(hip, C, H, W, k, s, ceil, mode):
+    x = torch.relu(rnd(2, C, H, W, seed=7))  # post-ReLU inputs: many exact ties at zero
+    if mode == "max":
+        ref, idx = F.max_pool2d(x, k, s, 0, ceil_mode=ceil, return_indices=True)
+    else:
+        ref = F.avg_pool2d(x, k, s, 0, ceil_mode=ceil)
+    y = hip.pool2d_fwd(dev(x), k, s, ceil, mode)
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape
+    if mode == "max":
+        assert torch.equal(y.cpu(), ref)
+    else:
+        assert rel_l2(y.cpu(), ref) <= 1e-6
+    gy = rnd(*ref.shape, seed=8)
+    xr = x.clone().requires_grad_(True)
+    (F.max_pool2d(xr, k, s, 0, ceil_mode=ceil) if mode == "max" else F.avg_pool2d(xr, k, s, 0, ceil_mode=ceil)).backward(gy)
+    gx = hip.pool2d_bwd(dev(gy), dev(x), k, s, ceil, mode)
+    torch.cuda.synchronize()
+    assert rel_l2(gx.cpu(), xr.grad) <= 1e-6
+
+
+def test_relu(hip):
+    x = rnd(3, 1000, seed=9)
+    y = hip.relu_(dev(x.clone()))
+    assert torch.equal(y.cpu(), torch.relu(x))
+    gy = rnd(3, 1000, seed=10)
+    gx = hip.relu_bwd(dev(gy), y)
+    assert torch.equal(gx.cpu(), gy * (x > 0))
+
+
+@pytest.mark.parametrize("C,HW", [(64, 4096), (64, 1000), (96, 900), (128, 77), (256, 256), (512, 64), (512, 4), (384, 3969),
+                                  (1024, 961), (3, 5)])
+@pytest.mark.parametrize("center", [False, True])
+def test_gram_fwd_bwd(hip, C, HW, center):
+    f = torch.relu(rnd(1, C, HW, 1, seed=11)) + (0.5 if center else 0.0)
+    ff = f.reshape(C, HW)
+    fc = ff - ff.mean(1, keepdim=True) if center else ff
+    scale = 1.0 / (C * HW)
+    ref = (fc.double() @ fc.double().t()) * scale
+    gram, mean = hip.gram_fwd(dev(f), scale, center)
+    torch.cuda.synchronize()
+    assert rel_l2(gram.cpu(), ref) <= TOL
+    assert torch.equal(gram.cpu(), gram.cpu().t())  # mirrored exactly
+    if center:
+        assert rel_l2(mean.cpu(), ff.mean(1)) <= 1e-6
+    # backward: gf (+)= D (F - mean)
+    d = rnd(C, C, seed=12)
+    d = d + d.t()
+    base = rnd(C, HW, seed=13)
+    refb = d.double() @ fc.double()
+    gf = hip.gram_bwd(dev(d), dev(f), mean, dev(torch.zeros(C, HW)), accumulate=False)
+    torch.cuda.synchronize()
+    assert rel_l2(gf.cpu(), refb) <= TOL
+    gf = hip.gram_bwd(dev(d), dev(f), mean, dev(base.clone()), accumulate=True)
+    torch.cuda.synchronize()
+    assert rel_l2(gf.cpu(), refb + base.double()) <= TOL
+
+
+def test_gram_deterministic(hip):
+    f = dev(torch.relu(rnd(1, 128, 64, 64, seed=14)))
+    a, _ = hip.gram_fwd(f, 1e-3)
+    b, _ = hip.gram_fwd(f, 1e-3)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n", [1, 7, 4096, 512 * 512, 3 * 1000 * 1000 + 3])
+def test_mse_fwd_bwd(hip, n):
+    x, t = rnd(n, seed=15), rnd(n, seed=16)
+    base = rnd(n, seed=17)
+    loss = torch.zeros(1, device="cuda")
+    g = dev(base.clone())
+    hip.mse_fwd_bwd(dev(x), dev(t), g, 0.37 / n, 1.7, True, loss)
+    torch.cuda.synchronize()
+    ref = 0.37 * ((x.double() - t.double()) ** 2).mean()
+    assert abs(loss.item() - ref.item()) <= 1e-6 * abs(ref.item())
+    assert rel_l2(g.cpu(), base + 1.7 * (x - t)) <= 1e-6
+    g2 = dev(torch.zeros(n))
+    hip.mse_fwd_bwd(dev(x), dev(t), g2, 1.0, -2.0, False, loss)
+    assert rel_l2(g2.cpu(), -2.0 * (x - t)) <= 1e-6
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 32, 32), (1, 3, 1, 9), (2, 3, 17, 5), (1, 3, 257, 300)])
+def test_tv(hip, shape):
+    x = rnd(*shape, seed=18)
+    x[0, 0, 0, :2] = 0.25  # an exact tie: sign(0) = 0 on both sides
+    xr = x.clone().requires_grad_(True)
+    ref = 0.02 * ((xr[:, :, 1:, :] - xr[:, :, :-1, :]).abs().sum() + (xr[:, :, :, 1:] - xr[:, :, :, :-1]).abs().sum())
+    ref.backward()
+    loss = torch.zeros(1, device="cuda")
+    g = dev(torch.zeros(*shape))
+    hip.tv_fwd_bwd(dev(x), g, 0.02, False, loss)
+    torch.cuda.synchronize()
+    assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item())
+    assert rel_l2(g.cpu(), xr.grad) <= 1e-6
+
+
+def test_adam_matches_torch(hip):
+    n = 10007
+    x0 = rnd(n, seed=19)
+    p = torch.nn.Parameter(x0.clone())
+    opt = torch.optim.Adam([p], lr=1.0)
+    x = dev(x0.clone())
+    m, v = dev(torch.zeros(n)), dev(torch.zeros(n))
+    for step in range(1, 8):
+        g = rnd(n, seed=100 + step) * (1.0 + step)
+        p.grad = g.clone()
+        opt.step()
+        hip.adam_step(x, dev(g), m, v, step, 1.0)
+    torch.cuda.synchronize()
+    assert rel_l2(x.cpu(), p.detach()) <= 1e-6
+
+
+def _toy_problem(n, seed, sigma=0.1):
+    """Smooth non-quadratic objective with its minimiser at 0, evaluated with torch ops on x's device.
+
+    fp32 L-BFGS loses digits in y = g - g_prev whenever the step is tiny compared with the curvature scale
+    (SURVEY.md §7 'catastrophic cancellation'); starting with |x0|_1 ~ 1 and sigma*|H| ~ 0.3 keeps |y| ~ |g|, so
+    this test measures the algorithm (ring, two-loop, step rules) and not that noise."""
+    g = torch.Generator().manual_seed(seed)
+    a = torch.rand(n, generator=g, dtype=torch.float64) * 3 + 0.5
+    q = 0.1 * n * n
+
+    def fg(x):
+        aa = a.to(x.device, x.dtype)
+        r = torch.roll(x, 1)
+        loss = sigma * ((aa * x * x).sum() + q * (x ** 4).sum() + 0.5 * (x * r).sum())
+        grad = sigma * (2 * aa * x + 4 * q * x ** 3 + 0.5 * (r + torch.roll(x, -1)))
+        return float(loss), grad
+    return fg
+
+
+@pytest.mark.parametrize("n,history,iters", [(1000, 100, 30), (5000, 5, 40), (3 * 64 * 64 + 1, 100, 25), (40000, 7, 12)])
+def test_lbfgs_matches_oracle(hip, n, history, iters):
+    """Device L-BFGS (coefficient-space two-loop) vs the oracle's restatement of torch.optim.LBFGS in fp64."""
+    from oracle import lbfgs_run
+    fg = _toy_problem(n, seed=5)
+    gen = torch.Generator().manual_seed(6)
+    x0 = torch.randn(n, generator=gen, dtype=torch.float64) * (1.25 / n)  # |x0|_1 ~ 1
+    x0 = x0.float().double()
+    trace, stats = [], {}
+    ref, _ = lbfgs_run(fg, x0, iters, history=history, trace=trace, stats=stats)
+    x = dev(x0.float())
+    st = hip.LbfgsState(n, history, x.device)
+    for it in range(iters):
+        _, g = fg(x)
+        st.iterate(x, g.contiguous())
+        if it in (0, 1, 2, 3, 5, 8, 11):
+            torch.cuda.synchronize()
+            assert rel_l2(x.cpu(), trace[it]) <= 2e-4, f"move {it}"
+    torch.cuda.synchronize()
+    s = st.status()
+    # pairs with y.s <= 1e-10 are skipped by both (late, tiny steps); allow the borderline ones to differ
+    assert s["n_iter"] == iters and abs(s["history_len"] - stats["history_len"]) <= 2 and not s["stopped"]
+    assert s["history_len"] <= history
+    assert float((x.cpu().double() - ref).norm() / x0.norm()) <= 1e-5
+
+
+def test_lbfgs_far_start_converges_like_the_oracle(hip):
+    """Far from the minimiser the first step is t = 1/|g|_1 << 1 and fp32 cancellation dominates the early moves;
+    both runs must still land on the same point."""
+    from oracle import lbfgs_run
+    n, iters = 6000, 60
+    fg = _toy_problem(n, seed=7, sigma=1.0)
+    x0 = torch.linspace(-2, 2, n, dtype=torch.float64) / n
+    ref, _ = lbfgs_run(fg, x0, iters)
+    x = dev(x0.float())
+    st = hip.LbfgsState(n, 100, x.device)
+    for it in range(iters):
+        st.iterate(x, fg(x)[1].contiguous())
+    torch.cuda.synchronize()
+    assert float((x.cpu().double() - ref).norm() / x0.norm()) <= 1e-3
+    assert float(x.cpu().double().norm() / x0.norm()) <= 1e-3  # converged towards the minimiser
+
+
+def test_lbfgs_stop_flag_and_first_step(hip):
+    """g.d > -tolerance_change stops the update (reference `break`), and the first step is min(1, 1/|g|_1)."""
+    n = 512
+    x0 = rnd(n, seed=21)
+    x = dev(x0.clone())
+    g = rnd(n, seed=22)
+    st = hip.LbfgsState(n, 100, x.device)
+    st.iterate(x, dev(g))
+    torch.cuda.synchronize()
+    t = min(1.0, 1.0 / float(g.abs().sum()))
+    assert rel_l2(x.cpu(), x0 - t * g) <= 1e-6
+    s = st.status()
+    assert abs(s["t"] - t) <= 1e-6 * t and abs(s["gtd"] + float(g.dot(g))) <= 1e-4 * float(g.dot(g))
+    # a huge tolerance_change forces the stop branch on the next call
+    before = x.clone()
+    st.iterate(x, dev(rnd(n, seed=23)), tolerance_change=1e30)
+    torch.cuda.synchronize()
+    assert st.status()["stopped"] and torch.equal(x, before)

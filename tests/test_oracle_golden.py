@@ -147,6 +147,16 @@ def test_trajectory_variants_history_ring_and_adam_lr():
     assert rel_l2(out, g["adam_lr2.5_N8_f32"]) <= max(1e-3, 2 * rel_l2(g["adam_lr2.5_N8_f32"], g["adam_lr2.5_N8_f64"]))
 
 
+def test_trajectory_variants_64():
+    g = gold("traj_vgg19_S64_variants")
+    content, style, init = synth.images(64)
+    sd = synth.vgg19_state_dict()
+    out = optimize(content, [style], init, 12, make_cfg(lbfgs_num_correction=3), sd, dtype=torch.float64)
+    assert rel_l2(out, g["lbfgs_m3_N12_f64"]) <= 1e-7
+    out = optimize(content, [style], init, 8, make_cfg(optimizer="adam", learning_rate=2.5), sd, dtype=torch.float64)
+    assert rel_l2(out, g["adam_lr2.5_N8_f64"]) <= 1e-9
+
+
 def test_lbfgs_eval_counts_match_reference():
     host = json.load(open(os.path.join(GOLDEN, "host_logic.json")))
     from oracle import lbfgs_run, adam_run

@@ -229,6 +229,15 @@ def gen_traj():
         out = run_traj(32, 8, "adam", double, extra=["--learning_rate", "2.5"])
         res[f"adam_lr2.5_N8_{'f64' if double else 'f32'}"] = out.numpy()
     save("traj_vgg19_S32_variants", **res)
+    # the same variants at 64^2: at 32^2 the deepest layers are 2x2, where one ReLU / max-pool decision flipped by a
+    # last-bit difference moves the whole gradient by ~1e-3 (seen on the HIP path), so 32^2 is a poor yardstick
+    res = {}
+    for double in (False, True):
+        out = run_traj(64, 12, "lbfgs", double, extra=["--lbfgs_num_correction", "3"])
+        res[f"lbfgs_m3_N12_{'f64' if double else 'f32'}"] = out.numpy()
+        out = run_traj(64, 8, "adam", double, extra=["--learning_rate", "2.5"])
+        res[f"adam_lr2.5_N8_{'f64' if double else 'f32'}"] = out.numpy()
+    save("traj_vgg19_S64_variants", **res)
 
 
 def gen_nin():
@@ -384,13 +393,24 @@ def gen_host():
     print(f"  wrote {os.path.relpath(path, REPO)}")
 
 
-GROUPS = {"feval": gen_feval, "traj": gen_traj, "nin": gen_nin, "hist": gen_hist, "host": gen_host}
+def gen_traj_variants64():
+    """Only the 64^2 variants block of gen_traj (added later; avoids regenerating the big trajectory file)."""
+    res = {}
+    for double in (False, True):
+        out = run_traj(64, 12, "lbfgs", double, extra=["--lbfgs_num_correction", "3"])
+        res[f"lbfgs_m3_N12_{'f64' if double else 'f32'}"] = out.numpy()
+        out = run_traj(64, 8, "adam", double, extra=["--learning_rate", "2.5"])
+        res[f"adam_lr2.5_N8_{'f64' if double else 'f32'}"] = out.numpy()
+    save("traj_vgg19_S64_variants", **res)
+
+
+GROUPS = {"traj64v": gen_traj_variants64, "feval": gen_feval, "traj": gen_traj, "nin": gen_nin, "hist": gen_hist, "host": gen_host}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     want = sys.argv[1:] or ["all"]
     if "all" in want:
-        want = list(GROUPS)
+        want = [g for g in GROUPS if g != "traj64v"]
     for gname in want:
         GROUPS[gname]()
     meta = {"torch": torch.__version__, "threads": 1, "numpy": np.__version__,
