@@ -71,6 +71,7 @@ struct ConvArgs {
     int relu, accumulate;
 };
 int conv_mfma_dispatch(const ConvArgs& a, int ks, int n, hipStream_t stream);
+int conv_mfma2_dispatch(const ConvArgs& a, int ks, int n, hipStream_t stream);
 int conv_direct_fwd(const float* x, const float* mask, const float* wf, const float* bias, float* y, int n, int cin, int h,
                     int w, int cout, int oh, int ow, int kh, int kw, int stride, int pad, int relu, int accumulate,
                     hipStream_t stream);

@@ -14,6 +14,8 @@
 //
 // The same kernel is the backward-data pass: the caller hands the flipped/transposed bank and, optionally, the
 // saved ReLU output as `mask` so that threshold_backward is applied while the gradient patch is staged.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace maua {
@@ -244,6 +246,8 @@ static int launch_variant(const ConvArgs& a, int n, hipStream_t stream) {
 
 // Picks the tile variant: the 8-row tile unless that leaves fewer than two workgroups per CU.
 int conv_mfma_dispatch(const ConvArgs& a, int ks, int n, hipStream_t stream) {
+    static const bool use_v1 = getenv("MAUA_CONV_V1") != nullptr;  // A/B switch: first-generation kernel
+    if (!use_v1) return conv_mfma2_dispatch(a, ks, n, stream);
     const int64_t opix = (int64_t)a.OH * a.OW;
     const int64_t co_tiles = (a.Cout + 63) / 64;
     const int64_t big_tiles = (ks == 1) ? (opix + 255) / 256 : (int64_t)((a.OW + 31) / 32) * ((a.OH + 7) / 8);
