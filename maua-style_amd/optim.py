@@ -186,7 +186,14 @@ def optimize(content, styles, init, num_iters, args, net=None, losses=None):
         PBAR.refresh()
 
     set_content_targets(net, content, args)
-    set_style_targets(net, styles, args)
+    # Style targets depend only on the style images and blend weights.  The reference recaptures them on every call
+    # (style.py:178 keeps the hoisting commented out); the result is identical, so a prebuilt net that is called again
+    # with the same style tensors (vid_img: once per frame) keeps its targets.
+    key = (tuple((s.data_ptr(), tuple(s.shape), s._version) for s in styles), tuple(args.style_blend_weights))
+    if getattr(net, "_maua_style_key", None) != key or any(m.target.nelement() == 0 for m in net.style_losses):
+        set_style_targets(net, styles, args)
+        net._maua_style_key = key
+        net._maua_style_refs = list(styles)  # keep the tensors alive so that data_ptr stays unique
     for mod in losses:
         mod.mode = "loss"
 

@@ -1,0 +1,134 @@
+"""Command-line entry point and workflow drivers with the reference's argument surface (reference style.py).
+
+    python style.py --content C.png --style S.png [flags of config.py]            (img_img)
+    torchrun --nproc-per-node 8 style.py --transfer_type vid_img --content frames/ --style S.png ...
+
+`img_img` is the reference's coarse-to-fine loop (style.py:22-73): resume by file existence, bilinear rescaling of
+content / styles / previous result, optional histogram matching before and after every scale, optim.optimize per
+scale, PNG per scale.  `vid_img` is the reference's per-frame loop (style.py:145-311) for the flow-less case
+(BASELINE config 4): without optical flow the frames are independent optimisations that share the network and
+the style targets, so they are block-partitioned over the ranks of a torchrun job (dist.py) - one RCCL broadcast
+of weights and style targets, no per-iteration collective, every rank writes its own frames.
+`img_vid` (README of the reference: "not sure if this is actually working") is not provided.
+"""
+import glob  # noqa: F401
+import math
+import os
+import os.path
+
+import numpy as np
+import torch as th
+import torch.nn.functional as F
+
+import config
+import dist
+import load
+import models
+import optim
+from utils import match_histogram, name
+
+
+def _scaled_styles(style_images_big, content_area, args):
+    out = []
+    for img in style_images_big:
+        scale = math.sqrt(content_area / (img.size(3) * img.size(2))) * args.style_scale
+        out.append(F.interpolate(th.clone(img), scale_factor=scale, mode="bilinear", align_corners=False))
+    return out
+
+
+def img_img(args):
+    style_images_big = load.process_style_images(args)
+    content_image_big = match_histogram(load.preprocess(args.content), style_images_big, mode=args.match_histograms)
+    content_size = np.array(content_image_big.size()[-2:])
+    pastiche = load.preprocess(args.init) if args.init not in ("content", "random") else None
+
+    for current_size, num_iters in zip(args.image_sizes, args.num_iters):
+        print("\nCurrent size {}px".format(current_size))
+        done = f"{args.output}_{current_size}.png"
+        if os.path.exists(done):  # resume: a finished scale is reloaded instead of recomputed
+            pastiche = load.preprocess(done)
+            continue
+
+        content_scale = current_size / max(*content_size)
+        content_image = F.interpolate(content_image_big, scale_factor=content_scale, mode="bilinear", align_corners=False)
+        style_images = _scaled_styles(style_images_big, content_image.shape[2] * content_image.shape[3], args)
+
+        hw = tuple(int(v) for v in content_image.shape[2:])
+        if args.init == "random" and pastiche is None:
+            pastiche = th.randn(1, 3, *hw).mul(0.001)
+        elif args.init == "content" and pastiche is None:
+            pastiche = F.interpolate(content_image_big.clone(), hw, mode="bilinear", align_corners=False)
+        else:
+            pastiche = F.interpolate(pastiche.clone(), hw, mode="bilinear", align_corners=False)
+        pastiche = match_histogram(pastiche, style_images_big, mode=args.match_histograms)
+
+        output_image = optim.optimize(content_image, style_images, pastiche, num_iters, args)
+
+        pastiche = match_histogram(output_image.detach().cpu(), style_images_big, mode=args.match_histograms)
+        load.save_tensor_to_file(pastiche.detach().cpu(), args, size=current_size)
+    return pastiche
+
+
+def img_vid(args):
+    raise NotImplementedError("img_vid (style videos with sliding Gram windows) is outside this build's scope")
+
+
+def vid_img(args):
+    """Per-frame stylisation without optical flow, frames sharded over the ranks of the job."""
+    rank, _, world = dist.init()
+    output_dir = args.output_dir + "/" + name(args.content) + "_" + "_".join([name(s) for s in args.style])
+    frames = load.process_content_frames(args.content)
+    lo, hi = dist.shard_range(len(frames), rank, world)
+    mine = frames[lo:hi]
+    content_size = np.array(load.preprocess(frames[0]).size()[-2:])
+    style_images_big = load.process_style_images(args)
+    passes = max(1, args.passes_per_scale)
+
+    prev_size = None
+    for size_n, (current_size, num_iters) in enumerate(zip(args.image_sizes, args.num_iters)):
+        print("\nCurrent size {}px".format(current_size))
+        os.makedirs(output_dir + "/" + str(current_size), exist_ok=True)
+        content_scale = current_size / max(*content_size)
+        content_area = content_scale ** 2 * content_size[0] * content_size[1]
+        style_images = _scaled_styles(style_images_big, content_area, args)
+
+        optim.set_model_args(args, current_size)
+        net, losses = models.load_model(args)
+        dist.broadcast_network(net, src=0)
+
+        for pass_n in range(passes):
+            for frame in mine:
+                args.output = "%s/%s/%s_%s.png" % (output_dir, current_size, pass_n + 1, name(frame))
+                if os.path.isfile(args.output):
+                    print("Skipping pass: %s, frame: %s. File already exists." % (pass_n + 1, name(frame)))
+                    continue
+                print("Optimizing... size: %s, pass: %s, frame: %s" % (current_size, pass_n + 1, name(frame)))
+                content = F.interpolate(load.preprocess(frame), scale_factor=content_scale, mode="bilinear",
+                                        align_corners=False)
+                content = match_histogram(content, style_images_big[0], mode=args.match_histograms)
+                if size_n == 0 and pass_n == 0:
+                    pastiche = th.randn(content.size()).mul(0.001) if args.init == "random" else content.clone()
+                else:  # previous result of this frame: last pass of the previous size, or previous pass of this size
+                    src = ("%s/%s/%s_%s.png" % (output_dir, prev_size, passes, name(frame)) if pass_n == 0 else
+                           "%s/%s/%s_%s.png" % (output_dir, current_size, pass_n, name(frame)))
+                    pastiche = F.interpolate(load.preprocess(src), size=content.size()[2:], mode="bilinear",
+                                             align_corners=False)
+                out = optim.optimize(content, style_images, pastiche, num_iters // passes, args, net, losses)
+                out = match_histogram(out.detach().cpu(), style_images_big[0], mode=args.match_histograms)
+                disp = load.deprocess(out.clone())
+                if args.original_colors == 1:
+                    disp = load.original_colors(load.deprocess(content.clone()), disp)
+                disp.save(str(args.output))
+        prev_size = current_size
+        del net
+        th.cuda.empty_cache()
+    dist.barrier()
+
+
+if __name__ == "__main__":
+    args = config.get_args()
+    if args.seed >= 0:
+        th.manual_seed(args.seed)
+        if th.cuda.is_available():
+            th.cuda.manual_seed_all(args.seed)
+    {"img_img": img_img, "vid_img": vid_img, "img_vid": img_vid}[args.transfer_type](args)

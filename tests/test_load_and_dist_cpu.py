@@ -1,0 +1,105 @@
+"""CPU-side pieces around the hot path: image pre/post-processing against the reference's (torchvision semantics),
+and the frame-sharding / broadcast layer over gloo with world_size 2."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import GOLDEN, PKG, REPO
+
+
+def test_preprocess_deprocess_match_reference():
+    import load
+    g = np.load(os.path.join(GOLDEN, "cli_config1.npz"))
+    import synth
+    pre = load.preprocess(os.path.join(REPO, "tests", "synth_content_256.png"))
+    assert pre.shape == (1, 3, 256, 256) and pre.dtype == torch.float32
+    np.testing.assert_allclose(np.array(synth.checksum(pre)), g["pre_content_checksum"], rtol=1e-12)
+    np.testing.assert_array_equal(pre[0, :, :4, :4].numpy(), g["pre_content_corner"])
+    out = np.asarray(load.deprocess(torch.from_numpy(g["deprocess_probe_in"]).clone()))
+    np.testing.assert_array_equal(out, g["deprocess_probe_out"])  # clamp + 8-bit truncation identical
+
+
+def test_save_naming(tmp_path):
+    import argparse
+    import load
+    args = argparse.Namespace(output=str(tmp_path / "c_s"), original_colors=False, content=None)
+    t = torch.zeros(1, 3, 8, 8)
+    load.save_tensor_to_file(t, args)
+    load.save_tensor_to_file(t, args, size=256)
+    load.save_tensor_to_file(t, args, iteration=7, size=256)
+    assert sorted(os.listdir(tmp_path)) == ["c_s.png", "c_s_256.png", "c_s_256_7.png"]
+
+
+def test_shard_ranges_cover_everything():
+    import dist
+    for n in (1, 7, 8, 64, 65):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                lo, hi = dist.shard_range(n, r, world)
+                assert 0 <= lo <= hi <= n and hi - lo in (n // world, n // world + 1)
+                seen += list(range(lo, hi))
+            assert seen == list(range(n))
+            for i in range(n):
+                lo, hi = dist.shard_range(n, dist.shard_owner(i, n, world), world)
+                assert lo <= i < hi
+
+
+def _worker(rank, world, port, tmp):
+    sys.path[:0] = [REPO, PKG]
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import argparse
+    import dist
+    import models
+    import synth
+    r, _, w = dist.init(backend="gloo")
+    assert (r, w) == (rank, world)
+    # every rank builds the same architecture; only rank 0 has the real weights
+    cnn = models.VGG(models.build_sequential(models.channel_list["VGG-19"][:5], "max"))
+    sd = synth.vgg19_state_dict()
+    if rank == 0:
+        cnn.load_state_dict({k: v for k, v in sd.items() if k in cnn.state_dict()}, strict=False)
+    else:
+        for p in cnn.parameters():
+            p.data.fill_(float("nan"))
+    args = argparse.Namespace(content_layers="relu2_1", style_layers="relu1_1,relu2_1", tv_weight=1e-3, temporal_weight=0.0,
+                              content_weight=5.0, style_weight=100.0, use_covariance=False, normalize_gradients=True,
+                              video_style_factor=100.0, shift_factor=0.0, verbose=False)
+    net, losses = models.assemble(cnn.features, models.vgg19_dict, args)
+    dist.broadcast_network(net, src=0)
+    params = list(net.parameters())  # conv1_1, conv1_2, conv2_1 weights and biases, in order
+    want = [sd[f"features.{i}.{n}"] for i in (0, 2, 5) for n in ("weight", "bias")]
+    assert len(params) == len(want) and all(torch.equal(a, b) for a, b in zip(params, want))
+    # style targets exist on rank 0 only, then on every rank
+    if rank == 0:
+        for i, m in enumerate(net.style_losses):
+            m.target = torch.full((4 + i, 4 + i), 1.5 + i)
+            m.video_target = m.target.clone() * 2
+    dist.broadcast_style_targets(net, src=0)
+    for i, m in enumerate(net.style_losses):
+        assert m.target.shape == (4 + i, 4 + i) and float(m.target[0, 0]) == 1.5 + i
+        assert float(m.video_target[1, 1]) == 2 * (1.5 + i)
+    # frames are block-partitioned; results gathered on every rank
+    n_frames = 5
+    lo, hi = dist.shard_range(n_frames, rank, world)
+    local = {i: torch.full((2,), float(i)) for i in range(lo, hi)}
+    merged = dist.gather_frames(local, n_frames)
+    assert sorted(merged) == list(range(n_frames)) and float(merged[4][0]) == 4.0
+    assert dist.max_over_ranks(float(rank)) == float(world - 1)
+    dist.barrier()
+    open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+
+
+def test_two_rank_gloo_broadcast_and_sharding(tmp_path):
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]

@@ -404,13 +404,102 @@ def gen_traj_variants64():
     save("traj_vgg19_S64_variants", **res)
 
 
-GROUPS = {"traj64v": gen_traj_variants64, "feval": gen_feval, "traj": gen_traj, "nin": gen_nin, "hist": gen_hist, "host": gen_host}
+def _install_torchvision_standins():
+    """Functional stand-ins with torchvision's documented semantics for the four transforms reference load.py uses
+    (SURVEY.md §8c): Lambda, Normalize, ToTensor (uint8 HWC -> float CHW / 255), ToPILImage (mul(255).byte())."""
+    from PIL import Image
+    T = sys.modules["torchvision.transforms"]
+
+    class Lambda:
+        def __init__(self, f):
+            self.f = f
+
+        def __call__(self, x):
+            return self.f(x)
+
+    class Normalize:
+        def __init__(self, mean, std):
+            self.mean, self.std = torch.tensor(mean), torch.tensor(std)
+
+        def __call__(self, x):
+            return (x - self.mean[:, None, None]) / self.std[:, None, None]
+
+    class ToTensor:
+        def __call__(self, img):
+            if isinstance(img, np.ndarray):
+                return torch.from_numpy(img.transpose(2, 0, 1).copy())
+            return torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float() / 255
+
+    class ToPILImage:
+        def __call__(self, t):
+            return Image.fromarray(t.mul(255).byte().permute(1, 2, 0).numpy(), mode="RGB")
+
+    T.Lambda, T.Normalize, T.ToTensor, T.ToPILImage = Lambda, Normalize, ToTensor, ToPILImage
+
+
+def gen_cli():
+    print("[cli] BASELINE config 1 through the reference's own style.img_img (256 px, 50 L-BFGS iterations, CPU)")
+    import shutil
+    _install_torchvision_standins()
+    sys.modules["flow"] = types.ModuleType("flow")
+    import load as ref_load  # noqa: F401
+    import style as ref_style
+    cpng, spng = os.path.join(REPO, "tests", "synth_content_256.png"), os.path.join(REPO, "tests", "synth_style_256.png")
+    outdir = os.path.join(TMP, "out")
+    os.makedirs(outdir, exist_ok=True)
+    argv = ["style.py", "--content", cpng, "--style", spng, "--image_sizes", "256", "--num_iters", "50", "--gpu", "c",
+            "--backend", "mkl", "--model_file", VGG_PATH, "--disable_check", "--scaling_args", SCALING, "--ffmpeg_args",
+            os.path.join(REF, "config", "ffmpeg-libx264.json"), "--seed", "0", "--no_hist_match", "--init", "content",
+            "--output_dir", outdir]
+    old = sys.argv
+    sys.argv = argv
+    try:
+        args = ref_config.get_args()
+    finally:
+        sys.argv = old
+    res = {}
+    pre_c, pre_s = ref_load.preprocess(cpng), ref_load.preprocess(spng)
+    res["pre_content_checksum"] = np.array(synth.checksum(pre_c))
+    res["pre_content_corner"] = pre_c[0, :, :4, :4].numpy()
+    g = torch.Generator().manual_seed(31)
+    probe = torch.rand(1, 3, 16, 16, generator=g) * 300 - 150  # exercises the clamp on both sides
+    res["deprocess_probe_in"] = probe.numpy()
+    res["deprocess_probe_out"] = np.asarray(ref_load.deprocess(probe.clone()))
+    captured = {}
+    real_opt = ref_optim.optimize
+
+    def spy(*a, **k):
+        out = real_opt(*a, **k)
+        captured["out"] = out.detach().clone()
+        return out
+    ref_optim.optimize = spy
+    torch.manual_seed(args.seed)
+    with quiet():
+        ref_style.img_img(args)
+    ref_optim.optimize = real_opt
+    png = os.path.join(outdir, "synth_content_256_synth_style_256_256.png")
+    shutil.copy(png, os.path.join(GOLD, "cli_config1_ref.png"))
+    res["out_f32"] = captured["out"].numpy()
+    # fp64 arbiter on the same preprocessed inputs
+    ref_optim.set_model_args(args, 256)
+    with quiet():
+        net, losses = ref_models.load_model(args)
+    net.double()
+    args.dtype = torch.DoubleTensor
+    with quiet():
+        out64 = ref_optim.optimize(pre_c, [pre_s], pre_c.clone(), 50, args, net, losses).detach()
+    res["out_f64"] = out64.numpy().astype(np.float32)  # stored in fp32: the comparison tolerance is >= 1e-3
+    print("    f32 vs f64 rel-L2 after 50 iterations:", float((captured["out"].double() - out64).norm() / out64.norm()))
+    save("cli_config1", **res)
+
+
+GROUPS = {"cli": gen_cli, "traj64v": gen_traj_variants64, "feval": gen_feval, "traj": gen_traj, "nin": gen_nin, "hist": gen_hist, "host": gen_host}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     want = sys.argv[1:] or ["all"]
     if "all" in want:
-        want = [g for g in GROUPS if g != "traj64v"]
+        want = [g for g in GROUPS if g not in ("traj64v", "cli")] + ["cli"]
     for gname in want:
         GROUPS[gname]()
     meta = {"torch": torch.__version__, "threads": 1, "numpy": np.__version__,
