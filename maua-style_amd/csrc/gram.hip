@@ -14,7 +14,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int GT = 64;       // tile edge (channels)
 constexpr int GK = 64;       // pixels per stage
-constexpr int GLD = GK + 1;  // padded LDS row: lanes of one 32-group hit distinct banks
+constexpr int GRS = GK + 4;  // LDS row stride (floats): 16-byte aligned rows, 4*row mod 64 banks -> conflict-free b128
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ void __launch_bounds__(256)
 row_mean_kernel(const float* __restrict__ f, float* __restrict__ mean, int64_t HW) {
@@ -26,15 +28,20 @@ row_mean_kernel(const float* __restrict__ f, float* __restrict__ mean, int64_t H
     if (threadIdx.x == 0) mean[blockIdx.x] = (float)(acc / (double)HW);
 }
 
+// One workgroup = one upper-triangular 64x64 tile pair (ti <= tj) x one slice of HW.  Each of the 4 waves owns a 32x32
+// block.  LDS tiles are [channel][pixel] exactly as in HBM (16-byte global loads, b128 LDS writes); a lane reads 4
+// consecutive pixels with one ds_read_b128 and uses them as the k-values of 4 MFMAs: half h of the wave takes pixels
+// 8q+4h..8q+4h+3 of every 8-pixel group, the same pixels for the A and the B operand, so the pairing is consistent.
+// On diagonal tiles the (1,0) block is the transpose of (0,1) and is not computed (gram_finish mirrors it).
+template <bool VEC>
 __global__ void __launch_bounds__(256)
 gram_partial_kernel(const float* __restrict__ f, const float* __restrict__ mean, float* __restrict__ partial, int C,
                     int64_t HW, int ksplit, int64_t chunk) {
-    __shared__ float At[GT * GLD];
-    __shared__ float Bt[GT * GLD];
+    __shared__ __attribute__((aligned(16))) float At[GT * GRS];
+    __shared__ __attribute__((aligned(16))) float Bt[GT * GRS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i32 = lane & 31, half = lane >> 5;
     const int wi = wave >> 1, wj = wave & 1;
-    // decode the upper-triangular tile pair
     int pair = blockIdx.x, ti = 0;
     const int ntile = (C + GT - 1) / GT;
     while (pair >= ntile - ti) {
@@ -47,19 +54,35 @@ gram_partial_kernel(const float* __restrict__ f, const float* __restrict__ mean,
     const int64_t p_begin = (int64_t)ks * chunk;
     const int64_t p_end = min(HW, p_begin + chunk);
 
-    constexpr int NL = GT * GK / 256;  // 16 loads per tile per thread
-    float ra[NL], rb[NL];
+    constexpr int NL = GT * GK / 4 / 256;  // 4 quads per tile per thread
+    f32x4 ra[NL], rb[NL];
     auto load_stage = [&](int64_t p0) {
 #pragma unroll
         for (int q = 0; q < NL; ++q) {
             const int e = tid + 256 * q;
-            const int r = e / GK, c = e - r * GK;
-            const int64_t pp = p0 + c;
+            const int r = e / (GK / 4), c4 = (e - r * (GK / 4)) * 4;
+            const int64_t pp = p0 + c4;
             const int rowa = ti * GT + r, rowb = tj * GT + r;
-            float va = 0.f, vb = 0.f;
-            if (pp < p_end) {
-                if (rowa < C) va = f[(int64_t)rowa * HW + pp] - (mean ? mean[rowa] : 0.f);
-                if (!diag && rowb < C) vb = f[(int64_t)rowb * HW + pp] - (mean ? mean[rowb] : 0.f);
+            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (VEC) {
+                if (pp < p_end) {
+                    if (rowa < C) {
+                        va = *reinterpret_cast<const f32x4*>(f + (int64_t)rowa * HW + pp);
+                        if (mean) va -= mean[rowa];
+                    }
+                    if (!diag && rowb < C) {
+                        vb = *reinterpret_cast<const f32x4*>(f + (int64_t)rowb * HW + pp);
+                        if (mean) vb -= mean[rowb];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (pp + k < p_end) {
+                        if (rowa < C) va[k] = f[(int64_t)rowa * HW + pp + k] - (mean ? mean[rowa] : 0.f);
+                        if (!diag && rowb < C) vb[k] = f[(int64_t)rowb * HW + pp + k] - (mean ? mean[rowb] : 0.f);
+                    }
+                }
             }
             ra[q] = va;
             rb[q] = vb;
@@ -69,15 +92,16 @@ gram_partial_kernel(const float* __restrict__ f, const float* __restrict__ mean,
 #pragma unroll
         for (int q = 0; q < NL; ++q) {
             const int e = tid + 256 * q;
-            const int r = e / GK, c = e - r * GK;
-            At[r * GLD + c] = ra[q];
-            if (!diag) Bt[r * GLD + c] = rb[q];
+            const int r = e / (GK / 4), c4 = (e - r * (GK / 4)) * 4;
+            *reinterpret_cast<f32x4*>(At + r * GRS + c4) = ra[q];
+            if (!diag) *reinterpret_cast<f32x4*>(Bt + r * GRS + c4) = rb[q];
         }
     };
 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const bool skip = diag && wi == 1 && wj == 0;  // wave-uniform
 
     if (p_begin < p_end) {
         load_stage(p_begin);
@@ -86,12 +110,16 @@ gram_partial_kernel(const float* __restrict__ f, const float* __restrict__ mean,
             store_stage();
             __syncthreads();
             if (p0 + GK < p_end) load_stage(p0 + GK);
-            const float* bt = diag ? At : Bt;
+            if (!skip) {
+                const float* at = At + (wi * 32 + i32) * GRS + 4 * half;
+                const float* bt = (diag ? At : Bt) + (wj * 32 + i32) * GRS + 4 * half;
 #pragma unroll
-            for (int kk = 0; kk < GK / 2; ++kk) {
-                const float a = At[(wi * 32 + i32) * GLD + 2 * kk + half];
-                const float b = bt[(wj * 32 + i32) * GLD + 2 * kk + half];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+                for (int q = 0; q < GK / 8; ++q) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(at + 8 * q);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(bt + 8 * q);
+#pragma unroll
+                    for (int cp = 0; cp < 4; ++cp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cp], b[cp], acc, 0, 0, 0);
+                }
             }
         }
     }
@@ -116,19 +144,22 @@ gram_finish_kernel(const float* __restrict__ partial, float* __restrict__ gram, 
     const int tj = ti + pair;
     const float* base = partial + (int64_t)blockIdx.x * ksplit * (GT * GT);
     const int e = blockIdx.y * 256 + threadIdx.x;
+    int er = e / GT, ec = e % GT;
+    // diagonal tiles: block (1,0) was not computed, read its mirror image from block (0,1)
+    const int src = (ti == tj && er >= 32 && ec < 32) ? ec * GT + er : e;
     double sd = 0.0;  // up to ~800 slabs: fp64 keeps the split-K sum exact to fp32 rounding
     int k = 0;
     for (; k + 4 <= ksplit; k += 4) {
-        const float v0 = base[(int64_t)(k + 0) * (GT * GT) + e], v1 = base[(int64_t)(k + 1) * (GT * GT) + e];
-        const float v2 = base[(int64_t)(k + 2) * (GT * GT) + e], v3 = base[(int64_t)(k + 3) * (GT * GT) + e];
+        const float v0 = base[(int64_t)(k + 0) * (GT * GT) + src], v1 = base[(int64_t)(k + 1) * (GT * GT) + src];
+        const float v2 = base[(int64_t)(k + 2) * (GT * GT) + src], v3 = base[(int64_t)(k + 3) * (GT * GT) + src];
         sd += (double)v0;
         sd += (double)v1;
         sd += (double)v2;
         sd += (double)v3;
     }
-    for (; k < ksplit; ++k) sd += (double)base[(int64_t)k * (GT * GT) + e];
+    for (; k < ksplit; ++k) sd += (double)base[(int64_t)k * (GT * GT) + src];
     const float s = (float)(sd * (double)scale);
-    const int gi = ti * GT + e / GT, gj = tj * GT + e % GT;
+    const int gi = ti * GT + er, gj = tj * GT + ec;
     if (gi < C && gj < C) {
         gram[(int64_t)gi * C + gj] = s;
         if (ti != tj) gram[(int64_t)gj * C + gi] = s;
@@ -186,8 +217,13 @@ int maua_gram_fwd(const float* f, float* gram, float* row_mean_out, int c, int64
         int rc = check_launch("row_mean_kernel");
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(gram_partial_kernel, dim3(npairs, ksplit), dim3(256), 0, s, f, center ? row_mean_out : nullptr,
-                       (float*)workspace, c, hw, ksplit, chunk);
+    const bool vec = (hw % 4 == 0) && ((uintptr_t)f % 16 == 0);
+    if (vec)
+        hipLaunchKernelGGL(gram_partial_kernel<true>, dim3(npairs, ksplit), dim3(256), 0, s, f,
+                           center ? row_mean_out : nullptr, (float*)workspace, c, hw, ksplit, chunk);
+    else
+        hipLaunchKernelGGL(gram_partial_kernel<false>, dim3(npairs, ksplit), dim3(256), 0, s, f,
+                           center ? row_mean_out : nullptr, (float*)workspace, c, hw, ksplit, chunk);
     int rc = check_launch("gram_partial_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(gram_finish_kernel, dim3(npairs, GT * GT / 256), dim3(256), 0, s, (const float*)workspace, gram, c, ksplit, scale);

@@ -5,13 +5,13 @@
 // 4-5 host synchronisations per iteration.  Here the same recursion is evaluated in the coefficient space of the
 // stored vectors ("vector-free" form): with the basis B = [s_0..s_m, y_0..y_m, g] and its Gram matrix M = B^T B,
 // every dot product of the recursion is a row of M times the coefficient vector, so one iteration needs
-//   1. ONE sweep over the history slab that (a) forms the new pair y = g - g_prev, s = t*d exactly as the reference
-//      does (fp32, elementwise) and (b) computes the dots of every stored vector with (s, y, g)   [lbfgs_pair_dots]
+//   1. the new pair y = g - g_prev, s = t*d formed exactly as the reference does (fp32, elementwise)   [lbfgs_pair]
+//      and ONE sweep over the history slab computing the dots of every stored vector with (s, y, g)  [lbfgs_pair_dots]
 //   2. a fixed-order reduction of the per-workgroup partials                                        [lbfgs_finish_dots]
 //   3. the recursion on (2m+3) coefficients in fp64 by one wave, incl. the y.s > 1e-10 test, the ring
 //      update, H_diag = ys/yy, t, g.d and the stop test g.d > -tolerance_change                     [lbfgs_coeffs]
 //   4. ONE more sweep: d = B * coeff, x += t*d                                                      [lbfgs_combine]
-// = 2 passes over the slab (the algorithmic 4m*n*4 bytes), 4 launches, no host sync, no float atomics.
+// = 2 passes over the slab (the algorithmic 4m*n*4 bytes), 5 launches, no host sync, no float atomics.
 #include "common.hpp"
 
 namespace maua {
@@ -29,7 +29,7 @@ struct LbfgsHeader {
     double reserved[4];
 };
 
-constexpr int LB_EPT = 8;             // elements per thread in the sweeps
+constexpr int LB_EPT = 16;            // elements per thread in the sweeps
 constexpr int LB_WG = 256 * LB_EPT;   // elements per workgroup
 
 struct LbfgsLayout {
@@ -98,12 +98,28 @@ __device__ __forceinline__ void wave_reduce3_store(float a, float b, float c, fl
     }
 }
 
-// Sweep 1.  ids: s-slot p -> p, y-slot p -> m1 + p, g -> 2*m1.  partial[wg][id][4] = per-workgroup dots of vector id
-// with (s_new, y_new, g) and, for id == g only, sum|g| in the 4th slot.
+// Pair update (elementwise): y = g - g_prev and s = t*d go to the candidate slot, g_prev = g.  First call: zeros.
 __global__ void __launch_bounds__(256)
-lbfgs_pair_dots_kernel(const LbfgsHeader* __restrict__ hdr, const float* __restrict__ g, float* __restrict__ g_prev,
-                       const float* __restrict__ d, float* __restrict__ S, float* __restrict__ Y,
-                       float* __restrict__ partial, int64_t n, int m1) {
+lbfgs_pair_kernel(const LbfgsHeader* __restrict__ hdr, const float* __restrict__ g, float* __restrict__ g_prev,
+                  const float* __restrict__ d, float* __restrict__ S, float* __restrict__ Y, int64_t n) {
+    const bool first = hdr->n_iter == 0;
+    const float t = hdr->t;
+    float* sc = S + (int64_t)hdr->cand * n;
+    float* yc = Y + (int64_t)hdr->cand * n;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const float gv = g[e];
+        sc[e] = first ? 0.f : d[e] * t;          // s = d.mul(t)
+        yc[e] = first ? 0.f : gv - g_prev[e];    // y = flat_grad.sub(prev_flat_grad)
+        g_prev[e] = gv;
+    }
+}
+
+// Sweep 1.  ids: s-slot p -> p, y-slot p -> m1 + p, g -> 2*m1.  partial[wg][id][4] = per-workgroup dots of vector id
+// with (s_new, y_new, g) and, for id == g only, sum|g| in the 4th slot.  The candidate pair is read back like any
+// stored pair, so the loop body is uniform: 2*LB_EPT coalesced loads, 6*LB_EPT FMAs, six 64-lane reductions.
+__global__ void __launch_bounds__(256)
+lbfgs_pair_dots_kernel(const LbfgsHeader* __restrict__ hdr, const float* __restrict__ g, const float* __restrict__ S,
+                       const float* __restrict__ Y, float* __restrict__ partial, int64_t n, int m1) {
     extern __shared__ float lds[];  // [4 waves][nb_ids][4]
     const int nb_ids = 2 * m1 + 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -111,63 +127,58 @@ lbfgs_pair_dots_kernel(const LbfgsHeader* __restrict__ hdr, const float* __restr
     __syncthreads();
     float* mine = lds + (size_t)wave * nb_ids * 4;
 
-    const bool first = hdr->n_iter == 0;
     const int cand = hdr->cand, len = hdr->len, head = hdr->head;
-    const float t = hdr->t;
-    const int64_t base = (int64_t)blockIdx.x * LB_WG + tid;
+    const int64_t blk = (int64_t)blockIdx.x * LB_WG;
+    const int rem = (int)min((int64_t)LB_WG, n - blk);  // valid elements of this block
+    int off[LB_EPT];
     float gv[LB_EPT], sv[LB_EPT], yv[LB_EPT];
+    {
+        const float* gB = g + blk;
+        const float* sB = S + (int64_t)cand * n + blk;
+        const float* yB = Y + (int64_t)cand * n + blk;
 #pragma unroll
-    for (int k = 0; k < LB_EPT; ++k) {
-        const int64_t e = base + 256 * k;
-        gv[k] = sv[k] = yv[k] = 0.f;
-        if (e < n) {
-            gv[k] = g[e];
-            if (!first) {
-                yv[k] = gv[k] - g_prev[e];  // y = flat_grad.sub(prev_flat_grad)
-                sv[k] = d[e] * t;           // s = d.mul(t)
-                S[(int64_t)cand * n + e] = sv[k];
-                Y[(int64_t)cand * n + e] = yv[k];
-            }
-            g_prev[e] = gv[k];
+        for (int k = 0; k < LB_EPT; ++k) {
+            const int e = tid + 256 * k;
+            const bool ok = e < rem;
+            off[k] = ok ? e : 0;  // lanes past the end re-read element 0 and multiply it by zero columns
+            gv[k] = ok ? gB[off[k]] : 0.f;
+            sv[k] = ok ? sB[off[k]] : 0.f;
+            yv[k] = ok ? yB[off[k]] : 0.f;
         }
     }
-    // stored pairs
-    for (int i = 0; i < len; ++i) {
-        const int p = (head + i) % m1;
-        const float* sp = S + (int64_t)p * n;
-        const float* yp = Y + (int64_t)p * n;
+#pragma unroll 1
+    for (int i = 0; i <= len; ++i) {  // stored pairs, then the candidate pair
+        const int p = i < len ? (head + i) % m1 : cand;
+        const float* sp = S + (int64_t)p * n + blk;
+        const float* yp = Y + (int64_t)p * n + blk;
+        float ls[LB_EPT], ly[LB_EPT];
+#pragma unroll
+        for (int k = 0; k < LB_EPT; ++k) {
+            ls[k] = sp[off[k]];
+            ly[k] = yp[off[k]];
+        }
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
 #pragma unroll
         for (int k = 0; k < LB_EPT; ++k) {
-            const int64_t e = base + 256 * k;
-            if (e < n) {
-                const float s_ = sp[e], y_ = yp[e];
-                a0 = fmaf(s_, sv[k], a0);
-                a1 = fmaf(s_, yv[k], a1);
-                a2 = fmaf(s_, gv[k], a2);
-                b0 = fmaf(y_, sv[k], b0);
-                b1 = fmaf(y_, yv[k], b1);
-                b2 = fmaf(y_, gv[k], b2);
-            }
+            a0 = fmaf(ls[k], sv[k], a0);
+            a1 = fmaf(ls[k], yv[k], a1);
+            a2 = fmaf(ls[k], gv[k], a2);
+            b0 = fmaf(ly[k], sv[k], b0);
+            b1 = fmaf(ly[k], yv[k], b1);
+            b2 = fmaf(ly[k], gv[k], b2);
         }
         wave_reduce3_store(a0, a1, a2, mine + 4 * p, lane);
         wave_reduce3_store(b0, b1, b2, mine + 4 * (m1 + p), lane);
     }
-    // the candidate pair and g itself, from registers
     {
-        float ss = 0.f, sy = 0.f, sg = 0.f, yy = 0.f, yg = 0.f, gg = 0.f, g1 = 0.f;
+        float sg = 0.f, yg = 0.f, gg = 0.f, g1 = 0.f;
 #pragma unroll
         for (int k = 0; k < LB_EPT; ++k) {
-            ss = fmaf(sv[k], sv[k], ss);
-            sy = fmaf(sv[k], yv[k], sy);
             sg = fmaf(sv[k], gv[k], sg);
-            yy = fmaf(yv[k], yv[k], yy);
             yg = fmaf(yv[k], gv[k], yg);
             gg = fmaf(gv[k], gv[k], gg);
             g1 += fabsf(gv[k]);
         }
-        wave_reduce3_store(ss, sy, sg, mine + 4 * cand, lane);
-        wave_reduce3_store(sy, yy, yg, mine + 4 * (m1 + cand), lane);
         wave_reduce3_store(sg, yg, gg, mine + 4 * (2 * m1), lane);
         g1 = wave_sum(g1);
         if (lane == 0) mine[4 * (2 * m1) + 3] = g1;
@@ -333,31 +344,38 @@ lbfgs_combine_kernel(const LbfgsHeader* __restrict__ hdr, const float* __restric
                      int64_t n, int m1) {
     const int len = hdr->len, head = hdr->head, stopped = hdr->stopped;
     const float t = hdr->t;
-    const int64_t base = (int64_t)blockIdx.x * LB_WG + threadIdx.x;
+    const int64_t blk = (int64_t)blockIdx.x * LB_WG;
+    const int rem = (int)min((int64_t)LB_WG, n - blk);
+    const int tid = threadIdx.x;
     float acc[LB_EPT];
     const float cg = coef[2 * m1];
+    const float* gB = g + blk;
 #pragma unroll
     for (int k = 0; k < LB_EPT; ++k) {
-        const int64_t e = base + 256 * k;
-        acc[k] = e < n ? cg * g[e] : 0.f;
+        const int e = tid + 256 * k;
+        acc[k] = e < rem ? cg * gB[e] : 0.f;
     }
+#pragma unroll 2
     for (int i = 0; i < len; ++i) {
         const int p = (head + i) % m1;
         const float cs = coef[p], cy = coef[m1 + p];
-        const float* sp = S + (int64_t)p * n;
-        const float* yp = Y + (int64_t)p * n;
+        const float* sp = S + (int64_t)p * n + blk;
+        const float* yp = Y + (int64_t)p * n + blk;
 #pragma unroll
         for (int k = 0; k < LB_EPT; ++k) {
-            const int64_t e = base + 256 * k;
-            if (e < n) acc[k] = fmaf(cy, yp[e], fmaf(cs, sp[e], acc[k]));
+            const int e = tid + 256 * k;
+            const int ec = e < rem ? e : 0;
+            acc[k] = fmaf(cy, yp[ec], fmaf(cs, sp[ec], acc[k]));  // lanes past the end accumulate garbage, never stored
         }
     }
+    float* dB = d + blk;
+    float* xB = x + blk;
 #pragma unroll
     for (int k = 0; k < LB_EPT; ++k) {
-        const int64_t e = base + 256 * k;
-        if (e < n) {
-            d[e] = acc[k];
-            if (!stopped) x[e] = fmaf(t, acc[k], x[e]);  // p.add_(d, alpha=t)
+        const int e = tid + 256 * k;
+        if (e < rem) {
+            dB[e] = acc[k];
+            if (!stopped) xB[e] = fmaf(t, acc[k], xB[e]);  // p.add_(d, alpha=t)
         }
     }
 }
@@ -410,9 +428,13 @@ int maua_lbfgs_iterate(void* state, float* x, const float* grad, int64_t count, 
     hipStream_t s = (hipStream_t)stream;
     const size_t lds1 = sizeof(float) * 4 * L.nb_ids * 4;
     MAUA_REQUIRE(lds1 <= 64 * 1024, MAUA_E_UNSUPPORTED, "lbfgs_iterate: history %d too large", history);
-    hipLaunchKernelGGL(lbfgs_pair_dots_kernel, dim3(L.nwg), dim3(256), lds1, s, hdr, grad, g_prev, d, S, Y, partial, count,
-                       L.m1);
-    int rc = check_launch("lbfgs_pair_dots_kernel");
+    int pg = (int)((count + 1023) / 1024);
+    if (pg > 2048) pg = 2048;
+    hipLaunchKernelGGL(lbfgs_pair_kernel, dim3(pg), dim3(256), 0, s, hdr, grad, g_prev, d, S, Y, count);
+    int rc = check_launch("lbfgs_pair_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(lbfgs_pair_dots_kernel, dim3(L.nwg), dim3(256), lds1, s, hdr, grad, S, Y, partial, count, L.m1);
+    rc = check_launch("lbfgs_pair_dots_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(lbfgs_finish_dots_kernel, dim3(L.nb_ids), dim3(256), 0, s, partial, dots, L.nwg, L.nb_ids);
     rc = check_launch("lbfgs_finish_dots_kernel");
