@@ -27,6 +27,8 @@ sys.path[:0] = [REPO, os.path.join(REPO, "maua-style_amd")]
 import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide)
+X6_MFMAS_PER_PRODUCT = 6        # bf16x6: six bf16 MFMAs carry one fp32-accurate product block (conv_x6.hip)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -71,7 +73,7 @@ def cpu_baseline(S_full, optimizer):
     from oracle.style_oracle import _LbfgsState, _lbfgs_step
     import argparse as ap
     cores = os.cpu_count() or 1
-    S = 256 if S_full >= 256 else S_full
+    S = 512 if S_full >= 512 else S_full
     cfg = ap.Namespace(model_file="vgg19", pooling="max", content_layers="relu4_2",
                        style_layers="relu1_1,relu2_1,relu3_1,relu4_1,relu5_1", tv_weight=1e-3, temporal_weight=50.0,
                        content_weight=5.0, style_weight=100.0, use_covariance=False, normalize_gradients=True,
@@ -94,7 +96,7 @@ def cpu_baseline(S_full, optimizer):
         total, _, g = net.feval(x.reshape(shape))
         return float(total), g.flatten()
 
-    iters = 4
+    iters = 40  # ~10-30 s of CPU work on the hosts seen so far
     st = _LbfgsState()
     t0 = time.perf_counter()
     _lbfgs_step(init.flatten().clone(), closure, st, iters, 100)
@@ -196,8 +198,16 @@ def main():
             d[1] += e0.elapsed_time(e1)
             d[2] += fl
             d[3] += nb
-        roofline = {"bound": "mfma", "kernel": "conv_mfma_kernel (fwd + bwd-data)", "achieved": round(achieved, 2),
-                    "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+        x6 = opt.engine is not None and opt.engine.x6_fwd and opt.engine.x6_bwd
+        # fp32-accurate products on the bf16 matrix cores cost six MFMAs each: the attainable rate of ALGORITHMIC
+        # (fp32-equivalent) FLOPs is the dense bf16 peak / 6; with the fp32 matrix cores it is the fp32 MFMA peak
+        peak = BF16_MFMA_PEAK_TFLOPS / X6_MFMAS_PER_PRODUCT if x6 else FP32_MFMA_PEAK_TFLOPS
+        roofline = {"bound": "mfma",
+                    "kernel": "conv_x6_kernel (3x3 conv fwd + bwd-data, bf16x6)" if x6 else "conv_mfma2_kernel (fwd + bwd-data)",
+                    "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                    "peak_note": ("algorithmic fp32-equivalent FLOPs; peak = 2500 TFLOP/s dense bf16 / 6 MFMAs per product block; "
+                                  "hardware bf16 rate = achieved x 6.67 (6 MFMAs, 10 taps per 9)") if x6 else "fp32 MFMA peak",
+                    "hw_bf16_tflops": round(achieved * 6 * 10 / 9, 1) if x6 else None,
                     "traffic": None, "launches": len(conv), "avg_launch_ms": round(tot_ms / len(conv), 4),
                     "flops_per_launch_avg": tot_fl / len(conv),
                     "per_kernel_ms_per_step": {k: round(v[1] / a.steps, 4) for k, v in by_tag.items()},
@@ -207,7 +217,8 @@ def main():
         "metric": "optimizer iterations/sec at 1024x1024 VGG-19" if S == 1024 else f"optimizer iterations/sec at {S}x{S} VGG-19",
         "value": round(a.steps * world / elapsed, 4), "unit": "iterations/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32 (3x3 convs: exact 3-way bf16 split of both operands on the bf16 matrix cores, fp32 accumulate)"
+                 if (opt.engine is not None and opt.engine.x6_fwd) else "f32", "data": "synthetic",
         "config": {"workload": f"{S}x{S} single-scale VGG-19 Gram style transfer, {a.optimizer.upper()}"
                                f"{' history ' + str(a.history) + ' (full)' if prefill else ''}, one image per GPU, "
                                "content 5 / style 100 / tv 1e-3, normalize_gradients, seeded synthetic weights and images",

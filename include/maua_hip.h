@@ -60,12 +60,27 @@ int maua_conv2d_fwd(const float* x, const float* in_mask, const float* wf, const
                     int h, int w, int cout, int kh, int kw, int stride, int pad, int relu, int accumulate,
                     maua_stream_t stream);
 
-/* gx = conv_transpose(gy * (mask > 0), w): gradient w.r.t. the conv input.  gy/out_mask: [n][cout][oh][ow] (mask nullable,
- * it is the saved ReLU output of this conv), gx: [n][cin][h][w].  wb: backward bank (stride 1) or the OIHW weights
- * themselves (stride > 1, direct path: pass w_oihw and wb = NULL). */
-int maua_conv2d_bwd_data(const float* gy, const float* out_mask, const float* wb, const float* w_oihw, float* gx, int n,
-                         int cin, int h, int w, int cout, int kh, int kw, int stride, int pad, int accumulate,
-                         maua_stream_t stream);
+/* gx = conv_transpose(gy * (out_mask > 0), w): gradient w.r.t. the conv input.  gy/out_mask: [n][cout][oh][ow] (mask
+ * nullable, it is the saved ReLU output of this conv), gx: [n][cin][h][w].  wb: backward bank (stride 1) or the OIHW
+ * weights themselves (stride > 1, direct path: pass w_oihw and wb = NULL).  in_relu_mask (nullable, shape of gx): the
+ * result is zeroed where it is <= 0 - the threshold_backward of the ReLU that produced this conv's INPUT, applied by the
+ * producer of the gradient so that the next backward pass needs no mask while staging. */
+int maua_conv2d_bwd_data(const float* gy, const float* out_mask, const float* wb, const float* w_oihw,
+                         const float* in_relu_mask, float* gx, int n, int cin, int h, int w, int cout, int kh, int kw,
+                         int stride, int pad, int accumulate, maua_stream_t stream);
+
+/* ---- 3x3 stride-1 convolution at fp32 accuracy on the bf16 matrix cores (three-way bf16 split of both operands, six
+ *      MFMAs per product block; conv_x6.hip).  Same math as maua_conv2d_fwd / maua_conv2d_bwd_data for k = 3, s = 1. ---- */
+/* Bytes of one pre-split bank for a pass that PRODUCES `cout_produced` channels from `cin_consumed` channels. */
+size_t maua_conv_x6_bank_bytes(int cout_produced, int cin_consumed);
+/* OIHW fp32 weights [cout][cin][3][3] -> forward bank (maua_conv_x6_bank_bytes(cout, cin)) and backward-data bank
+ * (maua_conv_x6_bank_bytes(cin, cout), taps flipped, roles swapped).  Either destination may be NULL. */
+int maua_conv_pack_filters_x6(const float* w_oihw, void* bank_fwd, void* bank_bwd, int cout, int cin, maua_stream_t stream);
+/* y[n][cout][h+2p-2][w+2p-2] = act(bias + conv3x3(x, bank)) (+ y if accumulate), then zeroed where out_relu_mask <= 0
+ * (nullable; the ReLU mask a backward-data pass applies on behalf of its consumer).  Forward: bank_fwd, pad p.
+ * Backward-data of a pad-p conv: x = gradient w.r.t. the conv output, bank_bwd, cin/cout exchanged, pad 2-p. */
+int maua_conv3x3_x6(const float* x, const void* bank, const float* bias, const float* out_relu_mask, float* y, int n,
+                    int cin, int h, int w, int cout, int pad, int relu, int accumulate, maua_stream_t stream);
 
 /* ---- ReLU on its own (module path; the engine fuses it into the convs): models.py:130 ------------- */
 int maua_relu_fwd(float* x_inplace, int64_t count, maua_stream_t stream);
@@ -76,9 +91,10 @@ int maua_pool_out_size(int in, int k, int stride, int ceil_mode);
 /* mode: 0 = max (first maximum in scan order wins, NaN propagates), 1 = avg (divisor = window clipped to the input). */
 int maua_pool2d_fwd(const float* x, float* y, int n, int c, int h, int w, int k, int stride, int ceil_mode, int mode,
                     maua_stream_t stream);
-/* gx[n][c][h][w] (overwritten): gather form, recomputes each window's argmax from x (no index tensor, no atomics). */
+/* gx[n][c][h][w] (overwritten): gather form, recomputes each window's argmax from x (no index tensor, no atomics).
+ * relu_mask_by_x != 0: gx is additionally zeroed where x <= 0 (x is a ReLU output; its threshold_backward fused here). */
 int maua_pool2d_bwd(const float* gy, const float* x, float* gx, int n, int c, int h, int w, int k, int stride,
-                    int ceil_mode, int mode, maua_stream_t stream);
+                    int ceil_mode, int mode, int relu_mask_by_x, maua_stream_t stream);
 
 /* ---- Gram / covariance matrix: loss.GramMatrix.forward, loss.py:67-91 (torch.mm at :91) ----------- */
 /* gram[C][C] = scale * Fc Fc^T with Fc = f[C][hw] (minus row means when `center` != 0, loss.py:87-89).
@@ -90,16 +106,19 @@ int maua_gram_fwd(const float* f, float* gram, float* row_mean_out, int c, int64
 
 /* ---- MSE forward + backward in one pass: nn.MSELoss at loss.py:56 (content) and :154/:178 (style) - */
 /* loss_out[0] = loss_scale * sum((x - target)^2) ; grad (nullable) (+)= grad_scale * (x - target).
+ * mask_grad_by_x != 0: the (accumulated) gradient is zeroed where x <= 0 (x is a ReLU output).
  * Used for ContentLoss on feature maps (grad accumulates into the feature gradient) and for StyleLoss on C x C
  * Gram matrices (grad = the matrix D fed to maua_gram_bwd).  workspace: maua_reduce_workspace_bytes(count). */
 size_t maua_reduce_workspace_bytes(int64_t count);
 int maua_mse_fwd_bwd(const float* x, const float* target, float* grad, int64_t count, float loss_scale, float grad_scale,
-                     int accumulate, float* loss_out, void* workspace, size_t workspace_bytes, maua_stream_t stream);
+                     int accumulate, int mask_grad_by_x, float* loss_out, void* workspace, size_t workspace_bytes,
+                     maua_stream_t stream);
 
 /* Backward of the Gram loss into the feature map: gf[C][hw] (+)= D[C][C] (symmetric) * (f - mean) ;
- * autograd of torch.mm(x, x.t()) at loss.py:91 with the MSE gradient D (scaled by the caller). */
-int maua_gram_bwd(const float* d_sym, const float* f, const float* row_mean, float* gf, int c, int64_t hw, int accumulate,
-                  void* workspace, size_t workspace_bytes, maua_stream_t stream);
+ * autograd of torch.mm(x, x.t()) at loss.py:91 with the MSE gradient D (scaled by the caller).  relu_mask (nullable,
+ * shape of gf): result zeroed where it is <= 0. */
+int maua_gram_bwd(const float* d_sym, const float* f, const float* row_mean, const float* relu_mask, float* gf, int c,
+                  int64_t hw, int accumulate, void* workspace, size_t workspace_bytes, maua_stream_t stream);
 
 /* ---- total variation: loss.TVLoss.forward, loss.py:224-233, and its autograd ---------------------- */
 /* loss_out[0] = strength * (sum|dy| + sum|dx|); grad (+)= strength * d/dx.  workspace as for the MSE. */

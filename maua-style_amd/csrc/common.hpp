@@ -69,14 +69,17 @@ struct ConvArgs {
     int Cin, H, W, Cout, OH, OW, pad;
     int tiles_x;
     int relu, accumulate;
+    const void* w6;      // bf16x3 filter bank of conv_x6.hip (maua_conv_pack_filters_x6), else null
+    const float* omask;  // nullable, output-shaped: result is zeroed where omask <= 0 (ReLU mask applied by the producer)
 };
 int conv_mfma_dispatch(const ConvArgs& a, int ks, int n, hipStream_t stream);
 int conv_mfma2_dispatch(const ConvArgs& a, int ks, int n, hipStream_t stream);
 int conv_direct_fwd(const float* x, const float* mask, const float* wf, const float* bias, float* y, int n, int cin, int h,
                     int w, int cout, int oh, int ow, int kh, int kw, int stride, int pad, int relu, int accumulate,
                     hipStream_t stream);
-int conv_direct_bwd(const float* gy, const float* mask, const float* w_oihw, float* gx, int n, int cin, int h, int w,
-                    int cout, int oh, int ow, int kh, int kw, int stride, int pad, int accumulate, hipStream_t stream);
+int conv_direct_bwd(const float* gy, const float* mask, const float* w_oihw, const float* omask, float* gx, int n, int cin,
+                    int h, int w, int cout, int oh, int ow, int kh, int kw, int stride, int pad, int accumulate,
+                    hipStream_t stream);
 
 inline int reduce_blocks(int64_t count, int per_block) {
     int64_t b = (count + per_block - 1) / per_block;

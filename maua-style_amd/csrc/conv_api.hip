@@ -44,9 +44,9 @@ int maua_conv2d_fwd(const float* x, const float* in_mask, const float* wf, const
                            (hipStream_t)stream);
 }
 
-int maua_conv2d_bwd_data(const float* gy, const float* out_mask, const float* wb, const float* w_oihw, float* gx, int n,
-                         int cin, int h, int w, int cout, int kh, int kw, int stride, int pad, int accumulate,
-                         maua_stream_t stream) {
+int maua_conv2d_bwd_data(const float* gy, const float* out_mask, const float* wb, const float* w_oihw,
+                         const float* in_relu_mask, float* gx, int n, int cin, int h, int w, int cout, int kh, int kw,
+                         int stride, int pad, int accumulate, maua_stream_t stream) {
     MAUA_REQUIRE(gy && gx && (wb || w_oihw), MAUA_E_INVAL, "conv2d_bwd_data: null pointer");
     MAUA_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0, MAUA_E_INVAL,
                  "conv2d_bwd_data: bad dims");
@@ -59,6 +59,7 @@ int maua_conv2d_bwd_data(const float* gy, const float* out_mask, const float* wb
         a.mask = out_mask;
         a.w = wb;
         a.bias = nullptr;
+        a.omask = in_relu_mask;
         a.y = gx;
         a.Cin = cout;
         a.H = oh;
@@ -73,7 +74,7 @@ int maua_conv2d_bwd_data(const float* gy, const float* out_mask, const float* wb
         return conv_mfma_dispatch(a, kh, n, (hipStream_t)stream);
     }
     MAUA_REQUIRE(w_oihw, MAUA_E_INVAL, "conv2d_bwd_data: the direct path needs the OIHW weights");
-    return conv_direct_bwd(gy, out_mask, w_oihw, gx, n, cin, h, w, cout, oh, ow, kh, kw, stride, pad, accumulate,
+    return conv_direct_bwd(gy, out_mask, w_oihw, in_relu_mask, gx, n, cin, h, w, cout, oh, ow, kh, kw, stride, pad, accumulate,
                            (hipStream_t)stream);
 }
 

@@ -40,8 +40,8 @@ conv_direct_fwd_kernel(const float* __restrict__ x, const float* __restrict__ ma
 
 __global__ void __launch_bounds__(256)
 conv_direct_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ mask, const float* __restrict__ w_oihw,
-                       float* __restrict__ gx, int Cin, int H, int W, int Cout, int OH, int OW, int KH, int KW,
-                       int stride, int pad, int accumulate) {
+                       const float* __restrict__ omask, float* __restrict__ gx, int Cin, int H, int W, int Cout, int OH,
+                       int OW, int KH, int KW, int stride, int pad, int accumulate) {
     const int64_t ipix = (int64_t)H * W;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int ci = blockIdx.y, n = blockIdx.z;
@@ -70,6 +70,7 @@ conv_direct_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ m
     }
     const int64_t o = ((int64_t)n * Cin + ci) * ipix + idx;
     if (accumulate) acc += gx[o];
+    if (omask) acc = omask[o] > 0.f ? acc : 0.f;
     gx[o] = acc;
 }
 
@@ -82,11 +83,12 @@ int conv_direct_fwd(const float* x, const float* mask, const float* wf, const fl
     return check_launch("conv_direct_fwd_kernel");
 }
 
-int conv_direct_bwd(const float* gy, const float* mask, const float* w_oihw, float* gx, int n, int cin, int h, int w,
-                    int cout, int oh, int ow, int kh, int kw, int stride, int pad, int accumulate, hipStream_t stream) {
+int conv_direct_bwd(const float* gy, const float* mask, const float* w_oihw, const float* omask, float* gx, int n, int cin,
+                    int h, int w, int cout, int oh, int ow, int kh, int kw, int stride, int pad, int accumulate,
+                    hipStream_t stream) {
     dim3 grid((unsigned)(((int64_t)h * w + 255) / 256), (unsigned)cin, (unsigned)n);
-    hipLaunchKernelGGL(conv_direct_bwd_kernel, grid, dim3(256), 0, stream, gy, mask, w_oihw, gx, cin, h, w, cout, oh, ow,
-                       kh, kw, stride, pad, accumulate);
+    hipLaunchKernelGGL(conv_direct_bwd_kernel, grid, dim3(256), 0, stream, gy, mask, w_oihw, omask, gx, cin, h, w, cout,
+                       oh, ow, kh, kw, stride, pad, accumulate);
     return check_launch("conv_direct_bwd_kernel");
 }
 

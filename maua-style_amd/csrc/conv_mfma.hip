@@ -205,6 +205,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs p) {
                     const int64_t o = (int64_t)co * out_plane + opix;
                     if (p.accumulate) v += yout[o];
                     if (p.relu) v = v > 0.f ? v : 0.f;
+                    if (p.omask) v = p.omask[(int64_t)n * p.Cout * out_plane + o] > 0.f ? v : 0.f;
                     yout[o] = v;
                 }
             }

@@ -242,6 +242,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma2_kernel(ConvArgs p) {
 
     // ---- epilogue ----------------------------------------------------------------------------------------------
     float* __restrict__ yout = p.y + (int64_t)n * p.Cout * out_plane;
+    const float* __restrict__ om = p.omask ? p.omask + (int64_t)n * p.Cout * out_plane : nullptr;
 #pragma unroll
     for (int u = 0; u < TPX; ++u) {
         int64_t opix;
@@ -265,6 +266,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma2_kernel(ConvArgs p) {
                     const int64_t o = (int64_t)co * out_plane + opix;
                     if (p.accumulate) v += yout[o];
                     if (p.relu) v = v > 0.f ? v : 0.f;
+                    if (om) v = om[o] > 0.f ? v : 0.f;
                     yout[o] = v;
                 }
             }

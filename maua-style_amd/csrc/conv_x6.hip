@@ -1,0 +1,314 @@
+// 3x3 stride-1 convolution with fp32-level accuracy on the bf16 matrix cores ("bf16x6").
+//
+// An fp32 value splits exactly into three bf16 parts x = xh + xm + xl (8 significant bits each).  A product of two
+// fp32 numbers is then the sum of nine bf16 x bf16 products, each exact in fp32; the six largest
+//        xh*wh + (xh*wm + xm*wh) + (xh*wl + xm*wm + xl*wh)
+// carry everything down to 2^-24 relative, i.e. fp32 rounding level.  Six v_mfma_f32_32x32x16_bf16 (1024 FLOP/clk/SIMD)
+// replace sixteen v_mfma_f32_32x32x2_f32 (64 FLOP/clk/SIMD) worth of work: 2.67x the fp32 matrix rate at the same
+// accuracy, with fp32 accumulation inside the MFMA.
+//
+// Geometry: workgroup = 4 waves = 64 output channels x (4 rows x 32 px); wave = 64 co x one 32-px row (two 32x32
+// accumulators).  K is consumed in chunks of 8 input channels; one MFMA k-step (K = 16) = two taps x 8 channels (lane
+// half h takes tap 2s+h; the ninth tap pairs with a zero A operand).  LDS holds ONE chunk: three bf16 images of the
+// patch [part][pos][8ch] (16 B per position: conflict-free b128 reads and writes) and the filter slice
+// [tap][co][part][8ch] (48-byte lane stride: conflict-free) = 37.6 KB, so four workgroups share a CU (4 waves/SIMD)
+// and hide each other's barriers.  The filter bank is pre-split on the device once (maua_conv_pack_filters_x6) in
+// exactly the LDS order, so a chunk's slice is one contiguous 27 KB block copied by 27 global_load_lds_dwordx4
+// (no VGPRs); activations are split while they are staged (v_cvt_pk_bf16_f32 + subtract).
+// The ReLU mask of a backward-data pass is NOT applied here while staging; it is applied by the producer of the
+// gradient (`omask` in this kernel's epilogue, the pooling backward, the loss kernels).
+#include <stdlib.h>
+
+#include "common.hpp"
+
+namespace maua {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+constexpr int X6_COT = 64;                    // output channels per workgroup
+constexpr int X6_PH = 4, X6_PR = 6, X6_PC = 34;
+constexpr int X6_NPOS = X6_PR * X6_PC;        // 204
+constexpr int X6_NPOS_PAD = 208;
+constexpr int X6_PATCH_BYTES = 3 * X6_NPOS_PAD * 16;      // 9984
+constexpr int X6_W_BYTES = 9 * X6_COT * 3 * 16;           // 27648 = 27 x 1024
+constexpr int X6_PIECES = X6_W_BYTES / 1024;
+
+__device__ __forceinline__ unsigned short bf16_bits(float x) {
+    const __bf16 b = (__bf16)x;  // v_cvt_pk_bf16_f32: round to nearest even
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float bf16_value(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
+
+// x -> (hi, mid, lo) bf16 bit patterns with x == hi + mid + lo (exactly, barring underflow of the last part)
+__device__ __forceinline__ void split3(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
+    h = bf16_bits(x);
+    const float r1 = x - bf16_value(h);
+    m = bf16_bits(r1);
+    const float r2 = r1 - bf16_value(m);
+    l = bf16_bits(r2);
+}
+
+// bank[dir][chunk][cotile][tap][co][part][ch]: fwd: co = output channel, ch = input channel, tap = ky*3+kx;
+// bwd-data: roles swapped and taps flipped.  Zero padding for channels beyond the tensor.
+__global__ void pack_x6_kernel(const float* __restrict__ w, unsigned short* __restrict__ bank, int cout, int cin,
+                               int backward) {
+    const int CO = backward ? cin : cout;   // channels produced by the pass
+    const int CI = backward ? cout : cin;   // channels consumed
+    const int nchunk = (CI + 7) / 8, ntile = (CO + X6_COT - 1) / X6_COT;
+    const int64_t total = (int64_t)nchunk * ntile * 9 * X6_COT * 8;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = e;
+        const int ch = (int)(r % 8);
+        r /= 8;
+        const int co = (int)(r % X6_COT);
+        r /= X6_COT;
+        const int tap = (int)(r % 9);
+        r /= 9;
+        const int tile = (int)(r % ntile);
+        const int chunk = (int)(r / ntile);
+        const int o = tile * X6_COT + co, i = chunk * 8 + ch;
+        float v = 0.f;
+        if (o < CO && i < CI) {
+            if (!backward) v = w[((int64_t)o * cin + i) * 9 + tap];
+            else v = w[((int64_t)i * cin + o) * 9 + (8 - tap)];
+        }
+        unsigned short h, m, l;
+        split3(v, h, m, l);
+        const int64_t base = ((((int64_t)chunk * ntile + tile) * 9 + tap) * X6_COT + co) * 24 + ch;
+        bank[base] = h;
+        bank[base + 8] = m;
+        bank[base + 16] = l;
+    }
+}
+
+template <bool TL>
+__global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[X6_PATCH_BYTES + X6_W_BYTES];
+    unsigned char* Pl = smem;                    // [part][pos][16 B]
+    unsigned char* Wl = smem + X6_PATCH_BYTES;   // [tap][co][part][16 B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    const int n = blockIdx.z;
+    const int cotile = blockIdx.y;
+    const int co0 = cotile * X6_COT;
+    const int ntile = gridDim.y;
+    const int in_plane = p.H * p.W;
+    const int64_t out_plane = (int64_t)p.OH * p.OW;
+    const float* __restrict__ xin = p.x + (int64_t)n * p.Cin * in_plane;
+    const int x0 = (blockIdx.x % p.tiles_x) * 32, y0 = (blockIdx.x / p.tiles_x) * X6_PH;
+
+    // staging descriptor of this thread's patch position
+    int p_off = -1;
+    if (tid < X6_NPOS) {
+        const int r = tid / X6_PC, col = tid - r * X6_PC;
+        const int iy = y0 + r - p.pad, ix = x0 + col - p.pad;
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) p_off = iy * p.W + ix;
+    }
+    float rp[8];
+    auto load_patch = [&](int c0) {
+        asm volatile("" : "+s"(c0));
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const bool ok = p_off >= 0 && c0 + c < p.Cin;
+            const int64_t a = ok ? (int64_t)(c0 + c) * in_plane + p_off : 0;
+            const float v = xin[a];
+            rp[c] = ok ? v : 0.f;
+        }
+    };
+    auto store_patch = [&]() {
+        if (tid < X6_NPOS_PAD) {
+            unsigned short h[8], m[8], l[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) split3(rp[c], h[c], m[c], l[c]);
+            u32x4 vh, vm, vl;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                vh[q] = (unsigned)h[2 * q] | ((unsigned)h[2 * q + 1] << 16);
+                vm[q] = (unsigned)m[2 * q] | ((unsigned)m[2 * q + 1] << 16);
+                vl[q] = (unsigned)l[2 * q] | ((unsigned)l[2 * q + 1] << 16);
+            }
+            *reinterpret_cast<u32x4*>(Pl + (0 * X6_NPOS_PAD + tid) * 16) = vh;
+            *reinterpret_cast<u32x4*>(Pl + (1 * X6_NPOS_PAD + tid) * 16) = vm;
+            *reinterpret_cast<u32x4*>(Pl + (2 * X6_NPOS_PAD + tid) * 16) = vl;
+        }
+    };
+    const unsigned char* __restrict__ bank = reinterpret_cast<const unsigned char*>(p.w6);
+    auto dma_filters = [&](int ch) {
+        const unsigned char* src = bank + ((int64_t)ch * ntile + cotile) * X6_W_BYTES;
+        for (int q = __builtin_amdgcn_readfirstlane(wave); q < X6_PIECES; q += 4) {  // uniform piece index: 1 KiB each
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + q * 1024 + lane * 16),
+                (__attribute__((address_space(3))) void*)(Wl + q * 1024), 16, 0, 0);
+        }
+    };
+
+    // fragment addresses: tap of this lane half for k-step s is 2s + half (clamped to 8 for the padding k-step)
+    int b_byte[5], a_byte[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int tap = min(2 * s + half, 8);
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        b_byte[s] = ((wave + ky) * X6_PC + j + kx) * 16;
+        a_byte[s] = ((tap * X6_COT + j) * 3) * 16;
+    }
+
+    // two-level accumulation (TL): fold the running sums into a master accumulator every FLUSH chunks so that no fp32
+    // accumulation chain is longer than FLUSH*5*6 MFMA additions (same idea as conv_mfma2.hip)
+    constexpr int FLUSH = 1;
+    f32x16 acc[2], master[TL ? 2 : 1];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[t][r] = 0.f;
+            if constexpr (TL) master[t][r] = 0.f;
+        }
+
+    const int nchunks = (p.Cin + 7) / 8;
+    load_patch(0);
+    store_patch();
+    dma_filters(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA completion
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const bool more = ch + 1 < nchunks;
+        if (more) load_patch((ch + 1) * 8);
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            bf16x8 b[3], a[2][3];
+#pragma unroll
+            for (int part = 0; part < 3; ++part)
+                b[part] = *reinterpret_cast<const bf16x8*>(Pl + part * X6_NPOS_PAD * 16 + b_byte[s]);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int part = 0; part < 3; ++part) {
+                    bf16x8 v = *reinterpret_cast<const bf16x8*>(Wl + a_byte[s] + (t * 32 * 3 + part) * 16);
+                    if (s == 4 && half == 1) {  // ninth tap has no partner: zero A on the upper half
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = (__bf16)0.f;
+                    }
+                    a[t][part] = v;
+                }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                // smallest terms first
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][2], b[0], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][1], b[1], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[2], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][1], b[0], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[1], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[0], acc[t], 0, 0, 0);
+            }
+        }
+        if constexpr (TL) {
+            if ((ch & (FLUSH - 1)) == FLUSH - 1 || !more) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        master[t][r] += acc[t][r];
+                        acc[t][r] = 0.f;
+                    }
+            }
+        }
+        __syncthreads();  // every wave is done reading this chunk
+        if (more) {
+            store_patch();
+            dma_filters(ch + 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane holds pixel column j of row y0+wave; register r is output channel (r&3)+8*(r>>2)+4*half of block t
+    float* __restrict__ yout = p.y + (int64_t)n * p.Cout * out_plane;
+    const float* __restrict__ om = p.omask ? p.omask + (int64_t)n * p.Cout * out_plane : nullptr;
+    const int oy = y0 + wave, ox = x0 + j;
+    const bool pvalid = oy < p.OH && ox < p.OW;
+    const int64_t opix = (int64_t)oy * p.OW + ox;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (pvalid && co < p.Cout) {
+                float v = TL ? master[t][r] : acc[t][r];
+                if (p.bias) v += p.bias[co];
+                const int64_t o = (int64_t)co * out_plane + opix;
+                if (p.accumulate) v += yout[o];
+                if (p.relu) v = v > 0.f ? v : 0.f;
+                if (om) v = om[o] > 0.f ? v : 0.f;
+                yout[o] = v;
+            }
+        }
+    }
+}
+
+int conv_x6_launch(const ConvArgs& a, int n, hipStream_t stream) {
+    ConvArgs p = a;
+    p.tiles_x = (a.OW + 31) / 32;
+    const int64_t tiles = (int64_t)p.tiles_x * ((a.OH + X6_PH - 1) / X6_PH);
+    dim3 grid((unsigned)tiles, (unsigned)((a.Cout + X6_COT - 1) / X6_COT), (unsigned)n);
+    if ((a.Cin + 7) / 8 > 4) hipLaunchKernelGGL(conv_x6_kernel<true>, grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(conv_x6_kernel<false>, grid, dim3(256), 0, stream, p);
+    return check_launch("conv_x6_kernel");
+}
+
+}  // namespace maua
+
+using namespace maua;
+
+extern "C" {
+
+size_t maua_conv_x6_bank_bytes(int cout_produced, int cin_consumed) {
+    if (cout_produced <= 0 || cin_consumed <= 0) return 0;
+    const size_t nchunk = (cin_consumed + 7) / 8, ntile = (cout_produced + X6_COT - 1) / X6_COT;
+    return nchunk * ntile * X6_W_BYTES;
+}
+
+int maua_conv_pack_filters_x6(const float* w_oihw, void* bank_fwd, void* bank_bwd, int cout, int cin, maua_stream_t stream) {
+    MAUA_REQUIRE(w_oihw && (bank_fwd || bank_bwd) && cout > 0 && cin > 0, MAUA_E_INVAL, "conv_pack_filters_x6: bad args");
+    if (bank_fwd) {
+        hipLaunchKernelGGL(pack_x6_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, w_oihw, (unsigned short*)bank_fwd,
+                           cout, cin, 0);
+        int rc = check_launch("pack_x6_kernel");
+        if (rc) return rc;
+    }
+    if (bank_bwd) {
+        hipLaunchKernelGGL(pack_x6_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, w_oihw, (unsigned short*)bank_bwd,
+                           cout, cin, 1);
+        return check_launch("pack_x6_kernel");
+    }
+    return MAUA_OK;
+}
+
+int maua_conv3x3_x6(const float* x, const void* bank, const float* bias, const float* out_relu_mask, float* y, int n,
+                    int cin, int h, int w, int cout, int pad, int relu, int accumulate, maua_stream_t stream) {
+    MAUA_REQUIRE(x && bank && y, MAUA_E_INVAL, "conv3x3_x6: null pointer");
+    MAUA_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0 && pad >= 0 && pad <= 2, MAUA_E_INVAL, "conv3x3_x6: bad dims");
+    MAUA_REQUIRE(h + 2 * pad >= 3 && w + 2 * pad >= 3, MAUA_E_UNSUPPORTED, "conv3x3_x6: input smaller than the filter");
+    MAUA_REQUIRE((int64_t)h * w < (1ll << 31), MAUA_E_UNSUPPORTED, "conv3x3_x6: plane too large");
+    ConvArgs a{};
+    a.x = x;
+    a.w6 = bank;
+    a.bias = bias;
+    a.omask = out_relu_mask;
+    a.y = y;
+    a.Cin = cin;
+    a.H = h;
+    a.W = w;
+    a.Cout = cout;
+    a.OH = h + 2 * pad - 2;
+    a.OW = w + 2 * pad - 2;
+    a.pad = pad;
+    a.relu = relu;
+    a.accumulate = accumulate;
+    return conv_x6_launch(a, n, (hipStream_t)stream);
+}
+
+}  // extern "C"

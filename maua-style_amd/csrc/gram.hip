@@ -230,8 +230,8 @@ int maua_gram_fwd(const float* f, float* gram, float* row_mean_out, int c, int64
     return check_launch("gram_finish_kernel");
 }
 
-int maua_gram_bwd(const float* d_sym, const float* f, const float* row_mean, float* gf, int c, int64_t hw, int accumulate,
-                  void* workspace, size_t workspace_bytes, maua_stream_t stream) {
+int maua_gram_bwd(const float* d_sym, const float* f, const float* row_mean, const float* relu_mask, float* gf, int c,
+                  int64_t hw, int accumulate, void* workspace, size_t workspace_bytes, maua_stream_t stream) {
     MAUA_REQUIRE(d_sym && f && gf && c > 0 && hw > 0, MAUA_E_INVAL, "gram_bwd: bad args");
     MAUA_REQUIRE(hw < (1ll << 31), MAUA_E_UNSUPPORTED, "gram_bwd: plane too large");
     float* bias = nullptr;
@@ -249,6 +249,7 @@ int maua_gram_bwd(const float* d_sym, const float* f, const float* row_mean, flo
     a.mask = nullptr;
     a.w = d_sym;  // symmetric: [k][c] layout == [c][k]
     a.bias = bias;
+    a.omask = relu_mask;
     a.y = gf;
     a.Cin = c;
     a.Cout = c;

@@ -110,7 +110,7 @@ __global__ void pool_fwd_kernel(const float* __restrict__ x, float* __restrict__
 }
 
 __global__ void pool_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x, float* __restrict__ gx,
-                                int64_t planes, int H, int W, int OH, int OW, int k, int s, int mode) {
+                                int64_t planes, int H, int W, int OH, int OW, int k, int s, int mode, int relu_mask) {
     const int64_t total = planes * H * W;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int ix = (int)(e % W);
@@ -132,6 +132,7 @@ __global__ void pool_bwd_kernel(const float* __restrict__ gy, const float* __res
                     acc += gplane[oy * OW + ox] / (float)((y1 - y0) * (x1 - x0));
                 }
             }
+        if (relu_mask && !(plane[iy * W + ix] > 0.f)) acc = 0.f;  // threshold_backward of the ReLU that produced x
         gx[e] = acc;
     }
 }
@@ -140,13 +141,17 @@ __global__ void pool_bwd_kernel(const float* __restrict__ gy, const float* __res
 // MSE: partial[b] = sum over the block's elements of (x-t)^2 (double); grad (+)= gs * (x - t).
 __global__ void __launch_bounds__(256)
 mse_kernel(const float* __restrict__ x, const float* __restrict__ t, float* __restrict__ grad, int64_t n, float gs,
-           int accumulate, double* __restrict__ partial) {
+           int accumulate, int mask_by_x, double* __restrict__ partial) {
     __shared__ double scratch[16];
     double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float d = x[i] - t[i];
         acc += (double)d * (double)d;
-        if (grad) grad[i] = accumulate ? fmaf(gs, d, grad[i]) : gs * d;
+        if (grad) {
+            float g = accumulate ? fmaf(gs, d, grad[i]) : gs * d;
+            if (mask_by_x && !(x[i] > 0.f)) g = 0.f;  // x is a ReLU output: apply its threshold_backward here
+            grad[i] = g;
+        }
     }
     acc = block_sum(acc, scratch);
     if (threadIdx.x == 0) partial[blockIdx.x] = acc;
@@ -258,27 +263,28 @@ int maua_pool2d_fwd(const float* x, float* y, int n, int c, int h, int w, int k,
 }
 
 int maua_pool2d_bwd(const float* gy, const float* x, float* gx, int n, int c, int h, int w, int k, int stride,
-                    int ceil_mode, int mode, maua_stream_t stream) {
+                    int ceil_mode, int mode, int relu_mask_by_x, maua_stream_t stream) {
     MAUA_REQUIRE(gy && x && gx && n > 0 && c > 0 && h > 0 && w > 0 && k > 0 && stride > 0 && (mode == 0 || mode == 1),
                  MAUA_E_INVAL, "pool2d_bwd: bad args");
     const int oh = maua_pool_out_size(h, k, stride, ceil_mode), ow = maua_pool_out_size(w, k, stride, ceil_mode);
     MAUA_REQUIRE(oh > 0 && ow > 0, MAUA_E_UNSUPPORTED, "pool2d_bwd: input %dx%d smaller than window %d", h, w, k);
     const int64_t total = (int64_t)n * c * h * w;
     hipLaunchKernelGGL(pool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, gy, x, gx, (int64_t)n * c,
-                       h, w, oh, ow, k, stride, mode);
+                       h, w, oh, ow, k, stride, mode, relu_mask_by_x);
     return check_launch("pool_bwd_kernel");
 }
 
 size_t maua_reduce_workspace_bytes(int64_t count) { return (size_t)reduce_blocks(count, 1024) * sizeof(double); }
 
 int maua_mse_fwd_bwd(const float* x, const float* target, float* grad, int64_t count, float loss_scale, float grad_scale,
-                     int accumulate, float* loss_out, void* workspace, size_t workspace_bytes, maua_stream_t stream) {
+                     int accumulate, int mask_grad_by_x, float* loss_out, void* workspace, size_t workspace_bytes,
+                     maua_stream_t stream) {
     MAUA_REQUIRE(x && target && loss_out && workspace && count > 0, MAUA_E_INVAL, "mse_fwd_bwd: bad args");
     const int nb = reduce_blocks(count, 1024);
     MAUA_REQUIRE(workspace_bytes >= nb * sizeof(double), MAUA_E_WORKSPACE, "mse_fwd_bwd: workspace %zu < %zu",
                  workspace_bytes, nb * sizeof(double));
     hipLaunchKernelGGL(mse_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, target, grad, count, grad_scale,
-                       accumulate, (double*)workspace);
+                       accumulate, mask_grad_by_x, (double*)workspace);
     int rc = check_launch("mse_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, nb,

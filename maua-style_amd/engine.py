@@ -17,6 +17,8 @@ Gradient weights follow the reference's ScaleGradients quirk (loss.py:10-20, SUR
 Activations and gradient buffers are allocated once per image size and reused by every iteration, so an
 iteration allocates nothing and can be captured into a hipGraph (`capture=True`).
 """
+import os
+
 import torch
 
 import hip
@@ -50,6 +52,11 @@ class StyleEngine:
         self.steps = self._plan(list(net))
         self.shape = None
         self.graph = None
+        # 3x3 stride-1 convs run on the bf16 matrix cores with a 3-way operand split (fp32 accuracy, conv_x6.hip) unless
+        # MAUA_CONV_X6=0 asks for the fp32-MFMA kernels (A/B comparisons)
+        mode = os.environ.get("MAUA_CONV_X6", "1")  # "1" both passes, "fwd" / "bwd" one of them, "0" off
+        self.use_x6 = mode != "0"
+        self.x6_fwd, self.x6_bwd = mode in ("1", "fwd"), mode in ("1", "bwd")
         self.timer = None  # bench.py: list receiving (tag, algorithmic flops, bytes, start event, end event) per launch
 
     # -- planning --------------------------------------------------------------------------------------
@@ -193,6 +200,10 @@ class StyleEngine:
         nbytes = (ob + ob + wbytes + ib) if backward else (ib + wbytes + ob)
         return flops, nbytes
 
+    def _x6_ok(self, s, produced_channels):
+        """bf16x6 kernel: 3x3, stride 1, and enough produced channels to fill its 64-channel tile."""
+        return self.use_x6 and s.k == 3 and s.stride == 1 and s.pad <= 2 and produced_channels > 32
+
     def _run(self, x):
         a, g = self.act, self.gbuf
         a[0] = x
@@ -200,10 +211,15 @@ class StyleEngine:
         # ---------------- forward
         for s in self.steps:
             if s.kind == "conv":
-                wf, _ = s.mod.banks()
                 fl, nb = self._conv_work(s, a[s.src].shape, a[s.dst].shape, False)
-                self._timed("conv_fwd", fl, nb, lambda: hip.conv2d_fwd(
-                    a[s.src], wf, s.mod.bias_device(), s.k, s.stride, s.pad, s.relu, out=a[s.dst]))
+                if self.x6_fwd and self._x6_ok(s, s.mod.out_channels):
+                    b6, _ = s.mod.banks6()
+                    self._timed("conv_fwd", fl, nb, lambda: hip.conv3x3_x6(
+                        a[s.src], b6, s.mod.bias_device(), s.mod.out_channels, s.pad, s.relu, out=a[s.dst]))
+                else:
+                    wf, _ = s.mod.banks()
+                    self._timed("conv_fwd", fl, nb, lambda: hip.conv2d_fwd(
+                        a[s.src], wf, s.mod.bias_device(), s.k, s.stride, s.pad, s.relu, out=a[s.dst]))
             elif s.kind == "relu":
                 hip.relu_(a[s.src])
             elif s.kind == "pool":
@@ -218,6 +234,18 @@ class StyleEngine:
                 hip.mse_fwd_bwd(self.gram[id(s)], s.mod.target, self.dmat[id(s)], lw / (c * c), gw * 4.0 / (c * c) / n,
                                 False, self.slots[s.slot:s.slot + 1], workspace=self.ws)
         # ---------------- backward
+        # Gradient buffers of fused conv+ReLU activations are kept PRE-MASKED: the last kernel that writes g[k] (the
+        # backward of the consumer, or the last loss term attached to k) zeroes it where a[k] <= 0, so no backward-data
+        # pass has to apply threshold_backward while it stages its input.
+        final_writer = {}
+        for s in self.steps:  # forward order == reverse of execution order: the first hit per activation wins
+            if s.kind in ("conv", "pool") or (s.kind in ("style", "content") and self._active(s, a[s.src].shape)):
+                final_writer.setdefault(s.src, s)
+        relu_acts = {s.dst for s in self.steps if s.kind == "conv" and s.relu}
+
+        def premask(s):
+            return final_writer.get(s.src) is s and s.src in relu_acts
+
         cur = None  # activation index whose gradient buffer currently holds d loss / d act
         for s in reversed(self.steps):
             if s.kind == "style":
@@ -225,15 +253,16 @@ class StyleEngine:
                     f = a[s.src]
                     c, n = f.shape[1], f[0].nelement()
                     acc = cur == s.src
+                    rm = f if premask(s) else None
                     self._timed("gram_bwd", 2 * c * c * (n // c), n * 4 * 3 + c * c * 4, lambda: hip.gram_bwd(
-                        self.dmat[id(s)], f, self.mean[id(s)], g[s.src], acc, workspace=self.ws))
+                        self.dmat[id(s)], f, self.mean[id(s)], g[s.src], acc, workspace=self.ws, relu_mask=rm))
                     cur = s.src
             elif s.kind == "content":
                 if self._active(s, a[s.src].shape):
                     lw, gw = self._coefficients(s)
                     n = a[s.src].nelement()
                     hip.mse_fwd_bwd(a[s.src], s.mod.target, g[s.src], lw / n, gw * 2.0 / n, cur == s.src,
-                                    self.slots[s.slot:s.slot + 1], workspace=self.ws)
+                                    self.slots[s.slot:s.slot + 1], workspace=self.ws, mask_grad_by_x=premask(s))
                     cur = s.src
             elif s.kind == "tv":
                 hip.tv_fwd_bwd(a[0], g[0], s.mod.strength, cur == 0, self.slots[s.slot:s.slot + 1], workspace=self.ws)
@@ -242,17 +271,24 @@ class StyleEngine:
                 continue  # nothing flows through layers behind the last loss
             elif s.kind == "conv":
                 assert cur == s.dst
-                _, wb = s.mod.banks()
                 fl, nb = self._conv_work(s, a[s.src].shape, a[s.dst].shape, True)
-                self._timed("conv_bwd", fl, nb, lambda: hip.conv2d_bwd_data(
-                    g[s.dst], a[s.dst] if s.relu else None, wb, s.mod.weight.detach(), a[s.src].shape, s.k, s.stride,
-                    s.pad, out=g[s.src]))
+                im = a[s.src] if premask(s) else None
+                if self.x6_bwd and self._x6_ok(s, s.mod.in_channels):
+                    _, b6 = s.mod.banks6()
+                    self._timed("conv_bwd", fl, nb, lambda: hip.conv3x3_x6(
+                        g[s.dst], b6, None, s.mod.in_channels, 2 - s.pad, False, out=g[s.src], out_relu_mask=im))
+                else:
+                    _, wb = s.mod.banks()
+                    self._timed("conv_bwd", fl, nb, lambda: hip.conv2d_bwd_data(
+                        g[s.dst], None, wb, s.mod.weight.detach(), a[s.src].shape, s.k, s.stride, s.pad, out=g[s.src],
+                        in_relu_mask=im))
                 cur = s.src
             elif s.kind == "relu":
                 hip.relu_bwd(g[s.src], a[s.src], out=g[s.src])
             elif s.kind == "pool":
                 assert cur == s.dst
-                hip.pool2d_bwd(g[s.dst], a[s.src], s.k, s.stride, s.ceil, s.mode, out=g[s.src])
+                hip.pool2d_bwd(g[s.dst], a[s.src], s.k, s.stride, s.ceil, s.mode, out=g[s.src],
+                               relu_mask_by_x=premask(s))
                 cur = s.src
         if cur != 0:
             hip.fill_(g[0], 0.0)

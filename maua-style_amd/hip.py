@@ -24,17 +24,20 @@ SIGNATURES = {
     "maua_last_error": (ctypes.c_char_p, []),
     "maua_conv_pack_filters": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "maua_conv2d_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
-    "maua_conv2d_bwd_data": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "maua_conv2d_bwd_data": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "maua_conv_x6_bank_bytes": (c_sz, [c_i, c_i]),
+    "maua_conv_pack_filters_x6": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p]),
+    "maua_conv3x3_x6": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "maua_relu_fwd": (c_i, [c_p, c_i64, c_p]),
     "maua_relu_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_p]),
     "maua_pool_out_size": (c_i, [c_i, c_i, c_i, c_i]),
     "maua_pool2d_fwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
-    "maua_pool2d_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "maua_pool2d_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "maua_gram_workspace_bytes": (c_sz, [c_i, c_i64]),
     "maua_gram_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i64, c_f, c_i, c_p, c_sz, c_p]),
     "maua_reduce_workspace_bytes": (c_sz, [c_i64]),
-    "maua_mse_fwd_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_f, c_f, c_i, c_p, c_p, c_sz, c_p]),
-    "maua_gram_bwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i64, c_i, c_p, c_sz, c_p]),
+    "maua_mse_fwd_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_f, c_f, c_i, c_i, c_p, c_p, c_sz, c_p]),
+    "maua_gram_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i64, c_i, c_p, c_sz, c_p]),
     "maua_tv_fwd_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_p, c_sz, c_p]),
     "maua_fill": (c_i, [c_p, c_i64, c_f, c_p]),
     "maua_axpy": (c_i, [c_p, c_p, c_f, c_i64, c_p]),
@@ -134,13 +137,35 @@ def conv2d_fwd(x, wf, bias, k, stride, pad, relu, out=None, in_mask=None, accumu
     return out
 
 
-def conv2d_bwd_data(gy, out_mask, wb, w_oihw, in_shape, k, stride, pad, out=None, accumulate=False):
+def conv2d_bwd_data(gy, out_mask, wb, w_oihw, in_shape, k, stride, pad, out=None, accumulate=False, in_relu_mask=None):
     n, cin, h, w = in_shape
     cout = gy.shape[1]
     if out is None:
         out = torch.empty(n, cin, h, w, device=gy.device, dtype=torch.float32)
-    _check(lib().maua_conv2d_bwd_data(_ptr(_f32(gy, "gy")), _ptr(out_mask), _ptr(wb), _ptr(w_oihw), _ptr(out), n, cin, h,
-                                      w, cout, k, k, stride, pad, int(accumulate), _stream()), "maua_conv2d_bwd_data")
+    _check(lib().maua_conv2d_bwd_data(_ptr(_f32(gy, "gy")), _ptr(out_mask), _ptr(wb), _ptr(w_oihw), _ptr(in_relu_mask),
+                                      _ptr(out), n, cin, h, w, cout, k, k, stride, pad, int(accumulate), _stream()),
+           "maua_conv2d_bwd_data")
+    return out
+
+
+def conv_pack_filters_x6(w):
+    """OIHW 3x3 weights -> (forward bank, backward-data bank) of pre-split bf16 triples (uint8 tensors)."""
+    cout, cin, kh, kw = w.shape
+    if kh != 3 or kw != 3:
+        raise HipError("the bf16x6 path covers 3x3 filters")
+    bf = torch.empty(lib().maua_conv_x6_bank_bytes(cout, cin), dtype=torch.uint8, device=w.device)
+    bb = torch.empty(lib().maua_conv_x6_bank_bytes(cin, cout), dtype=torch.uint8, device=w.device)
+    _check(lib().maua_conv_pack_filters_x6(_ptr(_f32(w, "w")), bf.data_ptr(), bb.data_ptr(), cout, cin, _stream()),
+           "maua_conv_pack_filters_x6")
+    return bf, bb
+
+
+def conv3x3_x6(x, bank, bias, cout, pad, relu, out=None, out_relu_mask=None, accumulate=False):
+    n, cin, h, w = x.shape
+    if out is None:
+        out = torch.empty(n, cout, h + 2 * pad - 2, w + 2 * pad - 2, device=x.device, dtype=torch.float32)
+    _check(lib().maua_conv3x3_x6(_ptr(_f32(x, "x")), bank.data_ptr(), _ptr(bias), _ptr(out_relu_mask), _ptr(out), n, cin, h,
+                                 w, cout, pad, int(relu), int(accumulate), _stream()), "maua_conv3x3_x6")
     return out
 
 
@@ -170,12 +195,12 @@ def pool2d_fwd(x, k, stride, ceil_mode, mode, out=None):
     return out
 
 
-def pool2d_bwd(gy, x, k, stride, ceil_mode, mode, out=None):
+def pool2d_bwd(gy, x, k, stride, ceil_mode, mode, out=None, relu_mask_by_x=False):
     n, c, h, w = x.shape
     if out is None:
         out = torch.empty_like(x)
     _check(lib().maua_pool2d_bwd(_ptr(_f32(gy, "gy")), _ptr(x), _ptr(out), n, c, h, w, k, stride, int(ceil_mode),
-                                 0 if mode == "max" else 1, _stream()), "maua_pool2d_bwd")
+                                 0 if mode == "max" else 1, int(relu_mask_by_x), _stream()), "maua_pool2d_bwd")
     return out
 
 
@@ -209,21 +234,22 @@ def gram_fwd(f, scale, center=False, out=None, mean_out=None, workspace=None):
     return out, (mean_out if center else None)
 
 
-def gram_bwd(d_sym, f, row_mean, gf, accumulate, workspace=None):
+def gram_bwd(d_sym, f, row_mean, gf, accumulate, workspace=None, relu_mask=None):
     c = d_sym.shape[0]
     hw = f.numel() // c
     workspace = _ws(workspace, 4 * c + 256, f.device)
-    _check(lib().maua_gram_bwd(_ptr(_f32(d_sym, "d")), _ptr(f), _ptr(row_mean), _ptr(gf), c, hw, int(accumulate),
+    _check(lib().maua_gram_bwd(_ptr(_f32(d_sym, "d")), _ptr(f), _ptr(row_mean), _ptr(relu_mask), _ptr(gf), c, hw, int(accumulate),
                                workspace.data_ptr(), workspace.numel() * workspace.element_size(), _stream()),
            "maua_gram_bwd")
     return gf
 
 
-def mse_fwd_bwd(x, target, grad, loss_scale, grad_scale, accumulate, loss_out, workspace=None):
+def mse_fwd_bwd(x, target, grad, loss_scale, grad_scale, accumulate, loss_out, workspace=None, mask_grad_by_x=False):
     n = x.numel()
     workspace = _ws(workspace, reduce_workspace_bytes(n), x.device)
     _check(lib().maua_mse_fwd_bwd(_ptr(_f32(x, "x")), _ptr(_f32(target, "target")), _ptr(grad), n, float(loss_scale),
-                                  float(grad_scale), int(accumulate), _ptr(loss_out), workspace.data_ptr(),
+                                  float(grad_scale), int(accumulate), int(mask_grad_by_x), _ptr(loss_out),
+                                  workspace.data_ptr(),
                                   workspace.numel() * workspace.element_size(), _stream()), "maua_mse_fwd_bwd")
     return loss_out
 

@@ -29,20 +29,30 @@ from loss import ContentLoss, GramMatrix, ScaleGradients, StyleLoss, TVLoss  # n
 # --------------------------------------------------------------------------------------------------
 
 
+def _x6_mode():
+    """MAUA_CONV_X6: "1" (default) = 3x3 stride-1 convs on the bf16 matrix cores with a 3-way operand split in both
+    passes, "fwd" / "bwd" = only that pass, "0" = fp32 matrix cores everywhere."""
+    import os
+    mode = os.environ.get("MAUA_CONV_X6", "1")
+    return mode in ("1", "fwd"), mode in ("1", "bwd")
+
+
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mod):
-        wf, _ = mod.banks()
         ctx.mod, ctx.in_shape = mod, x.shape
-        return hip.conv2d_fwd(x.contiguous(), wf, mod.bias_device(), mod.kernel_size[0], mod.stride[0], mod.padding[0],
-                              False)
+        k, stride, pad = mod.kernel_size[0], mod.stride[0], mod.padding[0]
+        if _x6_mode()[0] and k == 3 and stride == 1 and pad <= 2 and mod.out_channels > 32:
+            return hip.conv3x3_x6(x.contiguous(), mod.banks6()[0], mod.bias_device(), mod.out_channels, pad, False)
+        return hip.conv2d_fwd(x.contiguous(), mod.banks()[0], mod.bias_device(), k, stride, pad, False)
 
     @staticmethod
     def backward(ctx, gy):
         mod = ctx.mod
-        _, wb = mod.banks()
-        gx = hip.conv2d_bwd_data(gy.contiguous(), None, wb, mod.weight.detach(), ctx.in_shape, mod.kernel_size[0],
-                                 mod.stride[0], mod.padding[0])
+        k, stride, pad = mod.kernel_size[0], mod.stride[0], mod.padding[0]
+        if _x6_mode()[1] and k == 3 and stride == 1 and pad <= 2 and mod.in_channels > 32:
+            return hip.conv3x3_x6(gy.contiguous(), mod.banks6()[1], None, mod.in_channels, 2 - pad, False), None
+        gx = hip.conv2d_bwd_data(gy.contiguous(), None, mod.banks()[1], mod.weight.detach(), ctx.in_shape, k, stride, pad)
         return gx, None
 
 
@@ -59,6 +69,14 @@ class Conv2d(nn.Conv2d):
             self._banks = hip.conv_pack_filters(self.weight.detach().contiguous())
             self._bank_key = key
         return self._banks
+
+    def banks6(self):
+        """bf16x3 pre-split banks (forward, backward-data) of the fp32-accurate bf16 path, 3x3 filters only."""
+        key = (self.weight.data_ptr(), self.weight._version, self.weight.device)
+        if getattr(self, "_bank6_key", None) != key:
+            self._banks6 = hip.conv_pack_filters_x6(self.weight.detach().contiguous())
+            self._bank6_key = key
+        return self._banks6
 
     def bias_device(self):
         return None if self.bias is None else self.bias.detach()

@@ -296,3 +296,79 @@ def test_lbfgs_stop_flag_and_first_step(hip):
     st.iterate(x, dev(rnd(n, seed=23)), tolerance_change=1e30)
     torch.cuda.synchronize()
     assert st.status()["stopped"] and torch.equal(x, before)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# bf16x6 convolution (fp32 accuracy on the bf16 matrix cores) and producer-side ReLU masks
+# ---------------------------------------------------------------------------------------------------------
+X6_CASES = [(3, 64, 37, 45, 1), (64, 64, 32, 32, 1), (64, 128, 16, 24, 1), (128, 256, 8, 8, 1), (512, 512, 4, 4, 1),
+            (256, 512, 2, 2, 1), (20, 40, 13, 70, 1), (96, 70, 9, 33, 1), (8, 16, 9, 9, 0), (384, 1024, 7, 7, 1)]
+
+
+@pytest.mark.parametrize("cin,cout,H,W,pad", X6_CASES)
+def test_conv3x3_x6_forward_and_backward(hip, cin, cout, H, W, pad):
+    x = rnd(2, cin, H, W, seed=1)
+    w = rnd(cout, cin, 3, 3, seed=2, scale=math.sqrt(2.0 / (9 * cin)))
+    b = rnd(cout, seed=3, scale=0.1)
+    ref = torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=pad))
+    bank_f, bank_b = hip.conv_pack_filters_x6(dev(w))
+    y = hip.conv3x3_x6(dev(x), bank_f, dev(b), cout, pad, True)
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape
+    assert rel_l2(y.cpu(), ref) <= 2e-6  # fp32-level: the fp32 CPU conv itself is ~3e-7 from fp64
+    gy = rnd(*ref.shape, seed=4)
+    refb = torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), padding=pad)
+    mask = rnd(*x.shape, seed=6)  # "ReLU output" of the layer below: its sign decides what survives
+    gx = hip.conv3x3_x6(dev(gy), bank_b, None, cin, 2 - pad, False, out_relu_mask=dev(mask))
+    torch.cuda.synchronize()
+    assert rel_l2(gx.cpu(), refb * (mask > 0)) <= 2e-6
+    base = rnd(*x.shape, seed=5)
+    gx2 = hip.conv3x3_x6(dev(gy), bank_b, None, cin, 2 - pad, False, out=dev(base.clone()), accumulate=True)
+    torch.cuda.synchronize()
+    assert rel_l2(gx2.cpu(), refb + base.double()) <= 2e-6
+
+
+def test_conv3x3_x6_is_deterministic(hip):
+    x, w = dev(rnd(1, 64, 40, 40, seed=1)), dev(rnd(128, 64, 3, 3, seed=2, scale=0.05))
+    bank_f, _ = hip.conv_pack_filters_x6(w)
+    a = hip.conv3x3_x6(x, bank_f, None, 128, 1, False)
+    b = hip.conv3x3_x6(x, bank_f, None, 128, 1, False)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("cin,cout,H,W,k,stride,pad", [(64, 64, 20, 20, 3, 1, 1), (40, 24, 9, 31, 1, 1, 0), (3, 16, 31, 31, 11, 4, 0)])
+def test_conv_bwd_producer_side_relu_mask(hip, cin, cout, H, W, k, stride, pad):
+    x = rnd(1, cin, H, W, seed=1)
+    w = rnd(cout, cin, k, k, seed=2, scale=math.sqrt(2.0 / (k * k * cin)))
+    oh, ow = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    gy = rnd(1, cout, oh, ow, seed=4)
+    ref = torch.nn.grad.conv2d_input(x.shape, w, gy, stride=stride, padding=pad) * (x > 0)
+    _, wb = hip.conv_pack_filters(dev(w))
+    gx = hip.conv2d_bwd_data(dev(gy), None, wb, dev(w), x.shape, k, stride, pad, in_relu_mask=dev(x))
+    torch.cuda.synchronize()
+    assert rel_l2(gx.cpu(), ref) <= TOL
+
+
+def test_masks_on_pool_mse_gram_backward(hip):
+    x = torch.relu(rnd(1, 8, 12, 12, seed=7))
+    gy = rnd(1, 8, 6, 6, seed=8)
+    xr = x.clone().requires_grad_(True)
+    F.max_pool2d(xr, 2, 2).backward(gy)
+    gx = hip.pool2d_bwd(dev(gy), dev(x), 2, 2, False, "max", relu_mask_by_x=True)
+    assert rel_l2(gx.cpu(), xr.grad * (x > 0)) <= 1e-6
+    n = 5000
+    f, t, base = torch.relu(rnd(n, seed=1)), rnd(n, seed=2), rnd(n, seed=3)
+    g = dev(base.clone())
+    loss = torch.zeros(1, device="cuda")
+    hip.mse_fwd_bwd(dev(f), dev(t), g, 1.0 / n, 0.5, True, loss, mask_grad_by_x=True)
+    assert rel_l2(g.cpu(), (base + 0.5 * (f - t)) * (f > 0)) <= 1e-6
+    C, HW = 96, 500
+    fm = torch.relu(rnd(1, C, HW, 1, seed=4))
+    d = rnd(C, C, seed=5)
+    d = d + d.t()
+    base = rnd(C, HW, seed=6)
+    gf = hip.gram_bwd(dev(d), dev(fm), None, dev(base.clone()), True, relu_mask=dev(fm))
+    torch.cuda.synchronize()
+    ref = (d.double() @ fm.reshape(C, HW).double() + base.double()) * (fm.reshape(C, HW) > 0)
+    assert rel_l2(gf.cpu(), ref) <= TOL
