@@ -85,9 +85,12 @@ __global__ void pack_x6_kernel(const float* __restrict__ w, unsigned short* __re
 
 template <bool TL>
 __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[X6_PATCH_BYTES + X6_W_BYTES];
+    constexpr int ZERO_BYTES = (32 * 3 + 3) * 16;  // what a lane's A reads of one k-step span: (t*32*3 + part)*16 + 16
+    __shared__ __attribute__((aligned(16))) unsigned char smem[X6_PATCH_BYTES + X6_W_BYTES + ZERO_BYTES];
     unsigned char* Pl = smem;                    // [part][pos][16 B]
     unsigned char* Wl = smem + X6_PATCH_BYTES;   // [tap][co][part][16 B]
+    // zero block behind the filters: A operand of the upper lane half in the fifth k-step (the ninth tap has no partner)
+    for (int i = threadIdx.x * 4; i < ZERO_BYTES; i += 256 * 4) *reinterpret_cast<unsigned*>(Wl + X6_W_BYTES + i) = 0u;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -153,12 +156,12 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
         const int tap = min(2 * s + half, 8);
         const int ky = tap / 3, kx = tap - 3 * ky;
         b_byte[s] = ((wave + ky) * X6_PC + j + kx) * 16;
-        a_byte[s] = ((tap * X6_COT + j) * 3) * 16;
+        a_byte[s] = (2 * s + half > 8) ? X6_W_BYTES : ((tap * X6_COT + j) * 3) * 16;
     }
 
-    // two-level accumulation (TL): fold the running sums into a master accumulator every FLUSH chunks so that no fp32
-    // accumulation chain is longer than FLUSH*5*6 MFMA additions (same idea as conv_mfma2.hip)
-    constexpr int FLUSH = 1;
+    // two-level accumulation (TL): fold the running sums into a master accumulator (plain fp32 VALU adds, round to
+    // nearest) every FLUSH chunks so that no MFMA accumulation chain is longer than FLUSH*5*6 additions
+    constexpr int FLUSH = 1;  // measured: 1 halves the pixel-gradient error of 4 (the bf16 MFMA adder truncates toward zero)
     f32x16 acc[2], master[TL ? 2 : 1];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -187,12 +190,7 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int part = 0; part < 3; ++part) {
-                    bf16x8 v = *reinterpret_cast<const bf16x8*>(Wl + a_byte[s] + (t * 32 * 3 + part) * 16);
-                    if (s == 4 && half == 1) {  // ninth tap has no partner: zero A on the upper half
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) v[q] = (__bf16)0.f;
-                    }
-                    a[t][part] = v;
+                    a[t][part] = *reinterpret_cast<const bf16x8*>(Wl + a_byte[s] + (t * 32 * 3 + part) * 16);
                 }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {

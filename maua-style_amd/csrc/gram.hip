@@ -176,6 +176,107 @@ __global__ void center_bias_kernel(const float* __restrict__ d, const float* __r
     bias[c] = -s;
 }
 
+// Gram backward gf[c][p] (+)= sum_k D[k][c] * (F[k][p] - mean[k]), masked by relu_mask.  Bandwidth-bound for the
+// shallow layers (C = 64: three passes over a 268 MB map at 1024x1024), so the kernel is built around wide, few
+// accesses: 32 input channels per LDS stage (64 MFMAs per barrier and wave), F staged with 16-byte loads in its native
+// [channel][pixel] order (the B operand then reads consecutive pixels with ds_read_b32, conflict-free), D rows likewise.
+// Workgroup = 64 output channels x 256 pixels, wave = 64 x 64 (2 x 2 accumulators), double-buffered LDS (80 KB).
+constexpr int GB_KC = 32, GB_PX = 256, GB_CO = 64;
+
+__global__ void __launch_bounds__(256)
+gram_bwd_kernel(const float* __restrict__ d, const float* __restrict__ f, const float* __restrict__ mean,
+                const float* __restrict__ rmask, float* __restrict__ gf, int C, int64_t HW, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 x (Xl[32][256] + Wl[32][64])
+    constexpr int BUF = GB_KC * GB_PX + GB_KC * GB_CO;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    const int64_t p0 = (int64_t)blockIdx.x * GB_PX;
+    const int co0 = blockIdx.y * GB_CO;
+
+    f32x4 rx[8], rw[2];
+    auto load_stage = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + 256 * i;           // quad index: 32 rows x 64 quads
+            const int r = e >> 6, q = e & 63;
+            const int64_t pp = p0 + 4 * q;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k0 + r < C && pp < HW) {
+                v = *reinterpret_cast<const f32x4*>(f + (int64_t)(k0 + r) * HW + pp);
+                if (mean) v -= mean[k0 + r];
+            }
+            rx[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + 256 * i;           // 32 rows x 16 quads
+            const int r = e >> 4, q = e & 15;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k0 + r < C && co0 + 4 * q < C) v = *reinterpret_cast<const f32x4*>(d + (int64_t)(k0 + r) * C + co0 + 4 * q);
+            rw[i] = v;
+        }
+    };
+    auto store_stage = [&](int buf) {
+        float* xl = smem + buf * BUF;
+        float* wl = xl + GB_KC * GB_PX;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(xl + (tid + 256 * i) * 4) = rx[i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(wl + (tid + 256 * i) * 4) = rw[i];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    const int nst = (C + GB_KC - 1) / GB_KC;
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < nst) load_stage((st + 1) * GB_KC);
+        const float* xl = smem + cur * BUF;
+        const float* wl = xl + GB_KC * GB_PX;
+#pragma unroll
+        for (int kp = 0; kp < GB_KC / 2; ++kp) {
+            const int kk = 2 * kp + half;
+            float a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) a[t] = wl[kk * GB_CO + t * 32 + j];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) b[u] = xl[kk * GB_PX + (wave * 2 + u) * 32 + j];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[u], acc[t][u], 0, 0, 0);
+        }
+        if (st + 1 < nst) store_stage(cur ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int64_t pix = p0 + (wave * 2 + u) * 32 + j;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (pix < HW && co < C) {
+                    const int64_t o = (int64_t)co * HW + pix;
+                    float v = acc[t][u][r];
+                    if (accumulate) v += gf[o];
+                    if (rmask) v = rmask[o] > 0.f ? v : 0.f;
+                    gf[o] = v;
+                }
+            }
+    }
+}
+
 static void gram_plan(int c, int64_t hw, int* npairs, int* ksplit, int64_t* chunk) {
     const int ntile = (c + GT - 1) / GT;
     *npairs = ntile * (ntile + 1) / 2;
@@ -234,6 +335,20 @@ int maua_gram_bwd(const float* d_sym, const float* f, const float* row_mean, con
                   int64_t hw, int accumulate, void* workspace, size_t workspace_bytes, maua_stream_t stream) {
     MAUA_REQUIRE(d_sym && f && gf && c > 0 && hw > 0, MAUA_E_INVAL, "gram_bwd: bad args");
     MAUA_REQUIRE(hw < (1ll << 31), MAUA_E_UNSUPPORTED, "gram_bwd: plane too large");
+    if (hw % 4 == 0 && c % 4 == 0 && (uintptr_t)f % 16 == 0 && (uintptr_t)d_sym % 16 == 0) {
+        constexpr size_t lds = 2ull * (GB_KC * GB_PX + GB_KC * GB_CO) * sizeof(float);
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gram_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds);
+            attr_done = true;
+        }
+        dim3 grid((unsigned)((hw + GB_PX - 1) / GB_PX), (unsigned)((c + GB_CO - 1) / GB_CO));
+        hipLaunchKernelGGL(gram_bwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, d_sym, f, row_mean, relu_mask, gf, c, hw,
+                           accumulate);
+        return check_launch("gram_bwd_kernel");
+    }
+    // general shapes: the 1x1 path of the convolution kernel, centring as a per-row bias
     float* bias = nullptr;
     if (row_mean) {
         MAUA_REQUIRE(workspace && workspace_bytes >= (size_t)c * sizeof(float), MAUA_E_WORKSPACE,

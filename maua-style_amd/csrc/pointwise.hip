@@ -137,6 +137,41 @@ __global__ void pool_bwd_kernel(const float* __restrict__ gy, const float* __res
     }
 }
 
+// 2x2 stride-2 max pooling on even-sized planes (every VGG pool): one thread per window, 8-byte accesses, no divisions.
+// grid = (ceil(OW/256), OH, planes).  Same tie rule as window_argmax: scan order (0,0),(0,1),(1,0),(1,1), first max wins.
+__global__ void __launch_bounds__(256)
+pool2x2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int W, int OW) {
+    const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y;
+    if (ox >= OW) return;
+    const int64_t OHl = gridDim.y;
+    const float* p = x + ((int64_t)blockIdx.z * 2 * OHl + 2 * oy) * W + 2 * ox;
+    const float2 r0 = *reinterpret_cast<const float2*>(p), r1 = *reinterpret_cast<const float2*>(p + W);
+    float m = r0.x;
+    if (r0.y > m || r0.y != r0.y) m = r0.y;
+    if (r1.x > m || r1.x != r1.x) m = r1.x;
+    if (r1.y > m || r1.y != r1.y) m = r1.y;
+    y[((int64_t)blockIdx.z * OHl + oy) * OW + ox] = m;
+}
+
+__global__ void __launch_bounds__(256)
+pool2x2_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x, float* __restrict__ gx, int W, int OW,
+                   int relu_mask) {
+    const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y;
+    if (ox >= OW) return;
+    const int64_t OHl = gridDim.y;
+    const int64_t base = ((int64_t)blockIdx.z * 2 * OHl + 2 * oy) * W + 2 * ox;
+    const float2 r0 = *reinterpret_cast<const float2*>(x + base), r1 = *reinterpret_cast<const float2*>(x + base + W);
+    float m = r0.x;
+    int arg = 0;
+    if (r0.y > m || r0.y != r0.y) { m = r0.y; arg = 1; }
+    if (r1.x > m || r1.x != r1.x) { m = r1.x; arg = 2; }
+    if (r1.y > m || r1.y != r1.y) { m = r1.y; arg = 3; }
+    float g = gy[((int64_t)blockIdx.z * OHl + oy) * OW + ox];
+    if (relu_mask && !(m > 0.f)) g = 0.f;  // the winner is a ReLU output: its threshold_backward
+    *reinterpret_cast<float2*>(gx + base) = make_float2(arg == 0 ? g : 0.f, arg == 1 ? g : 0.f);
+    *reinterpret_cast<float2*>(gx + base + W) = make_float2(arg == 2 ? g : 0.f, arg == 3 ? g : 0.f);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // MSE: partial[b] = sum over the block's elements of (x-t)^2 (double); grad (+)= gs * (x - t).
 __global__ void __launch_bounds__(256)
@@ -256,6 +291,10 @@ int maua_pool2d_fwd(const float* x, float* y, int n, int c, int h, int w, int k,
                  MAUA_E_INVAL, "pool2d_fwd: bad args");
     const int oh = maua_pool_out_size(h, k, stride, ceil_mode), ow = maua_pool_out_size(w, k, stride, ceil_mode);
     MAUA_REQUIRE(oh > 0 && ow > 0, MAUA_E_UNSUPPORTED, "pool2d_fwd: input %dx%d smaller than window %d", h, w, k);
+    if (mode == 0 && k == 2 && stride == 2 && h % 2 == 0 && w % 2 == 0 && (int64_t)n * c <= 65535 && oh <= 65535) {
+        hipLaunchKernelGGL(pool2x2_fwd_kernel, dim3((ow + 255) / 256, oh, n * c), dim3(256), 0, (hipStream_t)stream, x, y, w, ow);
+        return check_launch("pool2x2_fwd_kernel");
+    }
     const int64_t total = (int64_t)n * c * oh * ow;
     hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, (int64_t)n * c, h, w,
                        oh, ow, k, stride, mode);
@@ -268,6 +307,11 @@ int maua_pool2d_bwd(const float* gy, const float* x, float* gx, int n, int c, in
                  MAUA_E_INVAL, "pool2d_bwd: bad args");
     const int oh = maua_pool_out_size(h, k, stride, ceil_mode), ow = maua_pool_out_size(w, k, stride, ceil_mode);
     MAUA_REQUIRE(oh > 0 && ow > 0, MAUA_E_UNSUPPORTED, "pool2d_bwd: input %dx%d smaller than window %d", h, w, k);
+    if (mode == 0 && k == 2 && stride == 2 && h % 2 == 0 && w % 2 == 0 && (int64_t)n * c <= 65535 && oh <= 65535) {
+        hipLaunchKernelGGL(pool2x2_bwd_kernel, dim3((ow + 255) / 256, oh, n * c), dim3(256), 0, (hipStream_t)stream, gy, x, gx, w,
+                           ow, relu_mask_by_x);
+        return check_launch("pool2x2_bwd_kernel");
+    }
     const int64_t total = (int64_t)n * c * h * w;
     hipLaunchKernelGGL(pool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, gy, x, gx, (int64_t)n * c,
                        h, w, oh, ow, k, stride, mode, relu_mask_by_x);
