@@ -112,21 +112,26 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
         if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) p_off = iy * p.W + ix;
     }
     float rp[8];
+    unsigned rp_ok = 0;  // bit c: channel c of the staged chunk is inside the tensor (and the position inside the image)
     auto load_patch = [&](int c0) {
         asm volatile("" : "+s"(c0));
+        // Unconditional loads from clamped addresses; NOTHING touches the loaded registers here, so the compiler's wait
+        // for them sits in store_patch (after the chunk's MFMAs), not right behind the loads.
+        rp_ok = 0;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const bool ok = p_off >= 0 && c0 + c < p.Cin;
-            const int64_t a = ok ? (int64_t)(c0 + c) * in_plane + p_off : 0;
-            const float v = xin[a];
-            rp[c] = ok ? v : 0.f;
+            unsigned long long a = ok ? (unsigned long long)((int64_t)(c0 + c) * in_plane + p_off) : 0ull;
+            asm volatile("" : "+v"(a));  // opaque address: the load may not be predicated on `ok`
+            rp[c] = xin[a];
+            rp_ok |= ok ? (1u << c) : 0u;
         }
     };
     auto store_patch = [&]() {
         if (tid < X6_NPOS_PAD) {
             unsigned short h[8], m[8], l[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) split3(rp[c], h[c], m[c], l[c]);
+            for (int c = 0; c < 8; ++c) split3((rp_ok >> c) & 1u ? rp[c] : 0.f, h[c], m[c], l[c]);
             u32x4 vh, vm, vl;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -140,12 +145,24 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
         }
     };
     const unsigned char* __restrict__ bank = reinterpret_cast<const unsigned char*>(p.w6);
-    auto dma_filters = [&](int ch) {
+    // Filter slice of a chunk = 27 pieces of 1 KiB in LDS order.  Half A = taps 0-3 (pieces 0-11, read by k-steps 0-1),
+    // half B = taps 4-8 (pieces 12-26, read by k-steps 2-4).  Every wave issues exactly 3 (A) or 4 (B) LDS-DMA
+    // instructions so that the counted vmcnt waits below are the same for all waves (wave 3 repeats piece 26).
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    auto dma_half = [&](int ch, bool second) {
         const unsigned char* src = bank + ((int64_t)ch * ntile + cotile) * X6_W_BYTES;
-        for (int q = __builtin_amdgcn_readfirstlane(wave); q < X6_PIECES; q += 4) {  // uniform piece index: 1 KiB each
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(src + q * 1024 + lane * 16),
-                (__attribute__((address_space(3))) void*)(Wl + q * 1024), 16, 0, 0);
+        const int first = second ? 12 : 0, count = second ? 4 : 3, last = second ? 26 : 11;
+        for (int i = 0; i < count; ++i) {
+            const int q = min(first + wv + 4 * i, last);
+            // LDS-DMA issued from inline asm so that hipcc does not drain it with vmcnt(0) at the next ds_read
+            // (cdna_hip_programming.md §5.7; M0 = wave-uniform LDS byte address, lane i lands at M0 + 16*i)
+            const unsigned char* g = src + q * 1024 + lane * 16;
+            const unsigned lds_dst = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(Wl + q * 1024);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_dst))
+                         : "memory");
         }
     };
 
@@ -171,38 +188,54 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
             if constexpr (TL) master[t][r] = 0.f;
         }
 
+    auto kstep = [&](int s) {
+        bf16x8 b[3], a[2][3];
+#pragma unroll
+        for (int part = 0; part < 3; ++part)
+            b[part] = *reinterpret_cast<const bf16x8*>(Pl + part * X6_NPOS_PAD * 16 + b_byte[s]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int part = 0; part < 3; ++part)
+                a[t][part] = *reinterpret_cast<const bf16x8*>(Wl + a_byte[s] + (t * 32 * 3 + part) * 16);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            // smallest terms first
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][2], b[0], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][1], b[1], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[2], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][1], b[0], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[1], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[0], acc[t], 0, 0, 0);
+        }
+    };
+
+    // Pipeline (raw s_barrier + counted vmcnt, cdna_hip_programming.md "Pipelining across barriers"): the filter halves of
+    // chunk c+1 stream in behind the k-steps of chunk c that no longer need the LDS region they overwrite.
+    //   chunk c:  [patch(c+1) global loads -> regs]  ks0 ks1 | X1 | DMA A(c+1) | ks2 ks3 ks4 | X2 | patch(c+1) -> LDS,
+    //             DMA B(c+1), wait A(c+1) | X3 | ... next chunk; B(c+1) is waited for just before the next X1.
+    // vmcnt is in issue order: before X1 the queue is [B(c) x4 (old), patch loads x8 (young)] -> vmcnt(8) retires B(c);
+    // before X3 it is [A(c+1) x3, B(c+1) x4] -> vmcnt(4) retires A(c+1) (the patch loads were consumed before).
     const int nchunks = (p.Cin + 7) / 8;
     load_patch(0);
     store_patch();
-    dma_filters(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA completion
-    __syncthreads();
+    dma_half(0, false);
+    dma_half(0, true);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     for (int ch = 0; ch < nchunks; ++ch) {
         const bool more = ch + 1 < nchunks;
         if (more) load_patch((ch + 1) * 8);
-#pragma unroll
-        for (int s = 0; s < 5; ++s) {
-            bf16x8 b[3], a[2][3];
-#pragma unroll
-            for (int part = 0; part < 3; ++part)
-                b[part] = *reinterpret_cast<const bf16x8*>(Pl + part * X6_NPOS_PAD * 16 + b_byte[s]);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int part = 0; part < 3; ++part) {
-                    a[t][part] = *reinterpret_cast<const bf16x8*>(Wl + a_byte[s] + (t * 32 * 3 + part) * 16);
-                }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                // smallest terms first
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][2], b[0], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][1], b[1], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[2], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][1], b[0], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[1], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[0], acc[t], 0, 0, 0);
-            }
-        }
+        kstep(0);
+        kstep(1);
+        // B(ch) must have landed (all waves) before k-step 2; A(ch)'s readers are done after this barrier
+        if (more) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (more) dma_half(ch + 1, false);
+        kstep(2);
+        kstep(3);
+        kstep(4);
         if constexpr (TL) {
             if ((ch & (FLUSH - 1)) == FLUSH - 1 || !more) {
 #pragma unroll
@@ -214,13 +247,14 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
                     }
             }
         }
-        __syncthreads();  // every wave is done reading this chunk
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // X2: every wave is done reading the patch and half B
         if (more) {
             store_patch();
-            dma_filters(ch + 1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            dma_half(ch + 1, true);
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");  // A(ch+1) landed, patch writes done
+            __builtin_amdgcn_s_barrier();  // X3
         }
-        __syncthreads();
     }
 
     // epilogue: lane holds pixel column j of row y0+wave; register r is output channel (r&3)+8*(r>>2)+4*half of block t
