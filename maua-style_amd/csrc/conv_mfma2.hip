@@ -22,7 +22,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int slot_swz(int p) { return ((p >> 2) ^ (p >> 3)) & 1; }
 
-template <int KS, int TCO, int TPX, bool TL, bool MASK>
+template <int KS, int TCO, int TPX, bool TL, bool MASK, bool ACC, bool OM>
 __global__ void __launch_bounds__(256, 2) conv_mfma2_kernel(ConvArgs p) {
     constexpr int KC = 8;
     constexpr int CO_T = 32 * TCO;
@@ -257,25 +257,33 @@ __global__ void __launch_bounds__(256, 2) conv_mfma2_kernel(ConvArgs p) {
         }
 #pragma unroll
         for (int t = 0; t < TCO; ++t) {
+            float prev[16], msk[16];  // loads first, stores second (see conv_x6.hip)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int64_t o = (pvalid && co < p.Cout) ? (int64_t)co * out_plane + opix : 0;
+                prev[r] = 0.f;
+                msk[r] = 1.f;
+                if constexpr (ACC) prev[r] = yout[o];
+                if constexpr (OM) msk[r] = om[o];
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (pvalid && co < p.Cout) {
                     float v = TL ? master[t][u][r] : acc[t][u][r];
                     if (p.bias) v += p.bias[co];
-                    const int64_t o = (int64_t)co * out_plane + opix;
-                    if (p.accumulate) v += yout[o];
+                    v += prev[r];
                     if (p.relu) v = v > 0.f ? v : 0.f;
-                    if (om) v = om[o] > 0.f ? v : 0.f;
-                    yout[o] = v;
+                    yout[(int64_t)co * out_plane + opix] = msk[r] > 0.f ? v : 0.f;
                 }
             }
         }
     }
 }
 
-template <int KS, int TCO, int TPX, bool TL, bool MASK>
-static int launch2(const ConvArgs& a, int n, hipStream_t stream) {
+template <int KS, int TCO, int TPX, bool TL, bool MASK, bool ACC, bool OM>
+static int launch2e(const ConvArgs& a, int n, hipStream_t stream) {
     constexpr int CO_T = 32 * TCO, PH = 4 * TPX;
     constexpr int PR = PH + KS - 1, PC = 32 + KS - 1;
     constexpr int NPOS_PAD = (PR * PC + 7) / 8 * 8;
@@ -292,12 +300,21 @@ static int launch2(const ConvArgs& a, int n, hipStream_t stream) {
     dim3 grid((unsigned)tiles, (unsigned)((a.Cout + CO_T - 1) / CO_T), (unsigned)n);
     static bool attr_done = false;
     if (!attr_done && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma2_kernel<KS, TCO, TPX, TL, MASK>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma2_kernel<KS, TCO, TPX, TL, MASK, ACC, OM>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_mfma2_kernel<KS, TCO, TPX, TL, MASK>), grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv_mfma2_kernel<KS, TCO, TPX, TL, MASK, ACC, OM>), grid, dim3(256), lds, stream, p);
     return check_launch("conv_mfma2_kernel");
+}
+
+template <int KS, int TCO, int TPX, bool TL, bool MASK>
+static int launch2(const ConvArgs& a, int n, hipStream_t stream) {
+    const bool acc = a.accumulate != 0, om = a.omask != nullptr;
+    if (acc && om) return launch2e<KS, TCO, TPX, TL, MASK, true, true>(a, n, stream);
+    if (acc) return launch2e<KS, TCO, TPX, TL, MASK, true, false>(a, n, stream);
+    if (om) return launch2e<KS, TCO, TPX, TL, MASK, false, true>(a, n, stream);
+    return launch2e<KS, TCO, TPX, TL, MASK, false, false>(a, n, stream);
 }
 
 template <int KS, int TCO, int TPX>

@@ -83,7 +83,7 @@ __global__ void pack_x6_kernel(const float* __restrict__ w, unsigned short* __re
     }
 }
 
-template <bool TL>
+template <bool TL, bool ACC, bool OM>
 __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
     constexpr int ZERO_BYTES = (32 * 3 + 3) * 16;  // what a lane's A reads of one k-step span: (t*32*3 + part)*16 + 16
     __shared__ __attribute__((aligned(16))) unsigned char smem[X6_PATCH_BYTES + X6_W_BYTES + ZERO_BYTES];
@@ -265,17 +265,28 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
     const int64_t opix = (int64_t)oy * p.OW + ox;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
+        // all loads of a 16-register block first (previous value, ReLU mask), then the stores: a load issued after a
+        // store to the same array would wait for it, turning the epilogue into 32 serial memory round trips
+        float prev[16], msk[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int64_t o = (pvalid && co < p.Cout) ? (int64_t)co * out_plane + opix : 0;
+            // compile-time switches: with run-time flags hipcc branches around every load and waits for each one
+            prev[r] = 0.f;
+            msk[r] = 1.f;
+            if constexpr (ACC) prev[r] = yout[o];
+            if constexpr (OM) msk[r] = om[o];
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (pvalid && co < p.Cout) {
                 float v = TL ? master[t][r] : acc[t][r];
                 if (p.bias) v += p.bias[co];
-                const int64_t o = (int64_t)co * out_plane + opix;
-                if (p.accumulate) v += yout[o];
+                v += prev[r];
                 if (p.relu) v = v > 0.f ? v : 0.f;
-                if (om) v = om[o] > 0.f ? v : 0.f;
-                yout[o] = v;
+                yout[(int64_t)co * out_plane + opix] = msk[r] > 0.f ? v : 0.f;
             }
         }
     }
@@ -286,8 +297,20 @@ int conv_x6_launch(const ConvArgs& a, int n, hipStream_t stream) {
     p.tiles_x = (a.OW + 31) / 32;
     const int64_t tiles = (int64_t)p.tiles_x * ((a.OH + X6_PH - 1) / X6_PH);
     dim3 grid((unsigned)tiles, (unsigned)((a.Cout + X6_COT - 1) / X6_COT), (unsigned)n);
-    if ((a.Cin + 7) / 8 > 4) hipLaunchKernelGGL(conv_x6_kernel<true>, grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(conv_x6_kernel<false>, grid, dim3(256), 0, stream, p);
+    const bool tl = (a.Cin + 7) / 8 > 4, acc = a.accumulate != 0, om = a.omask != nullptr;
+#define MAUA_X6_LAUNCH(TL_, ACC_, OM_) hipLaunchKernelGGL((conv_x6_kernel<TL_, ACC_, OM_>), grid, dim3(256), 0, stream, p)
+    if (tl) {
+        if (acc && om) MAUA_X6_LAUNCH(true, true, true);
+        else if (acc) MAUA_X6_LAUNCH(true, true, false);
+        else if (om) MAUA_X6_LAUNCH(true, false, true);
+        else MAUA_X6_LAUNCH(true, false, false);
+    } else {
+        if (acc && om) MAUA_X6_LAUNCH(false, true, true);
+        else if (acc) MAUA_X6_LAUNCH(false, true, false);
+        else if (om) MAUA_X6_LAUNCH(false, false, true);
+        else MAUA_X6_LAUNCH(false, false, false);
+    }
+#undef MAUA_X6_LAUNCH
     return check_launch("conv_x6_kernel");
 }
 

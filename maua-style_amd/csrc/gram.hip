@@ -183,6 +183,7 @@ __global__ void center_bias_kernel(const float* __restrict__ d, const float* __r
 // Workgroup = 64 output channels x 256 pixels, wave = 64 x 64 (2 x 2 accumulators), double-buffered LDS (80 KB).
 constexpr int GB_KC = 32, GB_PX = 256, GB_CO = 64;
 
+template <bool ACC, bool MASK>
 __global__ void __launch_bounds__(256)
 gram_bwd_kernel(const float* __restrict__ d, const float* __restrict__ f, const float* __restrict__ mean,
                 const float* __restrict__ rmask, float* __restrict__ gf, int C, int64_t HW, int accumulate) {
@@ -262,18 +263,30 @@ gram_bwd_kernel(const float* __restrict__ d, const float* __restrict__ f, const 
     for (int u = 0; u < 2; ++u) {
         const int64_t pix = p0 + (wave * 2 + u) * 32 + j;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) {
+            // read-modify-write in two sweeps: all loads of the 16 registers first, then all stores - otherwise every
+            // load waits behind the previous store (same array) and the epilogue becomes 64 serial round trips
+            float prev[16], msk[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const bool ok = pix < HW && co < C;
+                const int64_t o = ok ? (int64_t)co * HW + pix : 0;
+                // compile-time switches: with run-time flags hipcc branches around every load and waits for each one
+                prev[r] = 0.f;
+                msk[r] = 1.f;
+                if constexpr (ACC) prev[r] = gf[o];
+                if constexpr (MASK) msk[r] = rmask[o];
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (pix < HW && co < C) {
-                    const int64_t o = (int64_t)co * HW + pix;
-                    float v = acc[t][u][r];
-                    if (accumulate) v += gf[o];
-                    if (rmask) v = rmask[o] > 0.f ? v : 0.f;
-                    gf[o] = v;
+                    const float v = acc[t][u][r] + prev[r];
+                    gf[(int64_t)co * HW + pix] = msk[r] > 0.f ? v : 0.f;
                 }
             }
+        }
     }
 }
 
@@ -337,15 +350,16 @@ int maua_gram_bwd(const float* d_sym, const float* f, const float* row_mean, con
     MAUA_REQUIRE(hw < (1ll << 31), MAUA_E_UNSUPPORTED, "gram_bwd: plane too large");
     if (hw % 4 == 0 && c % 4 == 0 && (uintptr_t)f % 16 == 0 && (uintptr_t)d_sym % 16 == 0) {
         constexpr size_t lds = 2ull * (GB_KC * GB_PX + GB_KC * GB_CO) * sizeof(float);
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gram_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds);
-            attr_done = true;
-        }
         dim3 grid((unsigned)((hw + GB_PX - 1) / GB_PX), (unsigned)((c + GB_CO - 1) / GB_CO));
-        hipLaunchKernelGGL(gram_bwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, d_sym, f, row_mean, relu_mask, gf, c, hw,
-                           accumulate);
+        auto launch = [&](auto kernel) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kernel, grid, dim3(256), lds, (hipStream_t)stream, d_sym, f, row_mean, relu_mask, gf, c, hw,
+                               accumulate);
+        };
+        if (accumulate && relu_mask) launch(gram_bwd_kernel<true, true>);
+        else if (accumulate) launch(gram_bwd_kernel<true, false>);
+        else if (relu_mask) launch(gram_bwd_kernel<false, true>);
+        else launch(gram_bwd_kernel<false, false>);
         return check_launch("gram_bwd_kernel");
     }
     // general shapes: the 1x1 path of the convolution kernel, centring as a per-row bias
