@@ -78,9 +78,13 @@ size_t maua_conv_x6_bank_bytes(int cout_produced, int cin_consumed);
 int maua_conv_pack_filters_x6(const float* w_oihw, void* bank_fwd, void* bank_bwd, int cout, int cin, maua_stream_t stream);
 /* y[n][cout][h+2p-2][w+2p-2] = act(bias + conv3x3(x, bank)) (+ y if accumulate), then zeroed where out_relu_mask <= 0
  * (nullable; the ReLU mask a backward-data pass applies on behalf of its consumer).  Forward: bank_fwd, pad p.
- * Backward-data of a pad-p conv: x = gradient w.r.t. the conv output, bank_bwd, cin/cout exchanged, pad 2-p. */
+ * Backward-data of a pad-p conv: x = gradient w.r.t. the conv output, bank_bwd, cin/cout exchanged, pad 2-p.
+ * workspace (nullable): maua_conv_x6_workspace_bytes(...) bytes let small output grids split the channel loop over
+ * several workgroups (partial sums added in a fixed order by a second kernel: still deterministic). */
+size_t maua_conv_x6_workspace_bytes(int n, int cin, int h, int w, int cout, int pad);
 int maua_conv3x3_x6(const float* x, const void* bank, const float* bias, const float* out_relu_mask, float* y, int n,
-                    int cin, int h, int w, int cout, int pad, int relu, int accumulate, maua_stream_t stream);
+                    int cin, int h, int w, int cout, int pad, int relu, int accumulate, void* workspace,
+                    size_t workspace_bytes, maua_stream_t stream);
 
 /* ---- ReLU on its own (module path; the engine fuses it into the convs): models.py:130 ------------- */
 int maua_relu_fwd(float* x_inplace, int64_t count, maua_stream_t stream);

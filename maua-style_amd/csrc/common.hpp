@@ -71,6 +71,8 @@ struct ConvArgs {
     int relu, accumulate;
     const void* w6;      // bf16x3 filter bank of conv_x6.hip (maua_conv_pack_filters_x6), else null
     const float* omask;  // nullable, output-shaped: result is zeroed where omask <= 0 (ReLU mask applied by the producer)
+    int ksplit;          // conv_x6 split-K: > 1 -> blockIdx.z = n*ksplit + split, raw partial sums go to `ws`
+    float* ws;           // [n][ksplit][Cout][OH][OW] partial sums (split-K only)
 };
 int conv_mfma_dispatch(const ConvArgs& a, int ks, int n, hipStream_t stream);
 int conv_mfma2_dispatch(const ConvArgs& a, int ks, int n, hipStream_t stream);

@@ -95,7 +95,8 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, half = lane >> 5;
-    const int n = blockIdx.z;
+    const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
+    const int n = blockIdx.z / ksplit, split = blockIdx.z - n * ksplit;
     const int cotile = blockIdx.y;
     const int co0 = cotile * X6_COT;
     const int ntile = gridDim.y;
@@ -216,14 +217,17 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
     //             DMA B(c+1), wait A(c+1) | X3 | ... next chunk; B(c+1) is waited for just before the next X1.
     // vmcnt is in issue order: before X1 the queue is [B(c) x4 (old), patch loads x8 (young)] -> vmcnt(8) retires B(c);
     // before X3 it is [A(c+1) x3, B(c+1) x4] -> vmcnt(4) retires A(c+1) (the patch loads were consumed before).
-    const int nchunks = (p.Cin + 7) / 8;
-    load_patch(0);
+    const int nchunks_all = (p.Cin + 7) / 8;
+    const int cps = (nchunks_all + ksplit - 1) / ksplit;        // chunks per split
+    const int ch_begin = split * cps;
+    const int nchunks = min(nchunks_all, ch_begin + cps);      // this workgroup covers chunks [ch_begin, nchunks)
+    load_patch(ch_begin * 8);
     store_patch();
-    dma_half(0, false);
-    dma_half(0, true);
+    dma_half(ch_begin, false);
+    dma_half(ch_begin, true);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    for (int ch = 0; ch < nchunks; ++ch) {
+    for (int ch = ch_begin; ch < nchunks; ++ch) {
         const bool more = ch + 1 < nchunks;
         if (more) load_patch((ch + 1) * 8);
         kstep(0);
@@ -237,7 +241,7 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
         kstep(3);
         kstep(4);
         if constexpr (TL) {
-            if ((ch & (FLUSH - 1)) == FLUSH - 1 || !more) {
+            if (((ch - ch_begin) & (FLUSH - 1)) == FLUSH - 1 || !more) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -263,6 +267,17 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
     const int oy = y0 + wave, ox = x0 + j;
     const bool pvalid = oy < p.OH && ox < p.OW;
     const int64_t opix = (int64_t)oy * p.OW + ox;
+    if (p.ksplit > 1) {  // split-K: raw partial sums, finished by x6_splitk_finish_kernel in split order
+        float* wsp = p.ws + (int64_t)blockIdx.z * p.Cout * out_plane;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (pvalid && co < p.Cout) wsp[(int64_t)co * out_plane + opix] = TL ? master[t][r] : acc[t][r];
+            }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         // all loads of a 16-register block first (previous value, ReLU mask), then the stores: a load issued after a
@@ -292,12 +307,41 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
     }
 }
 
+// out = act(bias + sum_split ws[split]) (+ out) masked: the fixed-order second stage of the split-K convolution
+__global__ void x6_splitk_finish_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
+                                        const float* __restrict__ omask, float* __restrict__ y, int ksplit, int Cout,
+                                        int64_t out_plane, int64_t total, int relu, int accumulate) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t per_n = (int64_t)Cout * out_plane;
+        const int64_t n = e / per_n, r = e - n * per_n;
+        float v = 0.f;
+        for (int k = 0; k < ksplit; ++k) v += ws[(n * ksplit + k) * per_n + r];
+        if (bias) v += bias[r / out_plane];
+        if (accumulate) v += y[e];
+        if (relu) v = v > 0.f ? v : 0.f;
+        if (omask) v = omask[e] > 0.f ? v : 0.f;
+        y[e] = v;
+    }
+}
+
+// split the K loop over several workgroups when the output grid alone cannot fill the chip (4 workgroups per CU)
+static int x6_choose_split(const ConvArgs& a, int n) {
+    const int64_t wgs = (int64_t)((a.OW + 31) / 32) * ((a.OH + X6_PH - 1) / X6_PH) * ((a.Cout + X6_COT - 1) / X6_COT) * n;
+    const int nchunks = (a.Cin + 7) / 8;
+    if (wgs >= 512 || nchunks < 8) return 1;
+    int ks = (int)((1024 + wgs - 1) / wgs);
+    if (ks > nchunks / 4) ks = nchunks / 4;  // keep at least 4 chunks per workgroup
+    return ks < 2 ? 1 : ks;
+}
+
 int conv_x6_launch(const ConvArgs& a, int n, hipStream_t stream) {
     ConvArgs p = a;
     p.tiles_x = (a.OW + 31) / 32;
     const int64_t tiles = (int64_t)p.tiles_x * ((a.OH + X6_PH - 1) / X6_PH);
-    dim3 grid((unsigned)tiles, (unsigned)((a.Cout + X6_COT - 1) / X6_COT), (unsigned)n);
-    const bool tl = (a.Cin + 7) / 8 > 4, acc = a.accumulate != 0, om = a.omask != nullptr;
+    int ks = a.ws ? x6_choose_split(a, n) : 1;
+    p.ksplit = ks;
+    dim3 grid((unsigned)tiles, (unsigned)((a.Cout + X6_COT - 1) / X6_COT), (unsigned)(n * ks));
+    const bool tl = (a.Cin + 7) / 8 > 4, acc = ks == 1 && a.accumulate != 0, om = ks == 1 && a.omask != nullptr;
 #define MAUA_X6_LAUNCH(TL_, ACC_, OM_) hipLaunchKernelGGL((conv_x6_kernel<TL_, ACC_, OM_>), grid, dim3(256), 0, stream, p)
     if (tl) {
         if (acc && om) MAUA_X6_LAUNCH(true, true, true);
@@ -311,7 +355,14 @@ int conv_x6_launch(const ConvArgs& a, int n, hipStream_t stream) {
         else MAUA_X6_LAUNCH(false, false, false);
     }
 #undef MAUA_X6_LAUNCH
-    return check_launch("conv_x6_kernel");
+    int rc = check_launch("conv_x6_kernel");
+    if (rc || ks == 1) return rc;
+    const int64_t out_plane = (int64_t)a.OH * a.OW, total = (int64_t)n * a.Cout * out_plane;
+    int fb = (int)((total + 255) / 256);
+    if (fb > 4096) fb = 4096;
+    hipLaunchKernelGGL(x6_splitk_finish_kernel, dim3(fb), dim3(256), 0, stream, a.ws, a.bias, a.omask, a.y, ks, a.Cout, out_plane,
+                       total, a.relu, a.accumulate);
+    return check_launch("x6_splitk_finish_kernel");
 }
 
 }  // namespace maua
@@ -342,8 +393,21 @@ int maua_conv_pack_filters_x6(const float* w_oihw, void* bank_fwd, void* bank_bw
     return MAUA_OK;
 }
 
+size_t maua_conv_x6_workspace_bytes(int n, int cin, int h, int w, int cout, int pad) {
+    if (n <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || pad < 0) return 0;
+    ConvArgs a{};
+    a.Cin = cin;
+    a.Cout = cout;
+    a.OH = h + 2 * pad - 2;
+    a.OW = w + 2 * pad - 2;
+    if (a.OH <= 0 || a.OW <= 0) return 0;
+    const int ks = x6_choose_split(a, n);
+    return ks > 1 ? (size_t)n * ks * cout * a.OH * a.OW * sizeof(float) : 0;
+}
+
 int maua_conv3x3_x6(const float* x, const void* bank, const float* bias, const float* out_relu_mask, float* y, int n,
-                    int cin, int h, int w, int cout, int pad, int relu, int accumulate, maua_stream_t stream) {
+                    int cin, int h, int w, int cout, int pad, int relu, int accumulate, void* workspace,
+                    size_t workspace_bytes, maua_stream_t stream) {
     MAUA_REQUIRE(x && bank && y, MAUA_E_INVAL, "conv3x3_x6: null pointer");
     MAUA_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0 && pad >= 0 && pad <= 2, MAUA_E_INVAL, "conv3x3_x6: bad dims");
     MAUA_REQUIRE(h + 2 * pad >= 3 && w + 2 * pad >= 3, MAUA_E_UNSUPPORTED, "conv3x3_x6: input smaller than the filter");
@@ -363,6 +427,8 @@ int maua_conv3x3_x6(const float* x, const void* bank, const float* bias, const f
     a.pad = pad;
     a.relu = relu;
     a.accumulate = accumulate;
+    // split-K only with a big enough workspace; without one the kernel still runs, just with fewer workgroups
+    a.ws = (workspace && workspace_bytes >= maua_conv_x6_workspace_bytes(n, cin, h, w, cout, pad)) ? (float*)workspace : nullptr;
     return conv_x6_launch(a, n, (hipStream_t)stream);
 }
 

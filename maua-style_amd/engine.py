@@ -139,6 +139,12 @@ class StyleEngine:
                 self.dmat[id(s)] = torch.empty(c, c, device=dev)
                 self.mean[id(s)] = torch.empty(c, device=dev) if s.mod.use_covariance else None
                 ws = max(ws, hip.gram_workspace_bytes(c, hw), 4 * c + 256)
+        for s in self.steps:  # split-K workspaces of the bf16x6 convs (forward and backward-data geometry)
+            if s.kind == "conv" and s.k == 3 and s.stride == 1:
+                n, cin, h, w = shapes[s.src]
+                _, cout, oh, ow = shapes[s.dst]
+                ws = max(ws, hip.conv_x6_workspace_bytes(n, cin, h, w, cout, s.pad),
+                         hip.conv_x6_workspace_bytes(n, cout, oh, ow, cin, 2 - s.pad))
         self.ws = torch.empty(ws, dtype=torch.uint8, device=dev)
         self.x_static = torch.empty(self.shape, device=dev)
 
@@ -215,7 +221,7 @@ class StyleEngine:
                 if self.x6_fwd and self._x6_ok(s, s.mod.out_channels):
                     b6, _ = s.mod.banks6()
                     self._timed("conv_fwd", fl, nb, lambda: hip.conv3x3_x6(
-                        a[s.src], b6, s.mod.bias_device(), s.mod.out_channels, s.pad, s.relu, out=a[s.dst]))
+                        a[s.src], b6, s.mod.bias_device(), s.mod.out_channels, s.pad, s.relu, out=a[s.dst], workspace=self.ws))
                 else:
                     wf, _ = s.mod.banks()
                     self._timed("conv_fwd", fl, nb, lambda: hip.conv2d_fwd(
@@ -276,7 +282,8 @@ class StyleEngine:
                 if self.x6_bwd and self._x6_ok(s, s.mod.in_channels):
                     _, b6 = s.mod.banks6()
                     self._timed("conv_bwd", fl, nb, lambda: hip.conv3x3_x6(
-                        g[s.dst], b6, None, s.mod.in_channels, 2 - s.pad, False, out=g[s.src], out_relu_mask=im))
+                        g[s.dst], b6, None, s.mod.in_channels, 2 - s.pad, False, out=g[s.src], out_relu_mask=im,
+                        workspace=self.ws))
                 else:
                     _, wb = s.mod.banks()
                     self._timed("conv_bwd", fl, nb, lambda: hip.conv2d_bwd_data(

@@ -27,7 +27,8 @@ SIGNATURES = {
     "maua_conv2d_bwd_data": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "maua_conv_x6_bank_bytes": (c_sz, [c_i, c_i]),
     "maua_conv_pack_filters_x6": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p]),
-    "maua_conv3x3_x6": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "maua_conv_x6_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    "maua_conv3x3_x6": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "maua_relu_fwd": (c_i, [c_p, c_i64, c_p]),
     "maua_relu_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_p]),
     "maua_pool_out_size": (c_i, [c_i, c_i, c_i, c_i]),
@@ -160,12 +161,22 @@ def conv_pack_filters_x6(w):
     return bf, bb
 
 
-def conv3x3_x6(x, bank, bias, cout, pad, relu, out=None, out_relu_mask=None, accumulate=False):
+def conv_x6_workspace_bytes(n, cin, h, w, cout, pad):
+    return lib().maua_conv_x6_workspace_bytes(n, cin, h, w, cout, pad)
+
+
+def conv3x3_x6(x, bank, bias, cout, pad, relu, out=None, out_relu_mask=None, accumulate=False, workspace=None):
     n, cin, h, w = x.shape
     if out is None:
         out = torch.empty(n, cout, h + 2 * pad - 2, w + 2 * pad - 2, device=x.device, dtype=torch.float32)
+    if workspace is None:
+        need = conv_x6_workspace_bytes(n, cin, h, w, cout, pad)
+        workspace = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None
     _check(lib().maua_conv3x3_x6(_ptr(_f32(x, "x")), bank.data_ptr(), _ptr(bias), _ptr(out_relu_mask), _ptr(out), n, cin, h,
-                                 w, cout, pad, int(relu), int(accumulate), _stream()), "maua_conv3x3_x6")
+                                 w, cout, pad, int(relu), int(accumulate),
+                                 workspace.data_ptr() if workspace is not None else None,
+                                 workspace.numel() * workspace.element_size() if workspace is not None else 0, _stream()),
+           "maua_conv3x3_x6")
     return out
 
 

@@ -328,6 +328,30 @@ def test_conv3x3_x6_forward_and_backward(hip, cin, cout, H, W, pad):
     assert rel_l2(gx2.cpu(), refb + base.double()) <= 2e-6
 
 
+@pytest.mark.parametrize("cin,cout,H,W", [(512, 512, 16, 16), (256, 256, 33, 40), (512, 64, 8, 8)])
+def test_conv3x3_x6_split_k_matches_single_pass(hip, cin, cout, H, W):
+    # small output grids split the channel loop over workgroups; both forms are the same convolution
+    assert hip.conv_x6_workspace_bytes(1, cin, H, W, cout, 1) > 0
+    assert hip.conv_x6_workspace_bytes(1, 64, 1024, 1024, 64, 1) == 0
+    x = rnd(1, cin, H, W, seed=1)
+    w = rnd(cout, cin, 3, 3, seed=2, scale=math.sqrt(2.0 / (9 * cin)))
+    b = rnd(cout, seed=3, scale=0.1)
+    base, mask = rnd(1, cout, H, W, seed=5), rnd(1, cout, H, W, seed=6)
+    ref = (torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1) + base.double())) * (mask > 0)
+    bank_f, _ = hip.conv_pack_filters_x6(dev(w))
+    none = torch.empty(0, dtype=torch.uint8, device="cuda")
+    one = hip.conv3x3_x6(dev(x), bank_f, dev(b), cout, 1, True, out=dev(base.clone()), accumulate=True, out_relu_mask=dev(mask),
+                         workspace=none)
+    split = hip.conv3x3_x6(dev(x), bank_f, dev(b), cout, 1, True, out=dev(base.clone()), accumulate=True,
+                           out_relu_mask=dev(mask))
+    split2 = hip.conv3x3_x6(dev(x), bank_f, dev(b), cout, 1, True, out=dev(base.clone()), accumulate=True,
+                            out_relu_mask=dev(mask))
+    torch.cuda.synchronize()
+    assert rel_l2(one.cpu(), ref) <= 2e-6 and rel_l2(split.cpu(), ref) <= 2e-6
+    assert rel_l2(split.cpu(), one.cpu().double()) <= 5e-7
+    assert torch.equal(split, split2)
+
+
 def test_conv3x3_x6_is_deterministic(hip):
     x, w = dev(rnd(1, 64, 40, 40, seed=1)), dev(rnd(128, 64, 3, 3, seed=2, scale=0.05))
     bank_f, _ = hip.conv_pack_filters_x6(w)
