@@ -208,14 +208,35 @@ lbfgs_finish_dots_kernel(const float* __restrict__ partial, double* __restrict__
     }
 }
 
-// The recursion in coefficient space, one wave.  delta lives in LDS (fp64); M rows are read from global memory.
+// Sum of a double over the wave with DPP row shifts / row broadcasts (no LDS round trips); the result is uniform.
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_add(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return v + __hiloint2double(hi2, lo2);
+}
+__device__ inline double wave_total_f64(double v) {
+    v = dpp_add<0x111, 0xf>(v);  // row_shr:1   (inclusive scan inside each row of 16 lanes)
+    v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);  // row_shr:8
+    v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 -> rows 1, 3
+    v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 -> rows 2, 3 ; lane 63 holds the total
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
+// The recursion in coefficient space, one wave.  The 2*len steps form one dependent chain, so the step latency is what
+// counts: delta stays in registers (lane l holds entries l + 64 q), the dot of a step is reduced with DPP, and the rows
+// of M (which do not depend on delta) stream through a D-deep register ring so no step waits for global memory.
+template <int NQ>
 __global__ void __launch_bounds__(64)
 lbfgs_coeffs_kernel(LbfgsHeader* __restrict__ hdr, const double* __restrict__ dots, double* __restrict__ M,
                     float* __restrict__ coef, int m1, int history, float lr, float tol_change) {
-    extern __shared__ double sh[];  // delta[nb_ids], alpha[m1]
+    extern __shared__ double sh[];  // alpha[m1 + 1], rinv[m1 + 1]  (slot m1: sink / zero for the padding steps)
     const int nb_ids = 2 * m1 + 1, gid = 2 * m1;
-    double* delta = sh;
-    double* alpha = sh + nb_ids;
+    double* alpha = sh;
+    double* rinv = sh + m1 + 1;
     const int lane = threadIdx.x;
     int len = hdr->len, head = hdr->head, cand = hdr->cand;
     const bool first = hdr->n_iter == 0;
@@ -242,83 +263,71 @@ lbfgs_coeffs_kernel(LbfgsHeader* __restrict__ hdr, const double* __restrict__ do
         }
         M[(size_t)i * nb_ids + gid] = dg;
         M[(size_t)gid * nb_ids + i] = dg;
-        delta[i] = 0.0;
     }
     __syncthreads();
     __threadfence_block();
-    if (lane == 0) delta[gid] = -1.0;  // q = -g
+    for (int slot = lane; slot < m1; slot += 64) rinv[slot] = 1.0 / M[(size_t)(m1 + slot) * nb_ids + slot];  // ro = 1 / (y.s)
+    if (lane == 0) rinv[m1] = 0.0;
     __syncthreads();
 
-    // Rows of M do not depend on delta, so the row (and rho) of step i+1 is fetched while step i is reduced:
-    // the dependent chain per step is one wave reduction + one LDS update, not a global-memory round trip.
-    constexpr int NQ = 8;  // nb_ids <= 512  (history <= 254)
-    auto load_row = [&](int row, int rho_row, int rho_col, double (&r)[NQ], double& rho_den) {
+    // Unconditional loads (column index clamped; the matching delta entries are zero) so the ring is straight-line code
+    // and the compiler can wait for exactly the oldest row instead of draining the queue.
+    auto load_row = [&](int row, double (&r)[NQ]) {
         const double* mr = M + (size_t)row * nb_ids;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int jdx = lane + 64 * q;
-            r[q] = jdx < nb_ids ? mr[jdx] : 0.0;
-        }
-        rho_den = M[(size_t)rho_row * nb_ids + rho_col];
+        for (int q = 0; q < NQ; ++q) r[q] = mr[min(lane + 64 * q, nb_ids - 1)];
     };
-    auto dot_row = [&](const double (&r)[NQ]) {
-        double acc = 0.0;
+    double dl[NQ], grow[NQ];  // delta (q = -g to start with) and the row of g for the final g . d
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int jdx = lane + 64 * q;
-            if (jdx < nb_ids) acc += delta[jdx] * r[q];
-        }
-        acc = wave_sum(acc);
-        return __shfl(acc, 0, 64);
-    };
+    for (int q = 0; q < NQ; ++q) dl[q] = lane + 64 * q == gid ? -1.0 : 0.0;
+    load_row(gid, grow);
 
-    double cur[NQ], nxt[NQ], den_cur = 1.0, den_nxt = 1.0;
-    if (!first && len > 0) {
-        {
-            const int p = (head + len - 1) % m1;
-            load_row(p, m1 + p, p, cur, den_cur);
-        }
-        for (int i = len - 1; i >= 0; --i) {  // newest -> oldest
-            const int p = (head + i) % m1;
-            if (i > 0) {
-                const int pn = (head + i - 1) % m1;
-                load_row(pn, m1 + pn, pn, nxt, den_nxt);
-            } else {
-                const int pn = head % m1;  // first row of the second loop: y_oldest
-                load_row(m1 + pn, m1 + pn, pn, nxt, den_nxt);
-            }
-            const double al = dot_row(cur) * (1.0 / den_cur);  // al[i] = old_stps[i].dot(q) * ro[i]
-            if (lane == 0) {
-                alpha[i] = al;
-                delta[m1 + p] -= al;  // q.add_(old_dirs[i], alpha=-al[i])
-            }
-            __syncthreads();
+    // step k < len: first loop, newest -> oldest (row of s_i); step k >= len: second loop, oldest -> newest (row of y_i)
+    // Steps past `total` (padding up to a multiple of D) read the row of g and add zero.
+    const int total = first ? 0 : 2 * len;
+    auto row_of = [&](int k) { return k < len ? (head + len - 1 - k) % m1 : (k < total ? m1 + (head + k - len) % m1 : gid); };
+    constexpr int D = 8;
+    double ring[D][NQ];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) cur[q] = nxt[q];
-            den_cur = den_nxt;
+    for (int u = 0; u < D; ++u) load_row(row_of(u), ring[u]);
+    for (int k0 = 0; k0 < total; k0 += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int k = k0 + u;
+            const bool live = k < total, second = k >= len;
+            const int i = second ? k - len : len - 1 - k;
+            const int pslot = live ? (head + i) % m1 : m1;
+            const double ri = rinv[pslot];
+            const double al_i = alpha[second && live ? i : m1];
+            const double scale = k == len ? h_diag : 1.0;  // r = q * H_diag between the two loops
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                dl[q] *= scale;
+                acc = fma(dl[q], ring[u][q], acc);
+            }
+            const double dot = wave_total_f64(acc) * ri;
+            // first loop:  al[i] = old_stps[i].dot(q) * ro[i];  q.add_(old_dirs[i], alpha=-al[i])
+            // second loop: be_i = old_dirs[i].dot(r) * ro[i];   r.add_(old_stps[i], alpha=al[i]-be_i)
+            const int target = !live ? -1 : (second ? pslot : m1 + pslot);
+            const double add = second ? al_i - dot : -dot;
+            alpha[second || !live ? m1 : i] = dot;  // every lane stores the same value: no cross-lane hand-off to order
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) dl[q] += lane + 64 * q == target ? add : 0.0;
+            load_row(row_of(k + D), ring[u]);
         }
     }
-    if (!first) {
-        for (int jdx = lane; jdx < nb_ids; jdx += 64) delta[jdx] *= h_diag;  // r = q * H_diag
-        __syncthreads();
-        for (int i = 0; i < len; ++i) {  // oldest -> newest
-            const int p = (head + i) % m1;
-            if (i + 1 < len) {
-                const int pn = (head + i + 1) % m1;
-                load_row(m1 + pn, m1 + pn, pn, nxt, den_nxt);
-            }
-            const double be = dot_row(cur) * (1.0 / den_cur);  // be_i = old_dirs[i].dot(r) * ro[i]
-            if (lane == 0) delta[p] += alpha[i] - be;          // r.add_(old_stps[i], alpha=al[i]-be_i)
-            __syncthreads();
+    if (!first && len == 0) {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) cur[q] = nxt[q];
-            den_cur = den_nxt;
-        }
+        for (int q = 0; q < NQ; ++q) dl[q] *= h_diag;
     }
-    double gden;
-    load_row(gid, gid, gid, cur, gden);
-    const double gtd = dot_row(cur);  // g . d
-    for (int jdx = lane; jdx < nb_ids; jdx += 64) coef[jdx] = (float)delta[jdx];
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc = fma(dl[q], grow[q], acc);
+    const double gtd = wave_total_f64(acc);  // g . d
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+        if (lane + 64 * q < nb_ids) coef[lane + 64 * q] = (float)dl[q];
     if (lane == 0) {
         float t = lr;
         if (first) {
@@ -439,9 +448,13 @@ int maua_lbfgs_iterate(void* state, float* x, const float* grad, int64_t count, 
     hipLaunchKernelGGL(lbfgs_finish_dots_kernel, dim3(L.nb_ids), dim3(256), 0, s, partial, dots, L.nwg, L.nb_ids);
     rc = check_launch("lbfgs_finish_dots_kernel");
     if (rc) return rc;
-    const size_t lds3 = sizeof(double) * (L.nb_ids + L.m1);
-    hipLaunchKernelGGL(lbfgs_coeffs_kernel, dim3(1), dim3(64), lds3, s, hdr, dots, M, coef, L.m1, history, lr,
-                       tolerance_change);
+    const size_t lds3 = sizeof(double) * 2 * (L.m1 + 1);
+    if (L.nb_ids <= 256)
+        hipLaunchKernelGGL(lbfgs_coeffs_kernel<4>, dim3(1), dim3(64), lds3, s, hdr, dots, M, coef, L.m1, history, lr,
+                           tolerance_change);
+    else
+        hipLaunchKernelGGL(lbfgs_coeffs_kernel<8>, dim3(1), dim3(64), lds3, s, hdr, dots, M, coef, L.m1, history, lr,
+                           tolerance_change);
     rc = check_launch("lbfgs_coeffs_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(lbfgs_combine_kernel, dim3(L.nwg), dim3(256), 0, s, hdr, coef, grad, S, Y, d, x, count, L.m1);
