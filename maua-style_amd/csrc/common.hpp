@@ -75,6 +75,7 @@ struct ConvArgs {
     float* ws;           // [n][ksplit][Cout][OH][OW] partial sums (split-K only)
 };
 int conv_mfma_dispatch(const ConvArgs& a, int ks, int n, hipStream_t stream);
+int conv3x3_few_out(const ConvArgs& a, int n, hipStream_t stream);  // 3x3, stride 1, Cout <= 4 (conv_direct.hip)
 int conv_mfma2_dispatch(const ConvArgs& a, int ks, int n, hipStream_t stream);
 int conv_direct_fwd(const float* x, const float* mask, const float* wf, const float* bias, float* y, int n, int cin, int h,
                     int w, int cout, int oh, int ow, int kh, int kw, int stride, int pad, int relu, int accumulate,

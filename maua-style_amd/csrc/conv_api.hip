@@ -1,11 +1,18 @@
 // C-ABI entry points of the convolution family: route to the MFMA implicit-GEMM path (stride 1, k in {1,3,5}) or
 // to the direct path (everything else).
+#include <cstdlib>
+
 #include "common.hpp"
 
 using namespace maua;
 
 static inline bool mfma_geometry(int kh, int kw, int stride) {
     return stride == 1 && kh == kw && (kh == 1 || kh == 3 || kh == 5);
+}
+// a 3x3 pass that produces <= 4 channels from many (conv1_1 backward-data) is vector-ALU work, not an MFMA tile
+static int conv_route(const ConvArgs& a, int ks, int n, hipStream_t stream) {
+    if (ks == 3 && a.Cout <= 4 && a.Cin >= 16 && !getenv("MAUA_CONV_NO_FEW_OUT")) return conv3x3_few_out(a, n, stream);
+    return conv_mfma_dispatch(a, ks, n, stream);
 }
 
 extern "C" {
@@ -38,7 +45,7 @@ int maua_conv2d_fwd(const float* x, const float* in_mask, const float* wf, const
         a.pad = pad;
         a.relu = relu;
         a.accumulate = accumulate;
-        return conv_mfma_dispatch(a, kh, n, (hipStream_t)stream);
+        return conv_route(a, kh, n, (hipStream_t)stream);
     }
     return conv_direct_fwd(x, in_mask, wf, bias, y, n, cin, h, w, cout, oh, ow, kh, kw, stride, pad, relu, accumulate,
                            (hipStream_t)stream);
@@ -71,7 +78,7 @@ int maua_conv2d_bwd_data(const float* gy, const float* out_mask, const float* wb
         a.relu = 0;
         a.accumulate = accumulate;
         MAUA_REQUIRE(a.pad >= 0, MAUA_E_UNSUPPORTED, "conv2d_bwd_data: pad %d > k-1", pad);
-        return conv_mfma_dispatch(a, kh, n, (hipStream_t)stream);
+        return conv_route(a, kh, n, (hipStream_t)stream);
     }
     MAUA_REQUIRE(w_oihw, MAUA_E_INVAL, "conv2d_bwd_data: the direct path needs the OIHW weights");
     return conv_direct_bwd(gy, out_mask, w_oihw, in_relu_mask, gx, n, cin, h, w, cout, oh, ow, kh, kw, stride, pad, accumulate,

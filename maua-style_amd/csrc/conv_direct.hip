@@ -74,6 +74,127 @@ conv_direct_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ m
     gx[o] = acc;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution that PRODUCES only a few channels (CO <= 4): the backward-data pass of conv1_1
+// (64 gradient channels -> 3 pixel channels, reference models.py:129 through autograd).  A 64-row MFMA tile would be
+// 95 % padding; the work is 27 FMAs per input value, so this is a vector-ALU kernel bound by reading the input once:
+// lane = column, four output rows per thread, the left/right taps come from the neighbouring lanes through DPP
+// wave shifts (lanes 0 and 63 are halo), the 27 filter values of a channel are wave-uniform (scalar registers).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int FO_R = 4, FO_TW = 62;
+
+__device__ inline float lane_from_left(float v) {  // lane i <- lane i-1  (wave_shr:1)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ inline float lane_from_right(float v) {  // lane i <- lane i+1  (wave_shl:1)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+
+template <int CO, bool MASK>
+__global__ void __launch_bounds__(256)
+conv3x3_few_out_kernel(ConvArgs p, const float* __restrict__ wbank) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.z;
+    const int ox = blockIdx.x * FO_TW + lane - 1;          // output column (lanes 1..62 are stored)
+    const int oy0 = (blockIdx.y * 4 + wave) * FO_R;        // first of the FO_R output rows of this wave
+    const int cx = ox - p.pad + 1;                         // input column of the centre tap
+    const bool col_ok = cx >= 0 && cx < p.W;
+    const int64_t plane = (int64_t)p.H * p.W;
+    int off[FO_R + 2];
+    bool ok[FO_R + 2];
+#pragma unroll
+    for (int r = 0; r < FO_R + 2; ++r) {
+        const int iy = oy0 - p.pad + r;
+        ok[r] = col_ok && iy >= 0 && iy < p.H;
+        off[r] = min(max(iy, 0), p.H - 1) * p.W + min(max(cx, 0), p.W - 1);
+        asm volatile("" : "+v"(off[r]));  // keep the loads unconditional: the select below zeroes the padding
+    }
+    const float* xin = p.x + (int64_t)n * p.Cin * plane;
+    const float* min_ = MASK ? p.mask + (int64_t)n * p.Cin * plane : nullptr;
+    auto load = [&](int ci, float (&v)[FO_R + 2]) {
+        const float* xc = xin + (int64_t)ci * plane;
+#pragma unroll
+        for (int r = 0; r < FO_R + 2; ++r) {
+            float t = xc[off[r]];
+            if (MASK) t = min_[(int64_t)ci * plane + off[r]] > 0.f ? t : 0.f;
+            v[r] = ok[r] ? t : 0.f;
+        }
+    };
+    float master[FO_R][CO], acc[FO_R][CO];
+#pragma unroll
+    for (int r = 0; r < FO_R; ++r)
+#pragma unroll
+        for (int c = 0; c < CO; ++c) master[r][c] = acc[r][c] = 0.f;
+    float cur[FO_R + 2], nxt[FO_R + 2];
+    load(0, cur);
+    for (int ci = 0; ci < p.Cin; ++ci) {
+        load(min(ci + 1, p.Cin - 1), nxt);  // unconditional (the last one re-reads its own channel)
+        float wv[9][CO];  // wave-uniform: bank layout [tap][ci][co]
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < CO; ++c) wv[t][c] = wbank[((int64_t)t * p.Cin + ci) * CO + c];
+#pragma unroll
+        for (int r = 0; r < FO_R + 2; ++r) {
+            const float mid = cur[r], lft = lane_from_left(mid), rgt = lane_from_right(mid);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int orow = r - ky;  // input row r feeds output row r - ky through tap row ky
+                if (orow < 0 || orow >= FO_R) continue;
+#pragma unroll
+                for (int c = 0; c < CO; ++c) {
+                    acc[orow][c] = fmaf(lft, wv[ky * 3 + 0][c], acc[orow][c]);
+                    acc[orow][c] = fmaf(mid, wv[ky * 3 + 1][c], acc[orow][c]);
+                    acc[orow][c] = fmaf(rgt, wv[ky * 3 + 2][c], acc[orow][c]);
+                }
+            }
+        }
+        if ((ci & 7) == 7 || ci + 1 == p.Cin) {  // two-level accumulation like the MFMA kernels
+#pragma unroll
+            for (int r = 0; r < FO_R; ++r)
+#pragma unroll
+                for (int c = 0; c < CO; ++c) {
+                    master[r][c] += acc[r][c];
+                    acc[r][c] = 0.f;
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < FO_R + 2; ++r) cur[r] = nxt[r];
+    }
+    if (lane < 1 || lane > FO_TW || ox >= p.OW) return;
+    const int64_t oplane = (int64_t)p.OH * p.OW;
+#pragma unroll
+    for (int r = 0; r < FO_R; ++r) {
+        const int oy = oy0 + r;
+        if (oy >= p.OH) break;
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            const int64_t o = ((int64_t)n * CO + c) * oplane + (int64_t)oy * p.OW + ox;
+            float v = master[r][c];
+            if (p.bias) v += p.bias[c];
+            if (p.accumulate) v += p.y[o];
+            if (p.relu) v = v > 0.f ? v : 0.f;
+            if (p.omask) v = p.omask[o] > 0.f ? v : 0.f;
+            p.y[o] = v;
+        }
+    }
+}
+
+int conv3x3_few_out(const ConvArgs& a, int n, hipStream_t stream) {
+    dim3 grid((unsigned)((a.OW + FO_TW - 1) / FO_TW), (unsigned)((a.OH + 4 * FO_R - 1) / (4 * FO_R)), (unsigned)n);
+#define MAUA_FO(CO_)                                                                                            \
+    case CO_:                                                                                                   \
+        if (a.mask) hipLaunchKernelGGL((conv3x3_few_out_kernel<CO_, true>), grid, dim3(256), 0, stream, a, a.w);      \
+        else hipLaunchKernelGGL((conv3x3_few_out_kernel<CO_, false>), grid, dim3(256), 0, stream, a, a.w);             \
+        break;
+    switch (a.Cout) {
+        MAUA_FO(1) MAUA_FO(2) MAUA_FO(3) MAUA_FO(4)
+        default: MAUA_REQUIRE(false, MAUA_E_UNSUPPORTED, "conv3x3_few_out: %d output channels", a.Cout);
+    }
+#undef MAUA_FO
+    return check_launch("conv3x3_few_out_kernel");
+}
+
 int conv_direct_fwd(const float* x, const float* mask, const float* wf, const float* bias, float* y, int n, int cin, int h,
                     int w, int cout, int oh, int ow, int kh, int kw, int stride, int pad, int relu, int accumulate,
                     hipStream_t stream) {

@@ -48,6 +48,10 @@ CONV_CASES = [
     (3, 96, 99, 99, 11, 4, 0),
     (3, 96, 128, 128, 11, 4, 0),
     (8, 16, 9, 9, 3, 1, 0),          # no padding
+    (3, 64, 70, 200, 3, 1, 1),       # few-output-channel kernel (backward) over several 62-column tiles
+    (64, 4, 21, 130, 3, 1, 1),       # ... forward direction, 4 channels
+    (32, 1, 40, 64, 3, 1, 1),        # ... 1 channel
+    (2, 32, 19, 63, 3, 1, 0),        # ... 2 channels, no padding (backward pads by 2)
 ]
 
 
