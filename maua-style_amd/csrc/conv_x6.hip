@@ -40,6 +40,13 @@ __device__ __forceinline__ unsigned short bf16_bits(float x) {
     return __builtin_bit_cast(unsigned short, b);
 }
 __device__ __forceinline__ float bf16_value(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// one v_cvt_pk_bf16_f32: bits 15:0 = bf16(a), bits 31:16 = bf16(b), round to nearest even
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
 
 // x -> (hi, mid, lo) bf16 bit patterns with x == hi + mid + lo (exactly, barring underflow of the last part)
 __device__ __forceinline__ void split3(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
@@ -83,7 +90,7 @@ __global__ void pack_x6_kernel(const float* __restrict__ w, unsigned short* __re
     }
 }
 
-template <bool TL, bool ACC, bool OM>
+template <bool TL, bool ACC, bool OM, bool C8>
 __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
     constexpr int ZERO_BYTES = (32 * 3 + 3) * 16;  // what a lane's A reads of one k-step span: (t*32*3 + part)*16 + 16
     __shared__ __attribute__((aligned(16))) unsigned char smem[X6_PATCH_BYTES + X6_W_BYTES + ZERO_BYTES];
@@ -105,40 +112,47 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
     const float* __restrict__ xin = p.x + (int64_t)n * p.Cin * in_plane;
     const int x0 = (blockIdx.x % p.tiles_x) * 32, y0 = (blockIdx.x / p.tiles_x) * X6_PH;
 
-    // staging descriptor of this thread's patch position
-    int p_off = -1;
+    // staging descriptor of this thread's patch position: a 32-bit byte offset inside a channel plane (clamped into the
+    // image; positions in the zero padding are blanked when the chunk is written to LDS)
+    unsigned p_byte = 0;
+    bool pos_ok = false;
     if (tid < X6_NPOS) {
         const int r = tid / X6_PC, col = tid - r * X6_PC;
         const int iy = y0 + r - p.pad, ix = x0 + col - p.pad;
-        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) p_off = iy * p.W + ix;
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+            p_byte = (unsigned)(iy * p.W + ix) * 4u;
+            pos_ok = true;
+        }
     }
     float rp[8];
-    unsigned rp_ok = 0;  // bit c: channel c of the staged chunk is inside the tensor (and the position inside the image)
+    int rp_c0 = 0;  // first channel of the chunk held in rp
     auto load_patch = [&](int c0) {
         asm volatile("" : "+s"(c0));
-        // Unconditional loads from clamped addresses; NOTHING touches the loaded registers here, so the compiler's wait
-        // for them sits in store_patch (after the chunk's MFMAs), not right behind the loads.
-        rp_ok = 0;
+        // Unconditional loads, wave-uniform plane base + per-lane 32-bit offset (no vector address arithmetic); NOTHING
+        // touches the loaded registers here, so the wait for them sits in store_patch (after the chunk's MFMAs).
+        rp_c0 = c0;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const bool ok = p_off >= 0 && c0 + c < p.Cin;
-            unsigned long long a = ok ? (unsigned long long)((int64_t)(c0 + c) * in_plane + p_off) : 0ull;
-            asm volatile("" : "+v"(a));  // opaque address: the load may not be predicated on `ok`
-            rp[c] = xin[a];
-            rp_ok |= ok ? (1u << c) : 0u;
+            const int chn = C8 ? c0 + c : min(c0 + c, p.Cin - 1);
+            const char* plane = reinterpret_cast<const char*>(xin + (int64_t)chn * in_plane);
+            rp[c] = *reinterpret_cast<const float*>(plane + p_byte);
         }
     };
     auto store_patch = [&]() {
         if (tid < X6_NPOS_PAD) {
-            unsigned short h[8], m[8], l[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) split3((rp_ok >> c) & 1u ? rp[c] : 0.f, h[c], m[c], l[c]);
+            // split pairs of values with the packed converts: the three u32 words of a pair come out ready to store
             u32x4 vh, vm, vl;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                vh[q] = (unsigned)h[2 * q] | ((unsigned)h[2 * q + 1] << 16);
-                vm[q] = (unsigned)m[2 * q] | ((unsigned)m[2 * q + 1] << 16);
-                vl[q] = (unsigned)l[2 * q] | ((unsigned)l[2 * q + 1] << 16);
+                const bool ok0 = pos_ok && (C8 || rp_c0 + 2 * q < p.Cin), ok1 = pos_ok && (C8 || rp_c0 + 2 * q + 1 < p.Cin);
+                const float v0 = ok0 ? rp[2 * q] : 0.f, v1 = ok1 ? rp[2 * q + 1] : 0.f;
+                const unsigned H = cvt_pk_bf16(v0, v1);
+                const float r0 = v0 - __builtin_bit_cast(float, H << 16), r1 = v1 - __builtin_bit_cast(float, H & 0xffff0000u);
+                const unsigned M = cvt_pk_bf16(r0, r1);
+                const float s0 = r0 - __builtin_bit_cast(float, M << 16), s1 = r1 - __builtin_bit_cast(float, M & 0xffff0000u);
+                vh[q] = H;
+                vm[q] = M;
+                vl[q] = cvt_pk_bf16(s0, s1);
             }
             *reinterpret_cast<u32x4*>(Pl + (0 * X6_NPOS_PAD + tid) * 16) = vh;
             *reinterpret_cast<u32x4*>(Pl + (1 * X6_NPOS_PAD + tid) * 16) = vm;
@@ -342,7 +356,11 @@ int conv_x6_launch(const ConvArgs& a, int n, hipStream_t stream) {
     p.ksplit = ks;
     dim3 grid((unsigned)tiles, (unsigned)((a.Cout + X6_COT - 1) / X6_COT), (unsigned)(n * ks));
     const bool tl = (a.Cin + 7) / 8 > 4, acc = ks == 1 && a.accumulate != 0, om = ks == 1 && a.omask != nullptr;
-#define MAUA_X6_LAUNCH(TL_, ACC_, OM_) hipLaunchKernelGGL((conv_x6_kernel<TL_, ACC_, OM_>), grid, dim3(256), 0, stream, p)
+#define MAUA_X6_LAUNCH(TL_, ACC_, OM_)                                                                      \
+    do {                                                                                                    \
+        if (a.Cin % 8 == 0) hipLaunchKernelGGL((conv_x6_kernel<TL_, ACC_, OM_, true>), grid, dim3(256), 0, stream, p);  \
+        else hipLaunchKernelGGL((conv_x6_kernel<TL_, ACC_, OM_, false>), grid, dim3(256), 0, stream, p);                \
+    } while (0)
     if (tl) {
         if (acc && om) MAUA_X6_LAUNCH(true, true, true);
         else if (acc) MAUA_X6_LAUNCH(true, true, false);
@@ -411,7 +429,7 @@ int maua_conv3x3_x6(const float* x, const void* bank, const float* bias, const f
     MAUA_REQUIRE(x && bank && y, MAUA_E_INVAL, "conv3x3_x6: null pointer");
     MAUA_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0 && pad >= 0 && pad <= 2, MAUA_E_INVAL, "conv3x3_x6: bad dims");
     MAUA_REQUIRE(h + 2 * pad >= 3 && w + 2 * pad >= 3, MAUA_E_UNSUPPORTED, "conv3x3_x6: input smaller than the filter");
-    MAUA_REQUIRE((int64_t)h * w < (1ll << 31), MAUA_E_UNSUPPORTED, "conv3x3_x6: plane too large");
+    MAUA_REQUIRE((int64_t)h * w < (1ll << 30), MAUA_E_UNSUPPORTED, "conv3x3_x6: plane too large");
     ConvArgs a{};
     a.x = x;
     a.w6 = bank;

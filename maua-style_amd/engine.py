@@ -220,11 +220,11 @@ class StyleEngine:
                 fl, nb = self._conv_work(s, a[s.src].shape, a[s.dst].shape, False)
                 if self.x6_fwd and self._x6_ok(s, s.mod.out_channels):
                     b6, _ = s.mod.banks6()
-                    self._timed("conv_fwd", fl, nb, lambda: hip.conv3x3_x6(
+                    self._timed("conv_x6_fwd", fl, nb, lambda: hip.conv3x3_x6(
                         a[s.src], b6, s.mod.bias_device(), s.mod.out_channels, s.pad, s.relu, out=a[s.dst], workspace=self.ws))
                 else:
                     wf, _ = s.mod.banks()
-                    self._timed("conv_fwd", fl, nb, lambda: hip.conv2d_fwd(
+                    self._timed("conv_other_fwd", fl, nb, lambda: hip.conv2d_fwd(
                         a[s.src], wf, s.mod.bias_device(), s.k, s.stride, s.pad, s.relu, out=a[s.dst]))
             elif s.kind == "relu":
                 hip.relu_(a[s.src])
@@ -281,12 +281,12 @@ class StyleEngine:
                 im = a[s.src] if premask(s) else None
                 if self.x6_bwd and self._x6_ok(s, s.mod.in_channels):
                     _, b6 = s.mod.banks6()
-                    self._timed("conv_bwd", fl, nb, lambda: hip.conv3x3_x6(
+                    self._timed("conv_x6_bwd", fl, nb, lambda: hip.conv3x3_x6(
                         g[s.dst], b6, None, s.mod.in_channels, 2 - s.pad, False, out=g[s.src], out_relu_mask=im,
                         workspace=self.ws))
                 else:
                     _, wb = s.mod.banks()
-                    self._timed("conv_bwd", fl, nb, lambda: hip.conv2d_bwd_data(
+                    self._timed("conv_other_bwd", fl, nb, lambda: hip.conv2d_bwd_data(
                         g[s.dst], None, wb, s.mod.weight.detach(), a[s.src].shape, s.k, s.stride, s.pad, out=g[s.src],
                         in_relu_mask=im))
                 cur = s.src
