@@ -195,9 +195,130 @@ int conv3x3_few_out(const ConvArgs& a, int n, hipStream_t stream) {
     return check_launch("conv3x3_few_out_kernel");
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Strided stem (NIN conv1: 11x11 stride 4, 3 -> 96 channels, no padding; reference models.py:83).  Both passes are
+// vector-ALU kernels with wave-uniform filter values (scalar loads, no LDS):
+//   forward:  thread = one output pixel x COG output channels; a filter row's KS input values are contiguous
+//             (unaligned vector loads straight from global memory, L1 absorbs the overlap between neighbours).
+//   backward: thread = S consecutive input pixels of one row (all S column phases) x all CI input channels.  With
+//             ky = (iy mod S) + S a and kx = px + S b every filter value is used exactly once per thread and the
+//             gradient values it multiplies are the 3x3 neighbourhood gy[co][iy/S - a][ix/S - b].
+// ---------------------------------------------------------------------------------------------------------
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int KS, int S, int COG>
+__global__ void __launch_bounds__(256)
+conv_strided_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wf, const float* __restrict__ bias,
+                        float* __restrict__ y, int Cin, int H, int W, int Cout, int OH, int OW, int relu, int accumulate) {
+    const int64_t opix = (int64_t)OH * OW;
+    const int64_t idx_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t idx = idx_raw < opix ? idx_raw : opix - 1;  // out-of-range threads recompute the last pixel, store nothing
+    const int co0 = blockIdx.y * COG, n = blockIdx.z;
+    const int oy = (int)(idx / OW), ox = (int)(idx - (int64_t)oy * OW);
+    float acc[COG];
+#pragma unroll
+    for (int c = 0; c < COG; ++c) acc[c] = 0.f;
+    const float* xin = x + (int64_t)n * Cin * H * W + (int64_t)(oy * S) * W + ox * S;
+    for (int ci = 0; ci < Cin; ++ci) {
+        for (int ky = 0; ky < KS; ++ky) {
+            const float* row = xin + ((int64_t)ci * H + ky) * W;
+            float v[KS];
+#pragma unroll
+            for (int q = 0; q + 4 <= KS; q += 4) {
+                const f32x4u t = *reinterpret_cast<const f32x4u*>(row + q);
+                v[q] = t[0], v[q + 1] = t[1], v[q + 2] = t[2], v[q + 3] = t[3];
+            }
+#pragma unroll
+            for (int q = KS & ~3; q < KS; ++q) v[q] = row[q];
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                const float* wr = wf + ((int64_t)(ky * KS + kx) * Cin + ci) * Cout + co0;  // wave-uniform
+#pragma unroll
+                for (int c = 0; c < COG; ++c) acc[c] = fmaf(v[kx], wr[c], acc[c]);
+            }
+        }
+    }
+    if (idx_raw >= opix) return;
+#pragma unroll
+    for (int c = 0; c < COG; ++c) {
+        const int64_t o = ((int64_t)n * Cout + co0 + c) * opix + idx;
+        float r = acc[c] + (bias ? bias[co0 + c] : 0.f);
+        if (accumulate) r += y[o];
+        if (relu) r = r > 0.f ? r : 0.f;
+        y[o] = r;
+    }
+}
+
+template <int KS, int S, int CI>
+__global__ void __launch_bounds__(256)
+conv_strided_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ w_oihw, const float* __restrict__ omask,
+                        float* __restrict__ gx, int H, int W, int Cout, int OH, int OW, int accumulate) {
+    constexpr int NA = (KS + S - 1) / S;  // filter rows / columns per phase
+    const int bx = blockIdx.x * blockDim.x + threadIdx.x;  // block of S input columns
+    const int iy = blockIdx.y, n = blockIdx.z;
+    const int py = iy % S, by = iy / S;                   // wave-uniform
+    float acc[CI][S];
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+        for (int px = 0; px < S; ++px) acc[ci][px] = 0.f;
+    const float* g = gy + (int64_t)n * Cout * OH * OW;
+    // clamped gather offsets + validity of the NA x NA neighbourhood (same for every co)
+    int goff[NA][NA];
+    bool gok[NA][NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NA; ++b) {
+            const int oy = by - a, ox = bx - b;
+            gok[a][b] = oy >= 0 && oy < OH && ox >= 0 && ox < OW;
+            goff[a][b] = min(max(oy, 0), OH - 1) * OW + min(max(ox, 0), OW - 1);
+        }
+    for (int co = 0; co < Cout; ++co) {
+        const float* gc = g + (int64_t)co * OH * OW;
+        float gv[NA][NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int b = 0; b < NA; ++b) {
+                const float t = gc[goff[a][b]];
+                gv[a][b] = gok[a][b] ? t : 0.f;
+            }
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            const int ky = py + S * a;
+            if (ky >= KS) continue;  // wave-uniform
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci) {
+                const float* wr = w_oihw + (((int64_t)co * CI + ci) * KS + ky) * KS;  // wave-uniform row of KS values
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) acc[ci][kx % S] = fmaf(gv[a][kx / S], wr[kx], acc[ci][kx % S]);
+            }
+        }
+    }
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+        for (int px = 0; px < S; ++px) {
+            const int ix = bx * S + px;
+            if (ix >= W) continue;
+            const int64_t o = (((int64_t)n * CI + ci) * H + iy) * W + ix;
+            float r = acc[ci][px];
+            if (accumulate) r += gx[o];
+            if (omask) r = omask[o] > 0.f ? r : 0.f;
+            gx[o] = r;
+        }
+}
+
 int conv_direct_fwd(const float* x, const float* mask, const float* wf, const float* bias, float* y, int n, int cin, int h,
                     int w, int cout, int oh, int ow, int kh, int kw, int stride, int pad, int relu, int accumulate,
                     hipStream_t stream) {
+    if (kh == 11 && kw == 11 && stride == 4 && pad == 0 && !mask && cout % 16 == 0) {
+        dim3 sgrid((unsigned)(((int64_t)oh * ow + 255) / 256), (unsigned)(cout / 16), (unsigned)n);
+        hipLaunchKernelGGL((conv_strided_fwd_kernel<11, 4, 16>), sgrid, dim3(256), 0, stream, x, wf, bias, y, cin, h, w, cout,
+                           oh, ow, relu, accumulate);
+        return check_launch("conv_strided_fwd_kernel");
+    }
     dim3 grid((unsigned)(((int64_t)oh * ow + 255) / 256), (unsigned)cout, (unsigned)n);
     hipLaunchKernelGGL(conv_direct_fwd_kernel, grid, dim3(256), 0, stream, x, mask, wf, bias, y, cin, h, w, cout, oh, ow,
                        kh, kw, stride, pad, relu, accumulate);
@@ -207,6 +328,13 @@ int conv_direct_fwd(const float* x, const float* mask, const float* wf, const fl
 int conv_direct_bwd(const float* gy, const float* mask, const float* w_oihw, const float* omask, float* gx, int n, int cin,
                     int h, int w, int cout, int oh, int ow, int kh, int kw, int stride, int pad, int accumulate,
                     hipStream_t stream) {
+    if (kh == 11 && kw == 11 && stride == 4 && pad == 0 && !mask && cin == 3) {
+        const int blocks_x = (w + 3) / 4;
+        dim3 sgrid((unsigned)((blocks_x + 255) / 256), (unsigned)h, (unsigned)n);
+        hipLaunchKernelGGL((conv_strided_bwd_kernel<11, 4, 3>), sgrid, dim3(256), 0, stream, gy, w_oihw, omask, gx, h, w, cout,
+                           oh, ow, accumulate);
+        return check_launch("conv_strided_bwd_kernel");
+    }
     dim3 grid((unsigned)(((int64_t)h * w + 255) / 256), (unsigned)cin, (unsigned)n);
     hipLaunchKernelGGL(conv_direct_bwd_kernel, grid, dim3(256), 0, stream, gy, mask, w_oihw, omask, gx, cin, h, w, cout,
                        oh, ow, kh, kw, stride, pad, accumulate);

@@ -47,6 +47,8 @@ CONV_CASES = [
     (96, 256, 15, 17, 5, 1, 2),
     (3, 96, 99, 99, 11, 4, 0),
     (3, 96, 128, 128, 11, 4, 0),
+    (3, 96, 203, 310, 11, 4, 0),     # strided stem kernels: width not a multiple of the stride, ragged last block
+    (3, 32, 75, 1030, 11, 4, 0),     # ... more than one 256-thread block per row in the backward pass
     (8, 16, 9, 9, 3, 1, 0),          # no padding
     (3, 64, 70, 200, 3, 1, 1),       # few-output-channel kernel (backward) over several 62-column tiles
     (64, 4, 21, 130, 3, 1, 1),       # ... forward direction, 4 channels
