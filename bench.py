@@ -107,6 +107,29 @@ def cpu_baseline(S_full, optimizer):
                       f"({S}^2/{S_full}^2) to {S_full}x{S_full}"}
 
 
+def pmc_traffic(prefix):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC pass (profiles/pmc_r01_traffic.json, written
+    by tools/pmc_summary.py from separate `rocprofv3 --pmc` runs of this same command).  Reads: request counters x 64 B,
+    doubled as MI355X_MICROARCH.md prescribes for gfx950 (our own calibration, profiles/pmc_r01_calibration.json: x2.0
+    for 16 B/lane streams, x1.2-1.6 for 4 B/lane patterns, so this is an upper bound); writes are exact."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_r01_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        kernels = json.load(f)["kernels"]
+    n = rd = wr = 0
+    for name, e in kernels.items():
+        if name.startswith(prefix) and "read_bytes_raw" in e:
+            n += e["launches_seen"]
+            rd += e["read_bytes_raw"] * e["launches_seen"]
+            wr += e["write_bytes_raw"] * e["launches_seen"]
+    if not n:
+        return None
+    return {"bytes": round((2 * rd + wr) / n),
+            "note": "per launch, from profiles/pmc_r01_traffic.json (separate rocprofv3 --pmc passes of this command): "
+                    "2 x TCC_EA0_RDREQ x 64 B (gfx950 correction, upper bound for 4 B/lane loads) + write requests"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,6 +213,7 @@ def main():
     dominant = "conv_x6" if x6 else "conv"  # with bf16x6 on, conv1_1 (3 channels) runs other kernels: not counted here
     conv = [(fl, e0.elapsed_time(e1)) for tag, fl, nb, e0, e1 in timer if tag.startswith(dominant)]
     roofline = None
+    pmc = pmc_traffic("maua::conv_x6_kernel<" if x6 else "maua::conv_mfma2_kernel<") if S == 1024 else None
     if conv:
         tot_fl, tot_ms = sum(c[0] for c in conv), sum(c[1] for c in conv)
         achieved = tot_fl / (tot_ms * 1e-3) / 1e12
@@ -209,7 +233,9 @@ def main():
                     "peak_note": ("algorithmic fp32-equivalent FLOPs; peak = 2500 TFLOP/s dense bf16 / 6 MFMAs per product block; "
                                   "hardware bf16 rate = achieved x 6.67 (6 MFMAs, 10 taps per 9)") if x6 else "fp32 MFMA peak",
                     "hw_bf16_tflops": round(achieved * 6 * 10 / 9, 1) if x6 else None,
-                    "traffic": None, "launches": len(conv), "avg_launch_ms": round(tot_ms / len(conv), 4),
+                    "traffic": pmc["bytes"] if pmc else None, "traffic_note": pmc["note"] if pmc else None,
+                    "algorithmic_bytes_per_launch": round(sum(nb for tag, fl, nb, e0, e1 in timer if tag.startswith(dominant)) / len(conv)),
+                    "launches": len(conv), "avg_launch_ms": round(tot_ms / len(conv), 4),
                     "flops_per_launch_avg": tot_fl / len(conv),
                     "per_kernel_ms_per_step": {k: round(v[1] / a.steps, 4) for k, v in by_tag.items()},
                     "per_kernel_tflops": {k: round(v[2] / (v[1] * 1e-3) / 1e12, 2) for k, v in by_tag.items() if v[1] > 0},
