@@ -110,7 +110,13 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
     const int in_plane = p.H * p.W;
     const int64_t out_plane = (int64_t)p.OH * p.OW;
     const float* __restrict__ xin = p.x + (int64_t)n * p.Cin * in_plane;
-    const int x0 = (blockIdx.x % p.tiles_x) * 32, y0 = (blockIdx.x / p.tiles_x) * X6_PH;
+    // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin by linear id, so XCD k takes the k-th contiguous
+    // band of tiles (row-major) and the halo rows / columns that neighbouring tiles share are hits in ITS L2
+    const int tiles_total = p.tiles_x * ((p.OH + X6_PH - 1) / X6_PH);
+    const int per_xcd = (tiles_total + 7) >> 3;
+    const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= tiles_total) return;  // grid.x is rounded up to a multiple of 8 (whole workgroup leaves: no barrier is skipped)
+    const int x0 = (tile % p.tiles_x) * 32, y0 = (tile / p.tiles_x) * X6_PH;
 
     // staging descriptor of this thread's patch position: a 32-bit byte offset inside a channel plane (clamped into the
     // image; positions in the zero padding are blanked when the chunk is written to LDS)
@@ -354,7 +360,7 @@ int conv_x6_launch(const ConvArgs& a, int n, hipStream_t stream) {
     const int64_t tiles = (int64_t)p.tiles_x * ((a.OH + X6_PH - 1) / X6_PH);
     int ks = a.ws ? x6_choose_split(a, n) : 1;
     p.ksplit = ks;
-    dim3 grid((unsigned)tiles, (unsigned)((a.Cout + X6_COT - 1) / X6_COT), (unsigned)(n * ks));
+    dim3 grid((unsigned)(((tiles + 7) / 8) * 8), (unsigned)((a.Cout + X6_COT - 1) / X6_COT), (unsigned)(n * ks));
     const bool tl = (a.Cin + 7) / 8 > 4, acc = ks == 1 && a.accumulate != 0, om = ks == 1 && a.omask != nullptr;
 #define MAUA_X6_LAUNCH(TL_, ACC_, OM_)                                                                      \
     do {                                                                                                    \
