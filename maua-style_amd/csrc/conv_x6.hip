@@ -99,6 +99,9 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
     // zero block behind the filters: A operand of the upper lane half in the fifth k-step (the ninth tap has no partner)
     for (int i = threadIdx.x * 4; i < ZERO_BYTES; i += 256 * 4) *reinterpret_cast<unsigned*>(Wl + X6_W_BYTES + i) = 0u;
 
+#ifdef MAUA_X6_STAMP
+    const unsigned long long st_enter = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, half = lane >> 5;
@@ -241,12 +244,15 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
     const int cps = (nchunks_all + ksplit - 1) / ksplit;        // chunks per split
     const int ch_begin = split * cps;
     const int nchunks = min(nchunks_all, ch_begin + cps);      // this workgroup covers chunks [ch_begin, nchunks)
+    dma_half(ch_begin, false);  // the filter DMA and the patch loads are in flight together: one memory latency, not two
+    dma_half(ch_begin, true);
     load_patch(ch_begin * 8);
     store_patch();
-    dma_half(ch_begin, false);
-    dma_half(ch_begin, true);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#ifdef MAUA_X6_STAMP  // diagnostic build only (tools/x6_clock.py): shader clock = d(s_memtime) / d(s_memrealtime) x 100 MHz
+    const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int ch = ch_begin; ch < nchunks; ++ch) {
         const bool more = ch + 1 < nchunks;
         if (more) load_patch((ch + 1) * 8);
@@ -281,6 +287,18 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
         }
     }
 
+#ifdef MAUA_X6_STAMP
+    if (p.ws && p.ksplit <= 1 && lane == 0) {  // the stamps go to a buffer nothing else reads
+        const unsigned long long st_c1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(p.ws) +
+                                 2 * (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x * 4 + blockIdx.x * 4 + wave);
+        st[0] = st_c1 - st_c0;
+        st[1] = st_r1 - st_r0;
+        st[2 * (size_t)gridDim.x * gridDim.y * gridDim.z * 4] = st_r0;      // absolute 100 MHz stamps: second / third planes
+        st[4 * (size_t)gridDim.x * gridDim.y * gridDim.z * 4] = st_r1;
+        st[2 * (size_t)gridDim.x * gridDim.y * gridDim.z * 4 + 1] = st_enter;
+    }
+#endif
     // epilogue: lane holds pixel column j of row y0+wave; register r is output channel (r&3)+8*(r>>2)+4*half of block t
     float* __restrict__ yout = p.y + (int64_t)n * p.Cout * out_plane;
     const float* __restrict__ om = p.omask ? p.omask + (int64_t)n * p.Cout * out_plane : nullptr;
@@ -298,33 +316,68 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
             }
         return;
     }
+    // One exec mask for the whole epilogue (lanes outside the image leave), per-lane base pointers computed once, and
+    // wave-uniform channel offsets: a store costs one 64-bit add, no multiplies, no branch.
+    if (pvalid) {
+        const bool full = co0 + X6_COT <= p.Cout;  // wave-uniform: every channel of the tile exists
+        const int64_t lane_off = (int64_t)(co0 + 4 * half) * out_plane + opix;
+        float* __restrict__ yl = yout + lane_off;
+        const float* __restrict__ oml = OM ? om + lane_off : nullptr;
+        const float* __restrict__ bl = p.bias ? p.bias + co0 + 4 * half : nullptr;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        // all loads of a 16-register block first (previous value, ReLU mask), then the stores: a load issued after a
-        // store to the same array would wait for it, turning the epilogue into 32 serial memory round trips
-        float prev[16], msk[16];
+        for (int t = 0; t < 2; ++t) {
+            // all loads of a 16-register block first (previous value, ReLU mask, bias), then the stores: a load issued
+            // after a store to the same array would wait for it, turning the epilogue into 32 serial memory round trips
+            float prev[16], msk[16], bv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int64_t o = (pvalid && co < p.Cout) ? (int64_t)co * out_plane + opix : 0;
-            // compile-time switches: with run-time flags hipcc branches around every load and waits for each one
-            prev[r] = 0.f;
-            msk[r] = 1.f;
-            if constexpr (ACC) prev[r] = yout[o];
-            if constexpr (OM) msk[r] = om[o];
-        }
+            for (int r = 0; r < 16; ++r) {
+                const int cr = t * 32 + (r & 3) + 8 * (r >> 2);  // compile-time channel offset inside the tile
+                const int64_t o = (full || co0 + cr + 4 * half < p.Cout) ? (int64_t)cr * out_plane : 0;
+                // compile-time switches: with run-time flags hipcc branches around every load and waits for each one
+                prev[r] = 0.f;
+                msk[r] = 1.f;
+                bv[r] = 0.f;
+                if constexpr (ACC) prev[r] = yl[o];
+                if constexpr (OM) msk[r] = oml[o];
+            }
+            if (bl) {  // one wave-uniform branch around the whole batch of loads (not one per element)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (pvalid && co < p.Cout) {
+                for (int r = 0; r < 16; ++r) {
+                    const int cr = t * 32 + (r & 3) + 8 * (r >> 2);
+                    bv[r] = bl[(full || co0 + cr + 4 * half < p.Cout) ? cr : 0];
+                }
+            }
+            float outv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
                 float v = TL ? master[t][r] : acc[t][r];
-                if (p.bias) v += p.bias[co];
+                v += bv[r];
                 v += prev[r];
                 if (p.relu) v = v > 0.f ? v : 0.f;
-                yout[(int64_t)co * out_plane + opix] = msk[r] > 0.f ? v : 0.f;
+                outv[r] = msk[r] > 0.f ? v : 0.f;
+            }
+            if (full) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yl[(int64_t)(t * 32 + (r & 3) + 8 * (r >> 2)) * out_plane] = outv[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cr = t * 32 + (r & 3) + 8 * (r >> 2);
+                    if (co0 + cr + 4 * half < p.Cout) yl[(int64_t)cr * out_plane] = outv[r];
+                }
             }
         }
     }
+#ifdef MAUA_X6_STAMP
+    if (p.ws && p.ksplit <= 1 && lane == 0) {
+        const unsigned long long st_issued = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(p.ws) +
+                                 2 * (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x * 4 + blockIdx.x * 4 + wave);
+        st[4 * (size_t)gridDim.x * gridDim.y * gridDim.z * 4 + 1] = st_issued;
+        st[6 * (size_t)gridDim.x * gridDim.y * gridDim.z * 4] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // out = act(bias + sum_split ws[split]) (+ out) masked: the fixed-order second stage of the split-K convolution
@@ -359,6 +412,9 @@ int conv_x6_launch(const ConvArgs& a, int n, hipStream_t stream) {
     p.tiles_x = (a.OW + 31) / 32;
     const int64_t tiles = (int64_t)p.tiles_x * ((a.OH + X6_PH - 1) / X6_PH);
     int ks = a.ws ? x6_choose_split(a, n) : 1;
+#ifdef MAUA_X6_STAMP
+    ks = 1;  // the workspace is the stamp buffer in the diagnostic build
+#endif
     p.ksplit = ks;
     dim3 grid((unsigned)(((tiles + 7) / 8) * 8), (unsigned)((a.Cout + X6_COT - 1) / X6_COT), (unsigned)(n * ks));
     const bool tl = (a.Cin + 7) / 8 > 4, acc = ks == 1 && a.accumulate != 0, om = ks == 1 && a.omask != nullptr;
@@ -453,6 +509,9 @@ int maua_conv3x3_x6(const float* x, const void* bank, const float* bias, const f
     a.accumulate = accumulate;
     // split-K only with a big enough workspace; without one the kernel still runs, just with fewer workgroups
     a.ws = (workspace && workspace_bytes >= maua_conv_x6_workspace_bytes(n, cin, h, w, cout, pad)) ? (float*)workspace : nullptr;
+#ifdef MAUA_X6_STAMP
+    a.ws = (float*)workspace;  // caller provides 64 B per workgroup
+#endif
     return conv_x6_launch(a, n, (hipStream_t)stream);
 }
 

@@ -60,8 +60,9 @@ _lib = None
 
 def lib():
     """Load libmaua_hip.so once; raise HipError when it is missing (no CPU path exists)."""
-    global _lib
+    global _lib, LIB_PATH
     if _lib is None:
+        LIB_PATH = os.environ.get("MAUA_HIP_LIB", LIB_PATH)  # developer knob: A/B another build of the same library
         if not os.path.exists(LIB_PATH):
             raise HipError(
                 f"{LIB_PATH} not found: build it with `python maua-style_amd/build_native.py` "
