@@ -147,22 +147,26 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
             rp[c] = *reinterpret_cast<const float*>(plane + p_byte);
         }
     };
-    auto store_patch = [&]() {
-        if (tid < X6_NPOS_PAD) {
-            // split pairs of values with the packed converts: the three u32 words of a pair come out ready to store
-            u32x4 vh, vm, vl;
+    // The split is pure VALU work on registers: it runs behind the chunk's last MFMAs (which keep the matrix pipe busy
+    // for ~400 cycles after they are issued); only the three LDS writes have to wait for the barrier that frees the patch.
+    u32x4 vh, vm, vl;
+    auto split_patch = [&]() {
+        // pairs of values with the packed converts: the three u32 words of a pair come out ready to store
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const bool ok0 = pos_ok && (C8 || rp_c0 + 2 * q < p.Cin), ok1 = pos_ok && (C8 || rp_c0 + 2 * q + 1 < p.Cin);
-                const float v0 = ok0 ? rp[2 * q] : 0.f, v1 = ok1 ? rp[2 * q + 1] : 0.f;
-                const unsigned H = cvt_pk_bf16(v0, v1);
-                const float r0 = v0 - __builtin_bit_cast(float, H << 16), r1 = v1 - __builtin_bit_cast(float, H & 0xffff0000u);
-                const unsigned M = cvt_pk_bf16(r0, r1);
-                const float s0 = r0 - __builtin_bit_cast(float, M << 16), s1 = r1 - __builtin_bit_cast(float, M & 0xffff0000u);
-                vh[q] = H;
-                vm[q] = M;
-                vl[q] = cvt_pk_bf16(s0, s1);
-            }
+        for (int q = 0; q < 4; ++q) {
+            const bool ok0 = pos_ok && (C8 || rp_c0 + 2 * q < p.Cin), ok1 = pos_ok && (C8 || rp_c0 + 2 * q + 1 < p.Cin);
+            const float v0 = ok0 ? rp[2 * q] : 0.f, v1 = ok1 ? rp[2 * q + 1] : 0.f;
+            const unsigned H = cvt_pk_bf16(v0, v1);
+            const float r0 = v0 - __builtin_bit_cast(float, H << 16), r1 = v1 - __builtin_bit_cast(float, H & 0xffff0000u);
+            const unsigned M = cvt_pk_bf16(r0, r1);
+            const float s0 = r0 - __builtin_bit_cast(float, M << 16), s1 = r1 - __builtin_bit_cast(float, M & 0xffff0000u);
+            vh[q] = H;
+            vm[q] = M;
+            vl[q] = cvt_pk_bf16(s0, s1);
+        }
+    };
+    auto write_patch = [&]() {
+        if (tid < X6_NPOS_PAD) {
             *reinterpret_cast<u32x4*>(Pl + (0 * X6_NPOS_PAD + tid) * 16) = vh;
             *reinterpret_cast<u32x4*>(Pl + (1 * X6_NPOS_PAD + tid) * 16) = vm;
             *reinterpret_cast<u32x4*>(Pl + (2 * X6_NPOS_PAD + tid) * 16) = vl;
@@ -203,14 +207,26 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
     // two-level accumulation (TL): fold the running sums into a master accumulator (plain fp32 VALU adds, round to
     // nearest) every FLUSH chunks so that no MFMA accumulation chain is longer than FLUSH*5*6 additions
     constexpr int FLUSH = 1;  // measured: 1 halves the pixel-gradient error of 4 (the bf16 MFMA adder truncates toward zero)
+    // The accumulators start from the bias (loaded here, behind the prologue's memory latency) instead of zero, so the
+    // epilogue has no dependent loads.  Split-K partial sums start from zero: the finish kernel adds the bias once.
     f32x16 acc[2], master[TL ? 2 : 1];
+    {
+        const bool with_bias = p.bias != nullptr && p.ksplit <= 1;  // wave-uniform
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            acc[t][r] = 0.f;
-            if constexpr (TL) master[t][r] = 0.f;
-        }
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float b0 = 0.f;
+                if (with_bias) b0 = p.bias[min(co, p.Cout - 1)];
+                if constexpr (TL) {
+                    master[t][r] = b0;
+                    acc[t][r] = 0.f;
+                } else {
+                    acc[t][r] = b0;
+                }
+            }
+    }
 
     auto kstep = [&](int s) {
         bf16x8 b[3], a[2][3];
@@ -236,7 +252,7 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
 
     // Pipeline (raw s_barrier + counted vmcnt, cdna_hip_programming.md "Pipelining across barriers"): the filter halves of
     // chunk c+1 stream in behind the k-steps of chunk c that no longer need the LDS region they overwrite.
-    //   chunk c:  [patch(c+1) global loads -> regs]  ks0 ks1 | X1 | DMA A(c+1) | ks2 ks3 ks4 | X2 | patch(c+1) -> LDS,
+    //   chunk c:  [patch(c+1) global loads -> regs]  ks0 ks1 | X1 | DMA A(c+1) | ks2 ks3 ks4, split patch(c+1) | X2 | patch(c+1) -> LDS,
     //             DMA B(c+1), wait A(c+1) | X3 | ... next chunk; B(c+1) is waited for just before the next X1.
     // vmcnt is in issue order: before X1 the queue is [B(c) x4 (old), patch loads x8 (young)] -> vmcnt(8) retires B(c);
     // before X3 it is [A(c+1) x3, B(c+1) x4] -> vmcnt(4) retires A(c+1) (the patch loads were consumed before).
@@ -247,25 +263,47 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
     dma_half(ch_begin, false);  // the filter DMA and the patch loads are in flight together: one memory latency, not two
     dma_half(ch_begin, true);
     load_patch(ch_begin * 8);
-    store_patch();
+    split_patch();
+    write_patch();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #ifdef MAUA_X6_STAMP  // diagnostic build only (tools/x6_clock.py): shader clock = d(s_memtime) / d(s_memrealtime) x 100 MHz
     const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long st_w[6] = {0, 0, 0, 0, 0, 0}, st_t;
+#define ST_BEGIN() st_t = __builtin_amdgcn_s_memtime()
+#define ST_END(i) st_w[i] += __builtin_amdgcn_s_memtime() - st_t
+#else
+#define ST_BEGIN()
+#define ST_END(i)
 #endif
+    // Issue priority rotates among the workgroups that share a CU (HW_ID.TG_ID tells them apart): with equal priorities
+    // the arbiter always prefers the same (oldest) wave of a SIMD, which then finishes ~20 % early and leaves the matrix
+    // pipe to fewer and fewer waves; measured on conv4_2 the last wave ended 139 us after the first.
+    const int tg_slot = (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 16 << 6 | 4) & 3);  // hwreg(HW_REG_HW_ID, 16, 4)
     for (int ch = ch_begin; ch < nchunks; ++ch) {
         const bool more = ch + 1 < nchunks;
+        switch ((tg_slot + ch) & 3) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
         if (more) load_patch((ch + 1) * 8);
         kstep(0);
         kstep(1);
         // B(ch) must have landed (all waves) before k-step 2; A(ch)'s readers are done after this barrier
+        ST_BEGIN();
         if (more) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        ST_END(0);
+        ST_BEGIN();
         __builtin_amdgcn_s_barrier();
+        ST_END(1);
         if (more) dma_half(ch + 1, false);
         kstep(2);
         kstep(3);
         kstep(4);
+        if (more) split_patch();
         if constexpr (TL) {
             if (((ch - ch_begin) & (FLUSH - 1)) == FLUSH - 1 || !more) {
 #pragma unroll
@@ -277,13 +315,21 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
                     }
             }
         }
+        ST_BEGIN();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // X2: every wave is done reading the patch and half B
+        ST_END(2);
         if (more) {
-            store_patch();
+            ST_BEGIN();
+            write_patch();
             dma_half(ch + 1, true);
+            ST_END(3);
+            ST_BEGIN();
             asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");  // A(ch+1) landed, patch writes done
+            ST_END(4);
+            ST_BEGIN();
             __builtin_amdgcn_s_barrier();  // X3
+            ST_END(5);
         }
     }
 
@@ -297,6 +343,7 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
         st[2 * (size_t)gridDim.x * gridDim.y * gridDim.z * 4] = st_r0;      // absolute 100 MHz stamps: second / third planes
         st[4 * (size_t)gridDim.x * gridDim.y * gridDim.z * 4] = st_r1;
         st[2 * (size_t)gridDim.x * gridDim.y * gridDim.z * 4 + 1] = st_enter;
+        for (int i = 0; i < 6; ++i) st[2 * (4 + i) * (size_t)gridDim.x * gridDim.y * gridDim.z * 4] = st_w[i];
     }
 #endif
     // epilogue: lane holds pixel column j of row y0+wave; register r is output channel (r&3)+8*(r>>2)+4*half of block t
@@ -323,12 +370,11 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
         const int64_t lane_off = (int64_t)(co0 + 4 * half) * out_plane + opix;
         float* __restrict__ yl = yout + lane_off;
         const float* __restrict__ oml = OM ? om + lane_off : nullptr;
-        const float* __restrict__ bl = p.bias ? p.bias + co0 + 4 * half : nullptr;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            // all loads of a 16-register block first (previous value, ReLU mask, bias), then the stores: a load issued
+            // all loads of a 16-register block first (previous value, ReLU mask), then the stores: a load issued
             // after a store to the same array would wait for it, turning the epilogue into 32 serial memory round trips
-            float prev[16], msk[16], bv[16];
+            float prev[16], msk[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int cr = t * 32 + (r & 3) + 8 * (r >> 2);  // compile-time channel offset inside the tile
@@ -336,22 +382,13 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
                 // compile-time switches: with run-time flags hipcc branches around every load and waits for each one
                 prev[r] = 0.f;
                 msk[r] = 1.f;
-                bv[r] = 0.f;
                 if constexpr (ACC) prev[r] = yl[o];
                 if constexpr (OM) msk[r] = oml[o];
-            }
-            if (bl) {  // one wave-uniform branch around the whole batch of loads (not one per element)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int cr = t * 32 + (r & 3) + 8 * (r >> 2);
-                    bv[r] = bl[(full || co0 + cr + 4 * half < p.Cout) ? cr : 0];
-                }
             }
             float outv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = TL ? master[t][r] : acc[t][r];
-                v += bv[r];
                 v += prev[r];
                 if (p.relu) v = v > 0.f ? v : 0.f;
                 outv[r] = msk[r] > 0.f ? v : 0.f;

@@ -35,7 +35,7 @@ assert L.maua_conv_pack_filters_x6(vp(w.data_ptr()), vp(bank.data_ptr()), None, 
 y = torch.empty(1, cout, H, H, device="cuda")
 tiles = ((H + 31) // 32) * ((H + 3) // 4)
 nwg = ((tiles + 7) // 8 * 8) * ((cout + 63) // 64)
-stamps = torch.zeros(nwg * 4 * 2 * 4, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(nwg * 4 * 2 * 10, dtype=torch.int64, device="cuda")
 
 
 def launch():
@@ -60,7 +60,7 @@ for _ in range(20):
 e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / 20
-allp = stamps.view(4, -1, 2).cpu()
+allp = stamps.view(10, -1, 2).cpu()
 s = allp[0]
 live = s[:, 1] > 0
 r0, r1 = allp[1][:, 0][live].double(), allp[2][:, 0][live].double()
@@ -82,3 +82,11 @@ enter, issued, done = allp[1][:, 1][live].double(), allp[2][:, 1][live].double()
 print(f"  per wave (median, us): entry -> loop start {((r0 - enter).median()) / 100:.2f}; loop {((r1 - r0).median()) / 100:.2f}; "
       f"loop end -> stores issued {((issued - r1).median()) / 100:.2f}; stores issued -> landed {((done - issued).median()) / 100:.2f}; "
       f"residency {((done - enter).median()) / 100:.2f}")
+names = ["wait B landed (vmcnt) before X1", "barrier X1", "lgkmcnt + barrier X2", "store_patch + DMA issue", "wait A landed (vmcnt)", "barrier X3"]
+tot = cyc.median()
+acc = 0.0
+for i, nm in enumerate(names):
+    v = allp[4 + i][:, 0][live].double().median()
+    acc += v
+    print(f"  in-loop {nm}: median {v:.0f} cycles = {v / tot * 100:.1f} % of the loop ({v / nchunks:.0f} per chunk)")
+print(f"  sum of the stamped waits {acc / tot * 100:.1f} % of the loop")
