@@ -10,6 +10,7 @@ torch.optim.LBFGS's four host round trips per iteration are gone.  The loss is r
 `--print_iter` fires.
 """
 import json
+import os
 import sys
 
 import torch as th
@@ -129,13 +130,17 @@ class PixelOptimizer:
             self.m, self.v = th.zeros_like(self.x), th.zeros_like(self.x)
         else:
             raise ValueError(f"unknown optimizer {self.kind}")
-        self.use_graph = bool(getattr(args, "hip_graph", False))
+        # The whole iteration (25+ convolutions, Grams, losses, the optimiser sweeps: ~120 launches, every scalar on the
+        # device) is replayed from one captured hipGraph.  MAUA_HIP_GRAPH=0 or an attached engine timer runs it eagerly.
+        hg = getattr(args, "hip_graph", None)
+        self.use_graph = (os.environ.get("MAUA_HIP_GRAPH", "1") != "0") if hg is None else bool(hg)
+        self._graph = None
 
     def feval(self):
         """(loss slots, total, gradient) at the current image - device tensors, no sync."""
         if self.engine is not None:
             try:
-                return self.engine.feval(self.x, capture=self.use_graph)
+                return self.engine.feval(self.x, capture=self.use_graph and self.kind != "lbfgs" and self.engine.timer is None)
             except engine_mod.UnsupportedNet:
                 self.engine = None
         return self._feval_modules()
@@ -157,8 +162,31 @@ class PixelOptimizer:
             mod.loss = 0
         return slots, total.detach().reshape(1), x.grad.contiguous()
 
+    def _step_lbfgs_graph(self):
+        """feval + L-BFGS update as one graph replay; the first call runs eagerly (a real iteration) and captures."""
+        if self._graph is not None:
+            self._graph.replay()
+            self.step_count += 1
+            return self.engine.slots, self.engine.total
+        a = self.args
+        slots, total, grad = self.engine.feval(self.x)
+        self.state.iterate(self.x, grad, 1.0, float(a.lbfgs_tolerance_change))
+        self.step_count += 1
+        th.cuda.synchronize()
+        graph = th.cuda.CUDAGraph()
+        with th.cuda.graph(graph):
+            self.engine._run(self.x)
+            self.state.iterate(self.x, self.engine.gbuf[0], 1.0, float(a.lbfgs_tolerance_change))
+        self._graph = graph
+        return slots, total
+
     def step(self):
         """One iteration: evaluate, then move."""
+        if self.use_graph and self.kind == "lbfgs" and self.engine is not None and self.engine.timer is None:
+            try:
+                return self._step_lbfgs_graph()
+            except engine_mod.UnsupportedNet:
+                self.engine = None
         slots, total, grad = self.feval()
         self.step_count += 1
         a = self.args

@@ -159,6 +159,19 @@ def test_hip_graph_replay_equals_eager(weight_files):
     assert torch.equal(ga, gb)
 
 
+@pytest.mark.parametrize("opt", ["lbfgs", "adam"])
+def test_whole_iteration_graph_equals_eager(weight_files, opt, monkeypatch):
+    """The product replays each iteration from a hipGraph; the same kernels launched eagerly give the same bits."""
+    import optim
+    content, style, init = synth.images(64)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MAUA_HIP_GRAPH", flag)
+        args = product_args(weight_files, optimizer=opt, S=64, N=12)
+        outs.append(optim.optimize(content, [style], init.clone(), 12, args))
+    assert torch.equal(outs[0], outs[1])
+
+
 # ---------------------------------------------------------------------------------------------------------
 TRAJ = [("lbfgs", n) for n in (1, 2, 3, 4, 5, 10, 20)] + [("adam", n) for n in (1, 5, 10, 20)]
 
