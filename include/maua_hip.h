@@ -55,19 +55,24 @@ int maua_conv_pack_filters(const float* w_oihw, float* wf, float* wb, int cout, 
  *  wf: forward bank from maua_conv_pack_filters.  in_mask (nullable, same shape as x): x is read as
  *  x * (in_mask > 0) - the fused threshold_backward of the ReLU in front of a backward-data pass.
  *  bias nullable.  relu: 0/1.  accumulate: 0/1 (add into y instead of overwriting).
- *  stride 1 with k in {1,3,5} runs on the fp32 MFMA path; other geometry on the direct path. */
+ *  stride 1 with k in {1,3,5} runs on the fp32 MFMA path; other geometry on the direct path.
+ *  workspace (nullable): maua_conv_workspace_bytes(...) bytes let layers whose output grid cannot fill the chip (deep
+ *  1x1 layers on small maps) split the channel loop over workgroups; the partial sums are added in a fixed order. */
+size_t maua_conv_workspace_bytes(int n, int cin, int h, int w, int cout, int kh, int kw, int stride, int pad);
 int maua_conv2d_fwd(const float* x, const float* in_mask, const float* wf, const float* bias, float* y, int n, int cin,
-                    int h, int w, int cout, int kh, int kw, int stride, int pad, int relu, int accumulate,
-                    maua_stream_t stream);
+                    int h, int w, int cout, int kh, int kw, int stride, int pad, int relu, int accumulate, void* workspace,
+                    size_t workspace_bytes, maua_stream_t stream);
 
 /* gx = conv_transpose(gy * (out_mask > 0), w): gradient w.r.t. the conv input.  gy/out_mask: [n][cout][oh][ow] (mask
  * nullable, it is the saved ReLU output of this conv), gx: [n][cin][h][w].  wb: backward bank (stride 1) or the OIHW
  * weights themselves (stride > 1, direct path: pass w_oihw and wb = NULL).  in_relu_mask (nullable, shape of gx): the
  * result is zeroed where it is <= 0 - the threshold_backward of the ReLU that produced this conv's INPUT, applied by the
- * producer of the gradient so that the next backward pass needs no mask while staging. */
+ * producer of the gradient so that the next backward pass needs no mask while staging.
+ * workspace (nullable): maua_conv_workspace_bytes(n, cout, oh, ow, cin, kh, kw, 1, k-1-pad) bytes (the same pass seen as
+ * a forward convolution over the gradient). */
 int maua_conv2d_bwd_data(const float* gy, const float* out_mask, const float* wb, const float* w_oihw,
                          const float* in_relu_mask, float* gx, int n, int cin, int h, int w, int cout, int kh, int kw,
-                         int stride, int pad, int accumulate, maua_stream_t stream);
+                         int stride, int pad, int accumulate, void* workspace, size_t workspace_bytes, maua_stream_t stream);
 
 /* ---- 3x3 stride-1 convolution at fp32 accuracy on the bf16 matrix cores (three-way bf16 split of both operands, six
  *      MFMAs per product block; conv_x6.hip).  Same math as maua_conv2d_fwd / maua_conv2d_bwd_data for k = 3, s = 1. ---- */

@@ -75,7 +75,9 @@ struct ConvArgs {
     float* ws;           // [n][ksplit][Cout][OH][OW] partial sums (split-K only)
 };
 int conv_mfma_dispatch(const ConvArgs& a, int ks, int n, hipStream_t stream);
-int conv3x3_few_out(const ConvArgs& a, int n, hipStream_t stream);  // 3x3, stride 1, Cout <= 4 (conv_direct.hip)
+int conv3x3_few_out(const ConvArgs& a, int n, hipStream_t stream);
+int conv_splitk_finish(const ConvArgs& a, int n, int ksplit, hipStream_t stream);  // y = act(bias + sum of a.ws partials) ...
+int conv_mfma2_choose_split(const ConvArgs& a, int ks, int n);                     // 1 = no split  // 3x3, stride 1, Cout <= 4 (conv_direct.hip)
 int conv_mfma2_dispatch(const ConvArgs& a, int ks, int n, hipStream_t stream);
 int conv_direct_fwd(const float* x, const float* mask, const float* wf, const float* bias, float* y, int n, int cin, int h,
                     int w, int cout, int oh, int ow, int kh, int kw, int stride, int pad, int relu, int accumulate,

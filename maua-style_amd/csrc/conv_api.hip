@@ -17,9 +17,22 @@ static int conv_route(const ConvArgs& a, int ks, int n, hipStream_t stream) {
 
 extern "C" {
 
+size_t maua_conv_workspace_bytes(int n, int cin, int h, int w, int cout, int kh, int kw, int stride, int pad) {
+    if (n <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0) return 0;
+    if (!mfma_geometry(kh, kw, stride) || h + 2 * pad < kh || w + 2 * pad < kw) return 0;
+    ConvArgs a{};
+    a.Cin = cin;
+    a.Cout = cout;
+    a.OH = h + 2 * pad - kh + 1;
+    a.OW = w + 2 * pad - kw + 1;
+    if (kh == 3 && cout <= 4 && cin >= 16) return 0;  // few-output-channel kernel: no split
+    const int ks = conv_mfma2_choose_split(a, kh, n);
+    return ks > 1 ? (size_t)n * ks * cout * a.OH * a.OW * sizeof(float) : 0;
+}
+
 int maua_conv2d_fwd(const float* x, const float* in_mask, const float* wf, const float* bias, float* y, int n, int cin,
-                    int h, int w, int cout, int kh, int kw, int stride, int pad, int relu, int accumulate,
-                    maua_stream_t stream) {
+                    int h, int w, int cout, int kh, int kw, int stride, int pad, int relu, int accumulate, void* workspace,
+                    size_t workspace_bytes, maua_stream_t stream) {
     MAUA_REQUIRE(x && wf && y, MAUA_E_INVAL, "conv2d_fwd: null pointer");
     MAUA_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0, MAUA_E_INVAL,
                  "conv2d_fwd: bad dims n=%d cin=%d cout=%d h=%d w=%d k=%dx%d s=%d p=%d", n, cin, cout, h, w, kh, kw, stride,
@@ -45,6 +58,8 @@ int maua_conv2d_fwd(const float* x, const float* in_mask, const float* wf, const
         a.pad = pad;
         a.relu = relu;
         a.accumulate = accumulate;
+        a.ws = (workspace && workspace_bytes >= maua_conv_workspace_bytes(n, cin, h, w, cout, kh, kw, stride, pad))
+                   ? (float*)workspace : nullptr;
         return conv_route(a, kh, n, (hipStream_t)stream);
     }
     return conv_direct_fwd(x, in_mask, wf, bias, y, n, cin, h, w, cout, oh, ow, kh, kw, stride, pad, relu, accumulate,
@@ -53,7 +68,7 @@ int maua_conv2d_fwd(const float* x, const float* in_mask, const float* wf, const
 
 int maua_conv2d_bwd_data(const float* gy, const float* out_mask, const float* wb, const float* w_oihw,
                          const float* in_relu_mask, float* gx, int n, int cin, int h, int w, int cout, int kh, int kw,
-                         int stride, int pad, int accumulate, maua_stream_t stream) {
+                         int stride, int pad, int accumulate, void* workspace, size_t workspace_bytes, maua_stream_t stream) {
     MAUA_REQUIRE(gy && gx && (wb || w_oihw), MAUA_E_INVAL, "conv2d_bwd_data: null pointer");
     MAUA_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0, MAUA_E_INVAL,
                  "conv2d_bwd_data: bad dims");
@@ -78,6 +93,9 @@ int maua_conv2d_bwd_data(const float* gy, const float* out_mask, const float* wb
         a.relu = 0;
         a.accumulate = accumulate;
         MAUA_REQUIRE(a.pad >= 0, MAUA_E_UNSUPPORTED, "conv2d_bwd_data: pad %d > k-1", pad);
+        // backward-data = forward geometry with the channel roles exchanged on the gradient's plane
+        a.ws = (workspace && workspace_bytes >= maua_conv_workspace_bytes(n, cout, oh, ow, cin, kh, kw, 1, a.pad))
+                   ? (float*)workspace : nullptr;
         return conv_route(a, kh, n, (hipStream_t)stream);
     }
     MAUA_REQUIRE(w_oihw, MAUA_E_INVAL, "conv2d_bwd_data: the direct path needs the OIHW weights");

@@ -180,6 +180,32 @@ conv3x3_few_out_kernel(ConvArgs p, const float* __restrict__ wbank) {
     }
 }
 
+// out = act(bias + sum_split ws[split]) (+ out) masked: the fixed-order second stage of the split-K convolution
+__global__ void conv_splitk_finish_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
+                                        const float* __restrict__ omask, float* __restrict__ y, int ksplit, int Cout,
+                                        int64_t out_plane, int64_t total, int relu, int accumulate) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t per_n = (int64_t)Cout * out_plane;
+        const int64_t n = e / per_n, r = e - n * per_n;
+        float v = 0.f;
+        for (int k = 0; k < ksplit; ++k) v += ws[(n * ksplit + k) * per_n + r];
+        if (bias) v += bias[r / out_plane];
+        if (accumulate) v += y[e];
+        if (relu) v = v > 0.f ? v : 0.f;
+        if (omask) v = omask[e] > 0.f ? v : 0.f;
+        y[e] = v;
+    }
+}
+
+int conv_splitk_finish(const ConvArgs& a, int n, int ksplit, hipStream_t stream) {
+    const int64_t out_plane = (int64_t)a.OH * a.OW, total = (int64_t)n * a.Cout * out_plane;
+    int fb = (int)((total + 255) / 256);
+    if (fb > 4096) fb = 4096;
+    hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(fb), dim3(256), 0, stream, a.ws, a.bias, a.omask, a.y, ksplit, a.Cout,
+                       out_plane, total, a.relu, a.accumulate);
+    return check_launch("conv_splitk_finish_kernel");
+}
+
 int conv3x3_few_out(const ConvArgs& a, int n, hipStream_t stream) {
     dim3 grid((unsigned)((a.OW + FO_TW - 1) / FO_TW), (unsigned)((a.OH + 4 * FO_R - 1) / (4 * FO_R)), (unsigned)n);
 #define MAUA_FO(CO_)                                                                                            \

@@ -41,7 +41,9 @@ __global__ void __launch_bounds__(256, 2) conv_mfma2_kernel(ConvArgs p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, half = lane >> 5;
-    const int n = blockIdx.z;
+    const int ksplit = p.ksplit > 1 ? p.ksplit : 1;  // split-K: blockIdx.z = n * ksplit + split (see conv_x6.hip)
+    const int n = __builtin_amdgcn_readfirstlane(blockIdx.z / ksplit);  // the division runs on the vector ALU
+    const int split = blockIdx.z - n * ksplit;
     const int co0 = blockIdx.y * CO_T;
     const int in_plane = p.H * p.W;
     const int64_t out_plane = (int64_t)p.OH * p.OW;
@@ -86,7 +88,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma2_kernel(ConvArgs p) {
 
     f32x4 rp[NPI], rw[NWI];
     auto load_patch = [&](int c0) {
-        asm volatile("" : "+s"(c0));  // keep the addresses a function of c0: no per-load running pointers across chunks
+        c0 = __builtin_amdgcn_readfirstlane(c0);  // opaque + scalar: addresses stay a function of c0, no per-load running pointers
 #pragma unroll
         for (int i = 0; i < NPI; ++i) {
             const int h = (tid + 256 * i) / NPOS_PAD;
@@ -104,7 +106,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma2_kernel(ConvArgs p) {
     };
     constexpr int NWA = (NWI + 1) / 2;  // filter items staged in the first of two phases
     auto load_filters = [&](int c0, int lo, int hi) {
-        asm volatile("" : "+s"(c0));
+        c0 = __builtin_amdgcn_readfirstlane(c0);
 #pragma unroll
         for (int i = 0; i < NWI; ++i) {
             if (i < lo || i >= hi) continue;
@@ -171,13 +173,16 @@ __global__ void __launch_bounds__(256, 2) conv_mfma2_kernel(ConvArgs p) {
     // of the filter loads; the rest -> LDS after the last tap.  The other LDS buffer is free for the whole chunk (its
     // readers finished before the barrier).
     constexpr int P1 = KS == 1 ? 99 : (KS * KS) / 3, P2 = KS == 1 ? 99 : (2 * KS * KS) / 3;
-    const int nchunks = (p.Cin + KC - 1) / KC;
-    load_patch(0);
-    store_patch(0);
-    load_filters(0, 0, NWI);
-    store_filters(0, 0, NWI);
+    const int nchunks_all = (p.Cin + KC - 1) / KC;
+    const int cps = __builtin_amdgcn_readfirstlane((nchunks_all + ksplit - 1) / ksplit);
+    const int ch_begin = split * cps;
+    const int nchunks = min(nchunks_all, ch_begin + cps);  // this workgroup covers chunks [ch_begin, nchunks)
+    load_patch(ch_begin * KC);
+    store_patch(ch_begin & 1);
+    load_filters(ch_begin * KC, 0, NWI);
+    store_filters(ch_begin & 1, 0, NWI);
     __syncthreads();
-    for (int ch = 0; ch < nchunks; ++ch) {
+    for (int ch = ch_begin; ch < nchunks; ++ch) {
         const int cur = ch & 1;
         const bool more = ch + 1 < nchunks;
         const float* xl = smem + cur * BUF;
@@ -216,7 +221,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma2_kernel(ConvArgs p) {
                         acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][t][cp], fb[cb][u][cp], acc[t][u], 0, 0, 0);
         }
         if constexpr (TL) {
-            if ((ch & (FLUSH - 1)) == FLUSH - 1 || ch + 1 == nchunks) {
+            if (((ch - ch_begin) & (FLUSH - 1)) == FLUSH - 1 || ch + 1 == nchunks) {
 #pragma unroll
                 for (int t = 0; t < TCO; ++t)
 #pragma unroll
@@ -254,6 +259,17 @@ __global__ void __launch_bounds__(256, 2) conv_mfma2_kernel(ConvArgs p) {
             const int oy = y0 + wave * TPX + u, ox = x0 + j;
             pvalid = oy < p.OH && ox < p.OW;
             opix = (int64_t)oy * p.OW + ox;
+        }
+        if (p.ksplit > 1) {  // raw partial sums; conv_splitk_finish_kernel adds them in split order
+            float* wsp = p.ws + (int64_t)blockIdx.z * p.Cout * out_plane;
+#pragma unroll
+            for (int t = 0; t < TCO; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (pvalid && co < p.Cout) wsp[(int64_t)co * out_plane + opix] = TL ? master[t][u][r] : acc[t][u][r];
+                }
+            continue;
         }
 #pragma unroll
         for (int t = 0; t < TCO; ++t) {
@@ -297,7 +313,8 @@ static int launch2e(const ConvArgs& a, int n, hipStream_t stream) {
         p.tiles_x = (a.OW + 31) / 32;
         tiles = (int64_t)p.tiles_x * ((a.OH + PH - 1) / PH);
     }
-    dim3 grid((unsigned)tiles, (unsigned)((a.Cout + CO_T - 1) / CO_T), (unsigned)n);
+    const int ks = a.ksplit > 1 ? a.ksplit : 1;
+    dim3 grid((unsigned)tiles, (unsigned)((a.Cout + CO_T - 1) / CO_T), (unsigned)(n * ks));
     static bool attr_done = false;
     if (!attr_done && lds > 64 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma2_kernel<KS, TCO, TPX, TL, MASK, ACC, OM>),
@@ -305,12 +322,15 @@ static int launch2e(const ConvArgs& a, int n, hipStream_t stream) {
         attr_done = true;
     }
     hipLaunchKernelGGL((conv_mfma2_kernel<KS, TCO, TPX, TL, MASK, ACC, OM>), grid, dim3(256), lds, stream, p);
-    return check_launch("conv_mfma2_kernel");
+    int rc = check_launch("conv_mfma2_kernel");
+    if (rc || ks == 1) return rc;
+    return conv_splitk_finish(a, n, ks, stream);
 }
 
 template <int KS, int TCO, int TPX, bool TL, bool MASK>
 static int launch2(const ConvArgs& a, int n, hipStream_t stream) {
-    const bool acc = a.accumulate != 0, om = a.omask != nullptr;
+    const bool split = a.ksplit > 1;  // the finish kernel applies accumulate / mask / bias / ReLU
+    const bool acc = !split && a.accumulate != 0, om = !split && a.omask != nullptr;
     if (acc && om) return launch2e<KS, TCO, TPX, TL, MASK, true, true>(a, n, stream);
     if (acc) return launch2e<KS, TCO, TPX, TL, MASK, true, false>(a, n, stream);
     if (om) return launch2e<KS, TCO, TPX, TL, MASK, false, true>(a, n, stream);
@@ -325,7 +345,22 @@ static int launch2_variant(const ConvArgs& a, int n, hipStream_t stream) {
     return tl ? launch2<KS, TCO, TPX, true, false>(a, n, stream) : launch2<KS, TCO, TPX, false, false>(a, n, stream);
 }
 
-int conv_mfma2_dispatch(const ConvArgs& a, int ks, int n, hipStream_t stream) {
+// Split the channel loop when the output grid is far too small for 256 CUs (deep 1x1 layers on 31x31 maps ...).
+int conv_mfma2_choose_split(const ConvArgs& a, int ks, int n) {
+    if (ks != 1 && ks != 3 && ks != 5) return 1;
+    const int64_t opix = (int64_t)a.OH * a.OW;
+    const int64_t tiles = (ks == 1) ? (opix + 127) / 128 : (int64_t)((a.OW + 31) / 32) * ((a.OH + 3) / 4);
+    const int64_t wgs = tiles * ((a.Cout + 63) / 64) * n;
+    const int nchunks = (a.Cin + 7) / 8;
+    if (wgs >= 384 || nchunks < 16) return 1;
+    int s = (int)((768 + wgs - 1) / wgs);
+    if (s > nchunks / 8) s = nchunks / 8;  // at least 8 chunks per workgroup
+    return s < 2 ? 1 : s;
+}
+
+int conv_mfma2_dispatch(const ConvArgs& a0, int ks, int n, hipStream_t stream) {
+    ConvArgs a = a0;
+    a.ksplit = a.ws ? conv_mfma2_choose_split(a, ks, n) : 1;
     const int64_t opix = (int64_t)a.OH * a.OW;
     const int64_t co_tiles = (a.Cout + 63) / 64;
     const int64_t big_tiles = (ks == 1) ? (opix + 255) / 256 : (int64_t)((a.OW + 31) / 32) * ((a.OH + 7) / 8);
@@ -338,8 +373,8 @@ int conv_mfma2_dispatch(const ConvArgs& a, int ks, int n, hipStream_t stream) {
         case 3:
             if (narrow_co) return launch2_variant<3, 1, 2>(a, n, stream);
             return small_rows ? launch2_variant<3, 2, 1>(a, n, stream) : launch2_variant<3, 2, 2>(a, n, stream);
-        case 5:
-            return launch2_variant<5, 2, 2>(a, n, stream);
+        case 5:  // 25 taps x 64 channels of filters would leave one workgroup per CU: 32-channel tiles keep two
+            return launch2_variant<5, 1, 2>(a, n, stream);
         default:
             set_error("conv_mfma2: kernel size %d not instantiated", ks);
             return MAUA_E_UNSUPPORTED;

@@ -417,23 +417,6 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
 #endif
 }
 
-// out = act(bias + sum_split ws[split]) (+ out) masked: the fixed-order second stage of the split-K convolution
-__global__ void x6_splitk_finish_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
-                                        const float* __restrict__ omask, float* __restrict__ y, int ksplit, int Cout,
-                                        int64_t out_plane, int64_t total, int relu, int accumulate) {
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t per_n = (int64_t)Cout * out_plane;
-        const int64_t n = e / per_n, r = e - n * per_n;
-        float v = 0.f;
-        for (int k = 0; k < ksplit; ++k) v += ws[(n * ksplit + k) * per_n + r];
-        if (bias) v += bias[r / out_plane];
-        if (accumulate) v += y[e];
-        if (relu) v = v > 0.f ? v : 0.f;
-        if (omask) v = omask[e] > 0.f ? v : 0.f;
-        y[e] = v;
-    }
-}
-
 // split the K loop over several workgroups when the output grid alone cannot fill the chip (4 workgroups per CU)
 static int x6_choose_split(const ConvArgs& a, int n) {
     const int64_t wgs = (int64_t)((a.OW + 31) / 32) * ((a.OH + X6_PH - 1) / X6_PH) * ((a.Cout + X6_COT - 1) / X6_COT) * n;
@@ -474,12 +457,7 @@ int conv_x6_launch(const ConvArgs& a, int n, hipStream_t stream) {
 #undef MAUA_X6_LAUNCH
     int rc = check_launch("conv_x6_kernel");
     if (rc || ks == 1) return rc;
-    const int64_t out_plane = (int64_t)a.OH * a.OW, total = (int64_t)n * a.Cout * out_plane;
-    int fb = (int)((total + 255) / 256);
-    if (fb > 4096) fb = 4096;
-    hipLaunchKernelGGL(x6_splitk_finish_kernel, dim3(fb), dim3(256), 0, stream, a.ws, a.bias, a.omask, a.y, ks, a.Cout, out_plane,
-                       total, a.relu, a.accumulate);
-    return check_launch("x6_splitk_finish_kernel");
+    return conv_splitk_finish(a, n, ks, stream);
 }
 
 }  // namespace maua

@@ -166,14 +166,17 @@ gram_finish_kernel(const float* __restrict__ partial, float* __restrict__ gram, 
     }
 }
 
-// bias[c] = - sum_k D[k][c] * mean[k]   (the centering term of gf = D (F - mean 1^T))
-__global__ void center_bias_kernel(const float* __restrict__ d, const float* __restrict__ mean, float* __restrict__ bias,
-                                   int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// bias[c] = - sum_k D[k][c] * mean[k]   (the centering term of gf = D (F - mean 1^T)).  D is symmetric, so row c is
+// read instead of column c: one wave per output, coalesced loads, fixed-order wave reduction.
+__global__ void __launch_bounds__(256) center_bias_kernel(const float* __restrict__ d, const float* __restrict__ mean,
+                                                          float* __restrict__ bias, int C) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
+    const float* row = d + (int64_t)c * C;
     float s = 0.f;
-    for (int k = 0; k < C; ++k) s = fmaf(d[(int64_t)k * C + c], mean[k], s);
-    bias[c] = -s;
+    for (int k = lane; k < C; k += 64) s = fmaf(row[k], mean[k], s);
+    s = wave_sum(s);
+    if (lane == 0) bias[c] = -s;
 }
 
 // Gram backward gf[c][p] (+)= sum_k D[k][c] * (F[k][p] - mean[k]), masked by relu_mask.  Bandwidth-bound for the
@@ -368,7 +371,7 @@ int maua_gram_bwd(const float* d_sym, const float* f, const float* row_mean, con
         MAUA_REQUIRE(workspace && workspace_bytes >= (size_t)c * sizeof(float), MAUA_E_WORKSPACE,
                      "gram_bwd: workspace too small for the centering bias");
         bias = (float*)workspace;
-        hipLaunchKernelGGL(center_bias_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_sym, row_mean,
+        hipLaunchKernelGGL(center_bias_kernel, dim3((c + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_sym, row_mean,
                            bias, c);
         int rc = check_launch("center_bias_kernel");
         if (rc) return rc;

@@ -140,11 +140,14 @@ class StyleEngine:
                 self.mean[id(s)] = torch.empty(c, device=dev) if s.mod.use_covariance else None
                 ws = max(ws, hip.gram_workspace_bytes(c, hw), 4 * c + 256)
         for s in self.steps:  # split-K workspaces of the bf16x6 convs (forward and backward-data geometry)
-            if s.kind == "conv" and s.k == 3 and s.stride == 1:
+            if s.kind == "conv" and s.stride == 1:
                 n, cin, h, w = shapes[s.src]
                 _, cout, oh, ow = shapes[s.dst]
-                ws = max(ws, hip.conv_x6_workspace_bytes(n, cin, h, w, cout, s.pad),
-                         hip.conv_x6_workspace_bytes(n, cout, oh, ow, cin, 2 - s.pad))
+                ws = max(ws, hip.conv_workspace_bytes(n, cin, h, w, cout, s.k, 1, s.pad),
+                         hip.conv_workspace_bytes(n, cout, oh, ow, cin, s.k, 1, s.k - 1 - s.pad))
+                if s.k == 3:
+                    ws = max(ws, hip.conv_x6_workspace_bytes(n, cin, h, w, cout, s.pad),
+                             hip.conv_x6_workspace_bytes(n, cout, oh, ow, cin, 2 - s.pad))
         self.ws = torch.empty(ws, dtype=torch.uint8, device=dev)
         self.x_static = torch.empty(self.shape, device=dev)
 
@@ -225,7 +228,7 @@ class StyleEngine:
                 else:
                     wf, _ = s.mod.banks()
                     self._timed("conv_other_fwd", fl, nb, lambda: hip.conv2d_fwd(
-                        a[s.src], wf, s.mod.bias_device(), s.k, s.stride, s.pad, s.relu, out=a[s.dst]))
+                        a[s.src], wf, s.mod.bias_device(), s.k, s.stride, s.pad, s.relu, out=a[s.dst], workspace=self.ws))
             elif s.kind == "relu":
                 hip.relu_(a[s.src])
             elif s.kind == "pool":
@@ -288,7 +291,7 @@ class StyleEngine:
                     _, wb = s.mod.banks()
                     self._timed("conv_other_bwd", fl, nb, lambda: hip.conv2d_bwd_data(
                         g[s.dst], None, wb, s.mod.weight.detach(), a[s.src].shape, s.k, s.stride, s.pad, out=g[s.src],
-                        in_relu_mask=im))
+                        in_relu_mask=im, workspace=self.ws))
                 cur = s.src
             elif s.kind == "relu":
                 hip.relu_bwd(g[s.src], a[s.src], out=g[s.src])

@@ -23,8 +23,10 @@ SIGNATURES = {
     "maua_abi_version": (c_i, []),
     "maua_last_error": (ctypes.c_char_p, []),
     "maua_conv_pack_filters": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
-    "maua_conv2d_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
-    "maua_conv2d_bwd_data": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "maua_conv_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
+    "maua_conv2d_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
+    "maua_conv2d_bwd_data": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz,
+                                   c_p]),
     "maua_conv_x6_bank_bytes": (c_sz, [c_i, c_i]),
     "maua_conv_pack_filters_x6": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p]),
     "maua_conv_x6_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i]),
@@ -128,24 +130,43 @@ def conv_out_hw(h, w, k, stride, pad):
     return (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
 
 
-def conv2d_fwd(x, wf, bias, k, stride, pad, relu, out=None, in_mask=None, accumulate=False):
+def conv_workspace_bytes(n, cin, h, w, cout, k, stride, pad):
+    return lib().maua_conv_workspace_bytes(n, cin, h, w, cout, k, k, stride, pad)
+
+
+def _ws_args(workspace, need, device):
+    """(pointer, bytes) of a split-K workspace: the caller's when given, a fresh one when the geometry wants one."""
+    if workspace is None and need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=device)
+    if workspace is None:
+        return None, 0
+    return workspace.data_ptr(), workspace.numel() * workspace.element_size()
+
+
+def conv2d_fwd(x, wf, bias, k, stride, pad, relu, out=None, in_mask=None, accumulate=False, workspace=None):
     n, cin, h, w = x.shape
     cout = wf.shape[2]
     oh, ow = conv_out_hw(h, w, k, stride, pad)
     if out is None:
         out = torch.empty(n, cout, oh, ow, device=x.device, dtype=torch.float32)
+    wp, wn = _ws_args(workspace, conv_workspace_bytes(n, cin, h, w, cout, k, stride, pad) if workspace is None else 0, x.device)
     _check(lib().maua_conv2d_fwd(_ptr(_f32(x, "x")), _ptr(in_mask), _ptr(wf), _ptr(bias), _ptr(out), n, cin, h, w, cout,
-                                 k, k, stride, pad, int(relu), int(accumulate), _stream()), "maua_conv2d_fwd")
+                                 k, k, stride, pad, int(relu), int(accumulate), wp, wn, _stream()), "maua_conv2d_fwd")
     return out
 
 
-def conv2d_bwd_data(gy, out_mask, wb, w_oihw, in_shape, k, stride, pad, out=None, accumulate=False, in_relu_mask=None):
+def conv2d_bwd_data(gy, out_mask, wb, w_oihw, in_shape, k, stride, pad, out=None, accumulate=False, in_relu_mask=None,
+                    workspace=None):
     n, cin, h, w = in_shape
     cout = gy.shape[1]
     if out is None:
         out = torch.empty(n, cin, h, w, device=gy.device, dtype=torch.float32)
+    need = 0
+    if workspace is None and stride == 1 and k - 1 - pad >= 0:
+        need = conv_workspace_bytes(n, cout, gy.shape[2], gy.shape[3], cin, k, 1, k - 1 - pad)
+    wp, wn = _ws_args(workspace, need, gy.device)
     _check(lib().maua_conv2d_bwd_data(_ptr(_f32(gy, "gy")), _ptr(out_mask), _ptr(wb), _ptr(w_oihw), _ptr(in_relu_mask),
-                                      _ptr(out), n, cin, h, w, cout, k, k, stride, pad, int(accumulate), _stream()),
+                                      _ptr(out), n, cin, h, w, cout, k, k, stride, pad, int(accumulate), wp, wn, _stream()),
            "maua_conv2d_bwd_data")
     return out
 

@@ -27,7 +27,7 @@ def test_header_symbols_exported(libpath):
     out = subprocess.check_output(["nm", "-D", "--defined-only", libpath], text=True)
     exported = set(re.findall(r" T (maua_[a-z0-9_]+)", out))
     want = declared_symbols()
-    assert len(want) >= 28
+    assert len(want) >= 29
     missing = [s for s in want if s not in exported]
     assert not missing, f"declared in maua_hip.h but not exported: {missing}"
     extra = sorted(exported - set(want))
@@ -64,7 +64,7 @@ def test_host_only_entry_points(libpath):
 def test_invalid_arguments_are_rejected_without_touching_the_gpu(libpath):
     import hip
     L = hip.lib()
-    assert L.maua_conv2d_fwd(None, None, None, None, None, 1, 3, 8, 8, 4, 3, 3, 1, 1, 0, 0, None) == -1
+    assert L.maua_conv2d_fwd(None, None, None, None, None, 1, 3, 8, 8, 4, 3, 3, 1, 1, 0, 0, None, 0, None) == -1
     assert b"null" in L.maua_last_error()
     assert L.maua_fill(None, 10, 0.0, None) == -1
     assert L.maua_lbfgs_iterate(None, None, None, 10, 5, 1.0, -1.0, None) == -1

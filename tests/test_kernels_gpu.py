@@ -94,6 +94,32 @@ def test_conv_bwd_data(hip, cin, cout, H, W, k, stride, pad, masked):
     assert rel_l2(gx2.cpu(), ref + base) <= TOL
 
 
+@pytest.mark.parametrize("cin,cout,H,W,k,pad", [(1024, 1024, 31, 31, 1, 0), (384, 96, 15, 17, 3, 1), (256, 96, 20, 24, 5, 2)])
+def test_conv_fp32_split_k_matches_single_pass(hip, cin, cout, H, W, k, pad):
+    """Deep layers on small maps split the channel loop over workgroups (deterministic two-stage sum)."""
+    assert hip.conv_workspace_bytes(1, cin, H, W, cout, k, 1, pad) > 0
+    x = rnd(1, cin, H, W, seed=1)
+    w = rnd(cout, cin, k, k, seed=2, scale=math.sqrt(2.0 / (k * k * cin)))
+    b = rnd(cout, seed=3, scale=0.1)
+    ref = torch.relu(F.conv2d(x, w, b, padding=pad))
+    wf, wb = hip.conv_pack_filters(dev(w))
+    none = torch.empty(0, dtype=torch.uint8, device="cuda")
+    one = hip.conv2d_fwd(dev(x), wf, dev(b), k, 1, pad, True, workspace=none)
+    two = hip.conv2d_fwd(dev(x), wf, dev(b), k, 1, pad, True)
+    three = hip.conv2d_fwd(dev(x), wf, dev(b), k, 1, pad, True)
+    torch.cuda.synchronize()
+    assert rel_l2(one.cpu(), ref) <= TOL and rel_l2(two.cpu(), ref) <= TOL
+    assert torch.equal(two, three)
+    gy = rnd(*ref.shape, seed=4)
+    refb = torch.nn.grad.conv2d_input(x.shape, w, gy, padding=pad)
+    mask = rnd(*x.shape, seed=6)
+    base = rnd(*x.shape, seed=7)
+    gx = hip.conv2d_bwd_data(dev(gy), None, wb, dev(w), x.shape, k, 1, pad, out=dev(base.clone()), accumulate=True,
+                             in_relu_mask=dev(mask))
+    torch.cuda.synchronize()
+    assert rel_l2(gx.cpu(), (refb + base) * (mask > 0)) <= TOL
+
+
 def test_conv_rejects_bad_arguments(hip):
     x = dev(rnd(1, 3, 8, 8))
     wf, _ = hip.conv_pack_filters(dev(rnd(4, 3, 3, 3)))
