@@ -122,6 +122,13 @@ size_t maua_reduce_workspace_bytes(int64_t count);
 int maua_mse_fwd_bwd(const float* x, const float* target, float* grad, int64_t count, float loss_scale, float grad_scale,
                      int accumulate, int mask_grad_by_x, float* loss_out, void* workspace, size_t workspace_bytes,
                      maua_stream_t stream);
+/* The temporal ContentLoss with a reliability mask (loss.py:52-56 `input * self.weights`, set by
+ * optim.set_temporal_targets optim.py:35-47): loss_out[0] = loss_scale * sum((x*w - target)^2),
+ * grad (nullable) (+)= grad_scale * w * (x*w - target).  x, target, grad: [planes][plane]; weights: [weight_planes][plane]
+ * with weight_planes = 1 (one mask for every channel) or = planes. */
+int maua_mse_weighted_fwd_bwd(const float* x, const float* weights, const float* target, float* grad, int64_t planes,
+                              int64_t plane, int weight_planes, float loss_scale, float grad_scale, int accumulate,
+                              float* loss_out, void* workspace, size_t workspace_bytes, maua_stream_t stream);
 
 /* Backward of the Gram loss into the feature map: gf[C][hw] (+)= D[C][C] (symmetric) * (f - mean) ;
  * autograd of torch.mm(x, x.t()) at loss.py:91 with the MSE gradient D (scaled by the caller).  relu_mask (nullable,

@@ -192,6 +192,26 @@ mse_kernel(const float* __restrict__ x, const float* __restrict__ t, float* __re
     if (threadIdx.x == 0) partial[blockIdx.x] = acc;
 }
 
+// Weighted MSE of the temporal ContentLoss (reference loss.py:52-56: the reliability mask multiplies the INPUT only):
+// partial[b] = sum (x*w - t)^2 ; grad (+)= gs * w * (x*w - t).  w has `wplanes` planes of `plane` elements (1 = one mask
+// broadcast over the channels, or as many as x).
+__global__ void __launch_bounds__(256)
+mse_weighted_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ t,
+                    float* __restrict__ grad, int64_t n, int64_t plane, int wplanes, float gs, int accumulate,
+                    double* __restrict__ partial) {
+    __shared__ double scratch[16];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pl = i / plane;
+        const float wv = w[(pl % wplanes) * plane + (i - pl * plane)];
+        const float d = x[i] * wv - t[i];
+        acc += (double)d * (double)d;
+        if (grad) grad[i] = accumulate ? fmaf(gs * wv, d, grad[i]) : gs * wv * d;
+    }
+    acc = block_sum(acc, scratch);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
 // TV: loss = strength * (sum |x[y+1]-x[y]| + sum |x[x+1]-x[x]|); d/dx via sign() of the four neighbours' differences.
 __global__ void __launch_bounds__(256)
 tv_kernel(const float* __restrict__ x, float* __restrict__ grad, int64_t planes, int H, int W, float strength,
@@ -330,6 +350,25 @@ int maua_mse_fwd_bwd(const float* x, const float* target, float* grad, int64_t c
     hipLaunchKernelGGL(mse_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, target, grad, count, grad_scale,
                        accumulate, mask_grad_by_x, (double*)workspace);
     int rc = check_launch("mse_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, nb,
+                       loss_scale, loss_out);
+    return check_launch("finish_sum_kernel");
+}
+
+int maua_mse_weighted_fwd_bwd(const float* x, const float* weights, const float* target, float* grad, int64_t planes,
+                              int64_t plane, int weight_planes, float loss_scale, float grad_scale, int accumulate,
+                              float* loss_out, void* workspace, size_t workspace_bytes, maua_stream_t stream) {
+    MAUA_REQUIRE(x && weights && target && loss_out && workspace && planes > 0 && plane > 0, MAUA_E_INVAL,
+                 "mse_weighted_fwd_bwd: bad args");
+    MAUA_REQUIRE(weight_planes == 1 || weight_planes == planes, MAUA_E_INVAL,
+                 "mse_weighted_fwd_bwd: weights need 1 or %lld planes, got %d", (long long)planes, weight_planes);
+    const int64_t count = planes * plane;
+    const int nb = reduce_blocks(count, 1024);
+    MAUA_REQUIRE(workspace_bytes >= nb * sizeof(double), MAUA_E_WORKSPACE, "mse_weighted_fwd_bwd: workspace too small");
+    hipLaunchKernelGGL(mse_weighted_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, weights, target, grad, count, plane,
+                       weight_planes, grad_scale, accumulate, (double*)workspace);
+    int rc = check_launch("mse_weighted_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, nb,
                        loss_scale, loss_out);

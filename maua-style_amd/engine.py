@@ -179,7 +179,10 @@ class StyleEngine:
             if tuple(m.target.shape[1:]) != tuple(shapes_src[1:]):
                 return False  # loss.py:44
             if m.weights is not None:
-                raise UnsupportedNet("weighted (temporal) ContentLoss runs on the module path")
+                w = m.weights
+                if s.src != 0 or w.dim() != 4 or w.shape[0] != 1 or tuple(w.shape[2:]) != tuple(shapes_src[2:]) \
+                        or w.shape[1] not in (1, shapes_src[1]):
+                    raise UnsupportedNet("weighted ContentLoss of this shape runs on the module path")
             return True
         if m.target.nelement() == 0:
             raise RuntimeError(f"{m.name}: style target not captured")
@@ -270,8 +273,12 @@ class StyleEngine:
                 if self._active(s, a[s.src].shape):
                     lw, gw = self._coefficients(s)
                     n = a[s.src].nelement()
-                    hip.mse_fwd_bwd(a[s.src], s.mod.target, g[s.src], lw / n, gw * 2.0 / n, cur == s.src,
-                                    self.slots[s.slot:s.slot + 1], workspace=self.ws, mask_grad_by_x=premask(s))
+                    if s.mod.weights is not None:  # temporal loss on the pixels: MSE(x * w, target), loss.py:52-56
+                        hip.mse_weighted_fwd_bwd(a[s.src], s.mod.weights, s.mod.target, g[s.src], lw / n, gw * 2.0 / n,
+                                                 cur == s.src, self.slots[s.slot:s.slot + 1], workspace=self.ws)
+                    else:
+                        hip.mse_fwd_bwd(a[s.src], s.mod.target, g[s.src], lw / n, gw * 2.0 / n, cur == s.src,
+                                        self.slots[s.slot:s.slot + 1], workspace=self.ws, mask_grad_by_x=premask(s))
                     cur = s.src
             elif s.kind == "tv":
                 hip.tv_fwd_bwd(a[0], g[0], s.mod.strength, cur == 0, self.slots[s.slot:s.slot + 1], workspace=self.ws)

@@ -40,6 +40,7 @@ SIGNATURES = {
     "maua_gram_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i64, c_f, c_i, c_p, c_sz, c_p]),
     "maua_reduce_workspace_bytes": (c_sz, [c_i64]),
     "maua_mse_fwd_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_f, c_f, c_i, c_i, c_p, c_p, c_sz, c_p]),
+    "maua_mse_weighted_fwd_bwd": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_f, c_f, c_i, c_p, c_p, c_sz, c_p]),
     "maua_gram_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i64, c_i, c_p, c_sz, c_p]),
     "maua_tv_fwd_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_p, c_sz, c_p]),
     "maua_fill": (c_i, [c_p, c_i64, c_f, c_p]),
@@ -285,6 +286,19 @@ def mse_fwd_bwd(x, target, grad, loss_scale, grad_scale, accumulate, loss_out, w
                                   workspace.data_ptr(),
                                   workspace.numel() * workspace.element_size(), _stream()), "maua_mse_fwd_bwd")
     return loss_out
+
+
+def mse_weighted_fwd_bwd(x, weights, target, grad, loss_scale, grad_scale, accumulate, loss_out, workspace=None):
+    """Temporal ContentLoss: loss = loss_scale * sum((x*w - t)^2), grad (+)= grad_scale * w * (x*w - t)."""
+    n, c, h, w = x.shape
+    wplanes = weights.numel() // (h * w)
+    workspace = _ws(workspace, reduce_workspace_bytes(x.numel()), x.device)
+    _check(lib().maua_mse_weighted_fwd_bwd(_ptr(_f32(x, "x")), _ptr(_f32(weights, "weights")), _ptr(_f32(target, "target")),
+                                           _ptr(grad), n * c, h * w, wplanes, float(loss_scale), float(grad_scale),
+                                           int(accumulate), _ptr(loss_out), workspace.data_ptr(),
+                                           workspace.numel() * workspace.element_size(), _stream()),
+           "maua_mse_weighted_fwd_bwd")
+    return grad
 
 
 def tv_fwd_bwd(x, grad, strength, accumulate, loss_out, workspace=None):

@@ -1,9 +1,10 @@
 """Image pre/post-processing with the reference's conventions (reference load.py:21-137), without torchvision /
 skvideo (absent here): Caffe-style VGG input = BGR, 0..255, mean-subtracted.
 
-Video decoding and the optical-flow cache (load.py:141-231) need ffmpeg binaries and the flow networks of the
-un-vendored submodules; they are outside this build.  `process_content_frames` covers the flow-less video path by
-reading a directory of frame images.
+Video decoding and flow ESTIMATION (load.py:141-188) need ffmpeg binaries and the flow networks of the un-vendored
+submodules; they are outside this build.  `process_content_frames` reads a directory of frame images, and the flow
+files the reference caches (`.flo` fields, reliability PNGs; load.py:191-231) are consumed by `flow_warp_map` /
+`reliable_flow_weighting`.
 """
 import os
 
@@ -86,3 +87,60 @@ def process_content_frames(content):
     if not frames:
         raise FileNotFoundError(f"no frame images in {content}")
     return frames
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Precomputed optical flow.  Estimating flow (the reference's un-vendored flow networks) is out of
+# scope; consuming the files it leaves in <output_dir>/flow/ is not: Middlebury .flo fields and reliability PNGs.
+# ---------------------------------------------------------------------------------------------------------
+FLO_MAGIC = 202021.25
+
+
+def read_flo(filename):
+    """Middlebury .flo: float32 magic 202021.25, int32 width, int32 height, then h*w (u, v) float32 pairs."""
+    with open(filename, "rb") as f:
+        magic = np.fromfile(f, np.float32, count=1)
+        if magic.size != 1 or float(magic[0]) != FLO_MAGIC:
+            raise ValueError(f"{filename}: not a .flo file (magic {magic})")  # the reference prints and then fails on `w`
+        w = int(np.fromfile(f, np.int32, count=1)[0])
+        h = int(np.fromfile(f, np.int32, count=1)[0])
+        data = np.fromfile(f, np.float32, count=2 * w * h)
+    if data.size != 2 * w * h:
+        raise ValueError(f"{filename}: truncated flow field ({data.size} of {2 * w * h} values)")
+    return data.reshape(h, w, 2)
+
+
+def write_flow(flow, filename):
+    """Inverse of read_flo (reference load.py:221-231)."""
+    h, w = flow.shape[:2]
+    with open(filename, "wb") as f:
+        np.array([FLO_MAGIC], dtype=np.float32).tofile(f)
+        np.array([w], dtype=np.int32).tofile(f)
+        np.array([h], dtype=np.int32).tofile(f)
+        np.asarray(flow, dtype=np.float32).tofile(f)
+
+
+def flow_warp_map(filename, current_size):
+    """Sampling grid for F.grid_sample that moves an image along a stored flow field (reference load.py:191-214):
+    flow in pixels -> fractions of the image size, Gaussian-smoothed (sigma 5 px), added to the identity grid on
+    [-1, 1]^2, bilinearly resized to `current_size`.  Returns (1, H, W, 2)."""
+    import scipy.ndimage
+    import torch.nn.functional as F
+    flow = read_flo(filename).copy()
+    h, w = flow.shape[:2]
+    flow[:, :, 0] /= w
+    flow[:, :, 1] /= h
+    flow = scipy.ndimage.gaussian_filter(flow, [5, 5, 0])
+    gx, gy = np.meshgrid(np.linspace(-1, 1, w), np.linspace(-1, 1, h))
+    grid = th.from_numpy((np.stack([gx, gy], axis=2) + flow).astype(np.float32)).unsqueeze(0)
+    return F.interpolate(grid.permute(0, 3, 1, 2), size=tuple(current_size), mode="bilinear",
+                         align_corners=False).permute(0, 2, 3, 1)
+
+
+def reliable_flow_weighting(filename):
+    """Reliability mask PNG -> (1, C, H, W) float in [0, 1] (reference load.py:217-218, torchvision ToTensor)."""
+    arr = np.asarray(Image.open(filename))
+    if arr.ndim == 2:
+        arr = arr[:, :, None]
+    t = th.from_numpy(np.ascontiguousarray(arr)).permute(2, 0, 1)
+    return (t.float() / 255.0 if t.dtype == th.uint8 else t.float()).unsqueeze(0)

@@ -5,16 +5,19 @@
 
 `img_img` is the reference's coarse-to-fine loop (style.py:22-73): resume by file existence, bilinear rescaling of
 content / styles / previous result, optional histogram matching before and after every scale, optim.optimize per
-scale, PNG per scale.  `vid_img` is the reference's per-frame loop (style.py:145-311) for the flow-less case
-(BASELINE config 4): without optical flow the frames are independent optimisations that share the network and
-the style targets, so they are block-partitioned over the ranks of a torchrun job (dist.py) - one RCCL broadcast
-of weights and style targets, no per-iteration collective, every rank writes its own frames.
+scale, PNG per scale.  `vid_img` is the reference's per-frame loop (style.py:145-311).  Without optical flow
+(BASELINE config 4) the frames are independent optimisations that share the network and the style targets, so they
+are block-partitioned over the ranks of a torchrun job (dist.py) - one RCCL broadcast of weights and style targets,
+no per-iteration collective, every rank writes its own frames.  With a precomputed flow cache (`.flo` fields and
+reliability PNGs under <output_dir>/flow, as the reference's flow networks leave them) the temporally consistent
+loop runs: warped previous result as initialisation and as pixel-level temporal target (sequential, one rank).
 `img_vid` (README of the reference: "not sure if this is actually working") is not provided.
 """
-import glob  # noqa: F401
+import glob
 import math
 import os
 import os.path
+import random
 
 import numpy as np
 import torch as th
@@ -73,11 +76,103 @@ def img_vid(args):
     raise NotImplementedError("img_vid (style videos with sliding Gram windows) is outside this build's scope")
 
 
+def _vid_img_flow(args, output_dir, frames, style_images_big, content_size):
+    """The reference's temporally consistent loop (style.py:153-305) over a PRECOMPUTED flow cache
+    (`<output_dir>/flow/{forward,backward}_<prev>_<this>.flo` + `.png` reliability masks, as its flow networks leave them;
+    estimating flow is outside this build).  Frames depend on their predecessor (warped previous result = initialisation
+    and pixel-level temporal target), so this path is sequential: one rank runs it."""
+    passes = max(1, args.passes_per_scale)
+    prev_size = None
+    for size_n, (current_size, num_iters) in enumerate(zip(args.image_sizes, args.num_iters)):
+        nxt = args.image_sizes[min(len(args.image_sizes) - 1, size_n + 1)]
+        if len(glob.glob("%s/%s/*.png" % (output_dir, nxt))) == len(frames):
+            print("Skipping size: %s, already done." % current_size)
+            prev_size = current_size
+            continue
+        print("\nCurrent size {}px".format(current_size))
+        os.makedirs(output_dir + "/" + str(current_size), exist_ok=True)
+        content_scale = current_size / max(*content_size)
+        style_images = _scaled_styles(style_images_big, content_scale ** 2 * content_size[0] * content_size[1], args)
+        optim.set_model_args(args, current_size)
+        net, losses = models.load_model(args)
+
+        for pass_n in range(passes):
+            pastiche = None
+            if args.loop:
+                start_idx = random.randrange(0, len(frames) - 1)
+                frames = frames[start_idx:] + frames[:start_idx]  # rotate frames
+            if len(glob.glob("%s/%s/%s_*.png" % (output_dir, current_size, pass_n + 2))) == len(frames):
+                print(f"Skipping pass: {pass_n + 1}, already done.")
+                frames = list(reversed(frames))
+                continue
+            direction = "forward" if pass_n % 2 == 0 else "backward"
+            pairs = zip(frames + frames[: 11 if args.loop else 1], frames[1:] + frames[: 10 if args.loop else 1])
+            for n, (prev_frame, this_frame) in enumerate(pairs):
+                args.output = "%s/%s/%s_%s.png" % (output_dir, current_size, pass_n + 1, name(this_frame))
+                if os.path.isfile(args.output) and not n >= len(frames):
+                    print("Skipping pass: %s, frame: %s. File already exists." % (pass_n + 1, name(this_frame)))
+                    continue
+                print("Optimizing... size: %s, pass: %s, frame: %s" % (current_size, pass_n + 1, name(this_frame)))
+                content_frames = [
+                    match_histogram(F.interpolate(load.preprocess(f), scale_factor=content_scale, mode="bilinear",
+                                                  align_corners=False), style_images_big[0], mode=args.match_histograms)
+                    for f in (prev_frame, this_frame)]
+                stem = f"{output_dir}/flow/{direction}_{name(prev_frame)}_{name(this_frame)}"
+                if size_n == 0 and pass_n == 0:
+                    if args.init == "random":
+                        pastiche = th.randn(content_frames[1].size()).mul(0.001)
+                    elif args.init == "prev_warp":
+                        if pastiche is None:
+                            pastiche = content_frames[0]
+                        flow_map = load.flow_warp_map(stem + ".flo", pastiche.shape[2:])
+                        pastiche = F.grid_sample(pastiche, flow_map, padding_mode="border", align_corners=False)
+                    else:
+                        pastiche = content_frames[1].clone()
+                else:
+                    wrapped = n > len(frames)  # second lap of a looping clip reads this pass's own files
+                    if pass_n == 0:  # last pass of the previous size
+                        src_dir, src_pass = (current_size, pass_n + 1) if wrapped else (prev_size, passes)
+                    else:            # previous pass of this size
+                        src_dir, src_pass = current_size, (pass_n + 1 if wrapped else pass_n)
+                    hw = content_frames[0].size()[2:]
+                    if pastiche is None:
+                        pastiche = load.preprocess("%s/%s/%s_%s.png" % (output_dir, src_dir, src_pass, name(prev_frame)))
+                        if pass_n == 0:
+                            pastiche = F.interpolate(pastiche, size=hw, mode="bilinear", align_corners=False)
+                    blend_image = load.preprocess("%s/%s/%s_%s.png" % (output_dir, src_dir, src_pass, name(this_frame)))
+                    if pass_n == 0:
+                        blend_image = F.interpolate(blend_image, size=hw, mode="bilinear", align_corners=False)
+                    flow_map = load.flow_warp_map(stem + ".flo", pastiche.shape[2:])
+                    warp_image = F.grid_sample(pastiche, flow_map, padding_mode="border", align_corners=False)
+                    reliable = F.interpolate(load.reliable_flow_weighting(stem + ".png"), size=pastiche.size()[2:],
+                                             mode="bilinear", align_corners=False)
+                    optim.set_temporal_targets(net, warp_image, warp_weights=reliable, args=args)
+                    pastiche = (1 - args.temporal_blend) * blend_image + args.temporal_blend * pastiche
+
+                out = optim.optimize(content_frames[1], style_images, pastiche, num_iters // passes, args, net, losses)
+                pastiche = match_histogram(out.detach().cpu(), style_images_big[0], mode=args.match_histograms)
+                disp = load.deprocess(pastiche.clone())
+                if args.original_colors == 1:
+                    disp = load.original_colors(load.deprocess(content_frames[1].clone()), disp)
+                disp.save(str(args.output))
+            frames = list(reversed(frames))  # the next pass runs the clip the other way
+        prev_size = current_size
+        del net
+        th.cuda.empty_cache()
+
+
 def vid_img(args):
-    """Per-frame stylisation without optical flow, frames sharded over the ranks of the job."""
+    """Per-frame stylisation.  With a flow cache under <output_dir>/flow the reference's temporally consistent loop
+    runs (sequential, rank 0); without one the frames are independent and are sharded over the ranks of the job."""
     rank, _, world = dist.init()
     output_dir = args.output_dir + "/" + name(args.content) + "_" + "_".join([name(s) for s in args.style])
     frames = load.process_content_frames(args.content)
+    if args.temporal_weight > 0 and glob.glob(output_dir + "/flow/*.flo"):
+        if rank == 0:
+            _vid_img_flow(args, output_dir, frames, load.process_style_images(args),
+                          np.array(load.preprocess(frames[0]).size()[-2:]))
+        dist.barrier()
+        return
     lo, hi = dist.shard_range(len(frames), rank, world)
     mine = frames[lo:hi]
     content_size = np.array(load.preprocess(frames[0]).size()[-2:])

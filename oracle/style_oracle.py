@@ -218,6 +218,14 @@ class OracleNet:
             if l.kind == "content":
                 self.targets[i] = acts[i].clone()
 
+    def capture_temporal(self, warp_image, warp_weights=None):
+        """optim.set_temporal_targets (optim.py:35-47): the pixel-level ContentLoss captures the warped previous frame as
+        it is (loss.py:61-62) and keeps the reliability mask as `.weights` (applied to the INPUT only, loss.py:52-53)."""
+        for i, l in enumerate(self.spec):
+            if l.kind == "temporal":
+                self.targets[i] = warp_image.to(self.dtype).clone()
+                self.temporal_weights = None if warp_weights is None else warp_weights.to(self.dtype).clone()
+
     def capture_style(self, images, blend_weights):
         """optim.set_style_targets (optim.py:50-66) -> StyleLoss.static_loss 'capture' (loss.py:146-151):
         target = sum_i blend_i * Gram_i / (C*H*W) / B.  (The dynamic target, loss.py:170-175, equals it for B=1.)"""
@@ -264,7 +272,18 @@ class OracleNet:
                 g[:, :, :, :-1] -= sh
                 inject[i] = s * g
             elif l.kind == "temporal":
-                continue  # empty target in "loss" mode -> early return (loss.py:46-47)
+                if i not in self.targets:
+                    continue  # empty target in "loss" mode -> early return (loss.py:46-47)
+                # ContentLoss.forward on the pixels (loss.py:49-59): MSE(x * weights, target), weights on the input only
+                t, w = self.targets[i], getattr(self, "temporal_weights", None)
+                if x.shape[1:] != t.shape[1:]:
+                    continue  # loss.py:44
+                diff = (x * w if w is not None else x) - t
+                mse = (diff * diff).mean()
+                losses[i] = mse * s
+                coeff = _scale_grad_coeff(s, s) if l.normalize else s
+                gi = diff * (coeff * 2.0 / diff.numel())
+                inject[i] = gi * w if w is not None else gi
             elif l.kind == "content":
                 # ContentLoss.forward (loss.py:49-59), B = 1
                 f, t = acts[i], self.targets[i]
@@ -456,10 +475,13 @@ def adam_run(fg, x0, num_iters, lr=1.0, betas=(0.9, 0.999), eps=1e-8):
     return x.reshape(x0.shape), calls
 
 
-def optimize(content, styles, init, num_iters, cfg, state_dict, dtype=torch.float32, trace=None):
-    """optim.optimize (optim.py:111-255) for transfer types without '_vid' and B = 1."""
+def optimize(content, styles, init, num_iters, cfg, state_dict, dtype=torch.float32, trace=None, temporal=None):
+    """optim.optimize (optim.py:111-255) for transfer types without '_vid' and B = 1.  `temporal` = (warp_image,
+    warp_weights) when the caller had run optim.set_temporal_targets on the prebuilt net (style.py:281)."""
     spec = build_spec(cfg)
     net = OracleNet(spec, state_dict, dtype)
+    if temporal is not None:
+        net.capture_temporal(*temporal)
     net.capture_content(content)
     net.capture_style(styles, cfg.style_blend_weights)
     if getattr(cfg, "normalize_weights", False):

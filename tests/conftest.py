@@ -98,3 +98,34 @@ def product_args(weight_files, extra=(), model="vgg19", optimizer="lbfgs", S=64,
             "--scaling_args", scaling, "--optimizer", optimizer, "--image_sizes", str(S), "--num_iters", str(N),
             "--seed", "0", "--no_hist_match"] + list(extra)
     return config.get_args(argv)
+
+
+def write_video_fixture(root, n_frames=3, S=64):
+    """Frames + flow cache for vid_img: same construction as tools/make_golden.py::write_video_fixture (whose files came
+    from the reference's writer; the product's writer is byte-identical, tests/test_load_and_dist_cpu.py)."""
+    import numpy as np
+    from PIL import Image
+    import load
+    fdir = os.path.join(root, "clip")
+    os.makedirs(fdir, exist_ok=True)
+    names = []
+    base = torch.rand(S + 8, S + 8, 3, generator=torch.Generator().manual_seed(21))
+    for i in range(n_frames):
+        frame = (base[i * 2:i * 2 + S, i * 3:i * 3 + S] * 255).byte().numpy()
+        names.append("%04d" % i)
+        Image.fromarray(frame).save(os.path.join(fdir, names[-1] + ".png"))
+    flow_dir = os.path.join(root, "out", "clip_synth_style_256", "flow")
+    os.makedirs(flow_dir, exist_ok=True)
+    g = torch.Generator().manual_seed(22)
+    yy, xx = torch.meshgrid(torch.linspace(0, 3.14159, S), torch.linspace(0, 3.14159, S), indexing="ij")
+    for a in names:
+        for b in names:
+            if a == b:
+                continue
+            for direction in ("forward", "backward"):
+                amp = (torch.rand(2, generator=g) * 4 - 2)
+                flow = torch.stack([amp[0] * torch.sin(yy) * torch.cos(xx), amp[1] * torch.cos(yy) * torch.sin(xx)], dim=2)
+                load.write_flow(flow.numpy().astype(np.float32), os.path.join(flow_dir, f"{direction}_{a}_{b}.flo"))
+                rel = ((torch.rand(S, S, generator=g) > 0.2).float() * 255).byte().numpy()
+                Image.fromarray(rel, mode="L").save(os.path.join(flow_dir, f"{direction}_{a}_{b}.png"))
+    return fdir, os.path.join(root, "out")

@@ -100,3 +100,88 @@ def test_vid_img_frames_without_flow(tmp_path, weight_files):
     for size in ("32", "48"):
         assert sorted(os.listdir(base / size)) == sorted(f"{p}_{i:05d}.png" for p in (1, 2) for i in range(3))
     assert Image.open(base / "48" / "2_00002.png").size == (48, 48)
+
+
+def test_vid_img_with_flow_cache_matches_reference(weight_files, tmp_path):
+    """SURVEY 8(f)-3 end to end: style.vid_img over a precomputed flow cache (warp initialisation, pixel-level temporal
+    targets with reliability masks, two passes in opposite directions) against the reference's own vid_img run on the
+    same files (tests/golden/vid_flow_S64.npz, tools/make_golden.py::gen_vid)."""
+    import numpy as np
+    from PIL import Image
+    import config
+    import optim
+    import style
+    from conftest import GOLDEN, REPO, rel_l2, write_video_fixture
+    g = np.load(os.path.join(GOLDEN, "vid_flow_S64.npz"))
+    fdir, outdir = write_video_fixture(str(tmp_path))
+    scaling = os.path.join(os.path.dirname(weight_files["vgg19"]), "scaling-test.json")
+    if not os.path.exists(scaling):
+        with open(scaling, "w") as f:
+            json.dump({"100000": {"gpu": "0", "multidevice": False}}, f)
+    args = config.get_args(["--transfer_type", "vid_img", "--content", fdir, "--style", os.path.join(REPO, "tests", "synth_style_256.png"),
+                            "--image_sizes", "64", "--num_iters", "8", "--passes_per_scale", "2", "--init", "prev_warp",
+                            "--model_file", weight_files["vgg19"], "--disable_check", "--scaling_args", scaling, "--seed", "0",
+                            "--no_hist_match", "--output_dir", outdir])
+    calls, n_tt = [], [0]
+    real_opt, real_tt = optim.optimize, optim.set_temporal_targets
+
+    def spy(content, styles, init, n, a, net=None, losses=None):
+        init0 = init.detach().clone().cpu()
+        out = real_opt(content, styles, init, n, a, net, losses)
+        calls.append((os.path.basename(a.output), init0, out.detach().clone()))
+        return out
+
+    def spy_tt(*a, **k):
+        n_tt[0] += 1
+        return real_tt(*a, **k)
+    optim.optimize, optim.set_temporal_targets = spy, spy_tt
+    try:
+        torch.manual_seed(0)
+        style.vid_img(args)
+    finally:
+        optim.optimize, optim.set_temporal_targets = real_opt, real_tt
+    assert [c[0] for c in calls] == [str(x) for x in g["order"]]
+    assert n_tt[0] == int(g["temporal_target_calls"])
+    for k, (fname, init, out) in enumerate(calls):
+        e_init, e_out = rel_l2(init, g["init_" + fname]), rel_l2(out, g["out_" + fname])
+        png = np.asarray(Image.open(os.path.join(outdir, "clip_synth_style_256", "64", fname))).astype(np.int32)
+        d = np.abs(png - g["png_" + fname].astype(np.int32))
+        print(fname, "init", e_init, "out", e_out, "png max", d.max(), "mean", d.mean())
+        # The chain is sequential (frame k starts from the warped result of frame k-1, pass 2 from re-read 8-bit PNGs) and
+        # every call is 4 L-BFGS iterations from a rough start, which amplify input differences ~600x even in exact
+        # arithmetic (measured with the fp64 oracle on call 1: a 1.2e-4 perturbation of the initial image moves the result
+        # by 7.2e-2).  So only call 0, which starts from identical inputs, is compared tightly; the rest is a sanity bound
+        # and the per-call test below applies the trajectory rule from the reference's own inputs.
+        assert e_init <= (1e-6 if k == 0 else 0.3)
+        assert e_out <= (1e-3 if k == 0 else 0.5)
+        assert d.mean() <= (0.05 if k == 0 else 20.0)
+        assert np.isfinite(out.numpy()).all()
+
+
+def test_vid_img_calls_against_fp64_arbiter(weight_files, tmp_path):
+    """Every optimize call of the reference's vid_img run, replayed in isolation from the reference's own inputs (initial
+    image, temporal target, reliability mask) and judged by the trajectory rule against the fp64 arbiter of that call."""
+    import models
+    import optim
+    import load
+    from conftest import product_args, write_video_fixture
+    g = np.load(os.path.join(GOLDEN, "vid_flow_S64.npz"))
+    fdir, _ = write_video_fixture(str(tmp_path))
+    args = product_args(weight_files, S=64, N=4)
+    style_img = torch.nn.functional.interpolate(load.preprocess(os.path.join(REPO, "tests", "synth_style_256.png")),
+                                                scale_factor=0.25, mode="bilinear", align_corners=False)
+    optim.set_model_args(args, 64)
+    net, losses = models.load_model(args)
+    for fname in (str(x) for x in g["order"]):
+        content = load.preprocess(os.path.join(fdir, fname.split("_")[1]))
+        tmod = net.temporal_losses[0]
+        if "ttarget_" + fname in g:
+            optim.set_temporal_targets(net, torch.from_numpy(g["ttarget_" + fname]),
+                                       warp_weights=torch.from_numpy(g["tweights_" + fname]), args=args)
+        else:
+            tmod.target, tmod.weights = torch.Tensor(), None
+        out = optim.optimize(content, [style_img], torch.from_numpy(g["init_" + fname]).clone(), 4, args, net, losses)
+        floor = rel_l2(g["out_" + fname], g["out64_" + fname])
+        err = rel_l2(out, g["out64_" + fname])
+        print(fname, "err", err, "floor", floor)
+        assert err <= max(1e-3, 2 * floor), (fname, err, floor)

@@ -248,3 +248,60 @@ def test_cpu_mode_is_refused(weight_files):
     args = product_args(weight_files, ["--gpu", "c"], S=32)
     with pytest.raises(RuntimeError):
         models.load_model(args)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# temporal (flow-weighted) ContentLoss on the pixels
+# ---------------------------------------------------------------------------------------------------------
+def temporal_inputs(S):
+    """Same construction as tools/make_golden.py::temporal_inputs."""
+    g = torch.Generator().manual_seed(11)
+    warp = torch.rand(1, 3, S, S, generator=g) * 255 - 120
+    weights = (torch.rand(1, 1, S, S, generator=g) > 0.3).float() * torch.rand(1, 1, S, S, generator=g)
+    return warp, weights
+
+
+@pytest.mark.parametrize("tag,flags", [("default", []), ("no_grad_norm", ["--no_grad_norm"])])
+@pytest.mark.parametrize("fused", [True, False])
+def test_temporal_feval_matches_reference(weight_files, tag, flags, fused):
+    """optim.set_temporal_targets + one evaluation, on the fused plan (mse_weighted_kernel) and on the module path."""
+    import engine
+    import optim
+    S = 64
+    g = gold(f"feval_temporal_{tag}_S{S}")
+    args = product_args(weight_files, flags, S=S)
+    content, style, init = synth.images(S)
+    warp, weights = temporal_inputs(S)
+    net, losses = build(args, content, [style], S)
+    for m in losses:
+        m.mode = "none"
+    optim.set_temporal_targets(net, warp, warp_weights=weights, args=args)
+    for m in losses:
+        m.mode = "loss"
+    assert rel_l2(net.temporal_losses[0].target.cpu(), g["temporal_target"]) == 0.0
+    if fused:
+        slots, total, grad = engine.StyleEngine(net, losses).feval(init.cuda())
+    else:
+        opt = optim.PixelOptimizer(net, losses, init, args)
+        opt.engine = None
+        slots, total, grad = opt.feval()
+    torch.cuda.synchronize()
+    check_against_golden(g, losses, slots, total, grad)
+
+
+@pytest.mark.parametrize("opt", ["lbfgs", "adam"])
+def test_temporal_trajectory_vs_fp64_arbiter(weight_files, opt):
+    import models
+    import optim
+    S, N = 64, 6
+    g = gold(f"traj_temporal_S{S}")
+    args = product_args(weight_files, optimizer=opt, S=S, N=N)
+    content, style, init = synth.images(S)
+    warp, weights = temporal_inputs(S)
+    optim.set_model_args(args, S)
+    net, losses = models.load_model(args)
+    optim.set_temporal_targets(net, warp, warp_weights=weights, args=args)
+    out = optim.optimize(content, [style], init.clone(), N, args, net, losses)
+    floor = rel_l2(g[f"{opt}_N{N}_f32"], g[f"{opt}_N{N}_f64"])
+    err = rel_l2(out, g[f"{opt}_N{N}_f64"])
+    assert err <= max(1e-3, 2 * floor), (err, floor)

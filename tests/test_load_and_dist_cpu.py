@@ -103,3 +103,33 @@ def test_two_rank_gloo_broadcast_and_sharding(tmp_path):
     s.close()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
+
+
+def test_flow_warp_map_matches_reference_fixture(tmp_path):
+    """load.flow_warp_map / read_flo / write_flow against the reference's own reader and writer (tests/golden/flow_warp_map.npz,
+    tools/make_golden.py::gen_temporal)."""
+    import numpy as np
+    import torch.nn.functional as F
+    import load
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "flow_warp_map.npz"))
+    path = str(tmp_path / "a.flo")
+    g["flo_file_bytes"].tofile(path)
+    assert np.array_equal(load.read_flo(path), g["flow"])
+    for key in ("warp_40x56", "warp_64x80"):
+        hh, ww = (int(v) for v in key.split("_")[1].split("x"))
+        got = load.flow_warp_map(path, (hh, ww))
+        assert got.shape == (1, hh, ww, 2)
+        assert float((got - torch.from_numpy(g[key])).abs().max()) <= 1e-6
+    warped = F.grid_sample(torch.from_numpy(g["image"]), load.flow_warp_map(path, (64, 80)), padding_mode="border",
+                           align_corners=False)
+    assert float((warped - torch.from_numpy(g["warped"])).abs().max()) <= 1e-3
+    again = str(tmp_path / "b.flo")
+    load.write_flow(g["flow"], again)
+    assert np.array_equal(np.fromfile(again, dtype=np.uint8), g["flo_file_bytes"])
+    with open(str(tmp_path / "bad.flo"), "wb") as f:
+        f.write(b"\0" * 32)
+    try:
+        load.read_flo(str(tmp_path / "bad.flo"))
+        raise AssertionError("bad magic accepted")
+    except ValueError:
+        pass

@@ -193,3 +193,48 @@ def test_nin_adam_trajectory():
     content, style, init = synth.images(128)
     out = optimize(content, [style], init, 5, cfg, synth.nin_state_dict(), dtype=torch.float64)
     assert rel_l2(out, g["adam_N5_f64"]) <= 1e-9
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the temporal path (weighted pixel-level ContentLoss, .flo warp maps)
+# ---------------------------------------------------------------------------------------------------------
+def temporal_inputs(S):
+    """Same construction as tools/make_golden.py::temporal_inputs."""
+    g = torch.Generator().manual_seed(11)
+    warp = torch.rand(1, 3, S, S, generator=g) * 255 - 120
+    weights = (torch.rand(1, 1, S, S, generator=g) > 0.3).float() * torch.rand(1, 1, S, S, generator=g)
+    return warp, weights
+
+
+@pytest.mark.parametrize("tag,over", [("default", {}), ("no_grad_norm", {"normalize_gradients": False})])
+@pytest.mark.parametrize("double", [False, True])
+def test_oracle_temporal_feval_matches_reference(tag, over, double):
+    S = 64
+    g = gold(f"feval_temporal_{tag}_S{S}" + ("_f64" if double else ""))
+    cfg = make_cfg(**over)
+    dtype = torch.float64 if double else torch.float32
+    content, style, init = synth.images(S)
+    warp, weights = temporal_inputs(S)
+    net = OracleNet(build_spec(cfg), synth.vgg19_state_dict(), dtype)
+    net.capture_content(content)
+    net.capture_style([style], cfg.style_blend_weights)
+    net.capture_temporal(warp, weights)
+    total, losses, grad = net.feval(init)
+    names = [l.name for l in net.spec if l.kind in ("content", "style", "tv", "temporal")]
+    got = {net.spec[i].name: float(v) for i, v in losses.items()}
+    tol = 1e-9 if double else 2e-5
+    for name, want in zip(g["loss_names"], g["loss_values"]):
+        assert abs(got[str(name)] - want) <= tol * max(1.0, abs(want)), name
+    assert rel_l2(grad, torch.from_numpy(g["grad"])) <= (1e-9 if double else 2e-5)
+    assert "temporal 1" in names
+
+
+@pytest.mark.parametrize("opt", ["lbfgs", "adam"])
+def test_oracle_temporal_trajectory_fp64(opt):
+    S, N = 64, 6
+    g = gold(f"traj_temporal_S{S}")
+    cfg = make_cfg(optimizer=opt)
+    content, style, init = synth.images(S)
+    out = optimize(content, [style], init, N, cfg, synth.vgg19_state_dict(), dtype=torch.float64,
+                          temporal=temporal_inputs(S))
+    assert rel_l2(out, torch.from_numpy(g[f"{opt}_N{N}_f64"])) <= 1e-7

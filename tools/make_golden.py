@@ -428,7 +428,10 @@ def _install_torchvision_standins():
         def __call__(self, img):
             if isinstance(img, np.ndarray):
                 return torch.from_numpy(img.transpose(2, 0, 1).copy())
-            return torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float() / 255
+            arr = np.asarray(img, dtype=np.uint8)
+            if arr.ndim == 2:  # mode "L": torchvision returns (1, H, W)
+                arr = arr[:, :, None]
+            return torch.from_numpy(arr.copy()).permute(2, 0, 1).float() / 255
 
     class ToPILImage:
         def __call__(self, t):
@@ -493,13 +496,198 @@ def gen_cli():
     save("cli_config1", **res)
 
 
-GROUPS = {"cli": gen_cli, "traj64v": gen_traj_variants64, "feval": gen_feval, "traj": gen_traj, "nin": gen_nin, "hist": gen_hist, "host": gen_host}
+def write_video_fixture(root, write_flow, n_frames=3, S=64):
+    """Frames + the flow cache the reference's vid_img expects under <output_dir>/<content>_<style>/flow/ (normally
+    written by its flow networks): smooth synthetic fields and reliability masks for every ordered pair of frames.
+    Same construction in tests/conftest.py::write_video_fixture (the product's writer is byte-identical, see
+    tests/test_load_and_dist_cpu.py)."""
+    from PIL import Image
+    fdir = os.path.join(root, "clip")
+    os.makedirs(fdir, exist_ok=True)
+    names = []
+    base = torch.rand(S + 8, S + 8, 3, generator=torch.Generator().manual_seed(21))
+    for i in range(n_frames):  # a slowly translating random texture
+        frame = (base[i * 2:i * 2 + S, i * 3:i * 3 + S] * 255).byte().numpy()
+        names.append("%04d" % i)
+        Image.fromarray(frame).save(os.path.join(fdir, names[-1] + ".png"))
+    flow_dir = os.path.join(root, "out", "clip_synth_style_256", "flow")
+    os.makedirs(flow_dir, exist_ok=True)
+    g = torch.Generator().manual_seed(22)
+    yy, xx = torch.meshgrid(torch.linspace(0, 3.14159, S), torch.linspace(0, 3.14159, S), indexing="ij")
+    for a in names:
+        for b in names:
+            if a == b:
+                continue
+            for direction in ("forward", "backward"):
+                amp = (torch.rand(2, generator=g) * 4 - 2)
+                flow = torch.stack([amp[0] * torch.sin(yy) * torch.cos(xx), amp[1] * torch.cos(yy) * torch.sin(xx)], dim=2)
+                write_flow(flow.numpy().astype(np.float32), os.path.join(flow_dir, f"{direction}_{a}_{b}.flo"))
+                rel = ((torch.rand(S, S, generator=g) > 0.2).float() * 255).byte().numpy()
+                Image.fromarray(rel, mode="L").save(os.path.join(flow_dir, f"{direction}_{a}_{b}.png"))
+    return fdir, os.path.join(root, "out")
+
+
+def gen_vid():
+    """SURVEY 8(f)-3 end to end: the reference's own style.vid_img over precomputed flow files.  Only the flow
+    ESTIMATION (flow.get_flow_model / load.process_content_video) and the final ffmpeg call are stubbed."""
+    print("[vid] style.vid_img with a precomputed flow cache (3 frames, 64 px, 2 passes)")
+    _install_torchvision_standins()
+    flow_stub = types.ModuleType("flow")
+    flow_stub.get_flow_model = lambda args: None
+    sys.modules["flow"] = flow_stub
+
+    class _Chain:
+        def __getattr__(self, _):
+            return lambda *a, **k: self
+    sys.modules["ffmpeg"].input = lambda *a, **k: _Chain()
+    import load as ref_load
+    import style as ref_style
+    root = os.path.join(TMP, "vid")
+    fdir, outdir = write_video_fixture(root, ref_load.write_flow)
+    ref_load.process_content_video = lambda flow_model, args: sorted(os.path.join(fdir, f) for f in os.listdir(fdir))
+    spng = os.path.join(REPO, "tests", "synth_style_256.png")
+    argv = ["style.py", "--transfer_type", "vid_img", "--content", fdir, "--style", spng, "--image_sizes", "64", "--num_iters",
+            "8", "--passes_per_scale", "2", "--init", "prev_warp", "--gpu", "c", "--backend", "mkl", "--model_file", VGG_PATH,
+            "--disable_check", "--scaling_args", SCALING, "--ffmpeg_args", os.path.join(REF, "config", "ffmpeg-libx264.json"),
+            "--seed", "0", "--no_hist_match", "--output_dir", outdir]
+    old = sys.argv
+    sys.argv = argv
+    try:
+        args = ref_config.get_args()
+    finally:
+        sys.argv = old
+    calls = []
+    real_opt, real_tt = ref_optim.optimize, ref_optim.set_temporal_targets
+
+    arb = {}
+
+    def spy(content, styles, init, n, a, net=None, losses=None):
+        init0 = init.detach().clone()  # the reference optimises `init` in place (nn.Parameter(init.type(same dtype)))
+        tmod = net.temporal_losses[0]
+        tstate = (tmod.target.detach().clone(), None if tmod.weights is None else tmod.weights.detach().clone())
+        out = real_opt(content, styles, init, n, a, net, losses)
+        # fp64 arbiter of THIS call: same inputs, same temporal state, the reference's optimize on a double network
+        if "net" not in arb:
+            arb["net"], arb["losses"] = ref_models.load_model(a)
+            arb["net"].double()
+        m64 = arb["net"].temporal_losses[0]
+        m64.target = tstate[0].double()
+        m64.weights = None if tstate[1] is None else tstate[1].double()
+        a.dtype = torch.DoubleTensor
+        out64 = real_opt(content, styles, init0.clone(), n, a, arb["net"], arb["losses"]).detach().clone()
+        a.dtype = torch.FloatTensor
+        calls.append((os.path.basename(a.output), init0, out.detach().clone(), out64, tstate))
+        return out
+    n_tt = [0]
+
+    def spy_tt(*a, **k):
+        n_tt[0] += 1
+        return real_tt(*a, **k)
+    ref_optim.optimize, ref_optim.set_temporal_targets = spy, spy_tt
+    torch.manual_seed(args.seed)
+    with quiet():
+        ref_style.vid_img(args)
+    ref_optim.optimize, ref_optim.set_temporal_targets = real_opt, real_tt
+    from PIL import Image
+    res = {"order": np.array([c[0] for c in calls]), "temporal_target_calls": np.array(n_tt[0])}
+    for fname, init, out, out64, tstate in calls:
+        res["init_" + fname] = init.numpy()
+        res["out_" + fname] = out.numpy()
+        res["out64_" + fname] = out64.numpy().astype(np.float32)  # compared at >= 1e-3
+        if tstate[0].nelement():
+            res["ttarget_" + fname] = tstate[0].numpy()
+            res["tweights_" + fname] = tstate[1].numpy()
+        png = os.path.join(outdir, "clip_synth_style_256", "64", fname)
+        res["png_" + fname] = np.asarray(Image.open(png))
+        print(f"    {fname}: f32 vs f64 of this call {float((out.double() - out64).norm() / out64.norm()):.3e}")
+    print("    optimize calls:", [c[0] for c in calls], " set_temporal_targets calls:", n_tt[0])
+    save("vid_flow_S64", **res)
+
+
+def temporal_inputs(S):
+    """Synthetic stand-ins for what vid_img feeds the temporal loss: the previous result warped by the flow (an image in
+    the preprocessed range) and the flow-reliability mask in [0, 1] (style.py:272-281)."""
+    g = torch.Generator().manual_seed(11)
+    warp = torch.rand(1, 3, S, S, generator=g) * 255 - 120
+    weights = (torch.rand(1, 1, S, S, generator=g) > 0.3).float() * torch.rand(1, 1, S, S, generator=g)
+    return warp, weights
+
+
+def gen_temporal():
+    """pixel-level weighted ContentLoss ('temporal') set by optim.set_temporal_targets, and the flow-file
+    reader load.flow_warp_map.  Reference code only; flow estimation itself is out of scope (files are synthetic)."""
+    print("[temporal] weighted temporal ContentLoss + .flo warp maps")
+    S = 64
+    content, style, init = synth.images(S)
+    warp, weights = temporal_inputs(S)
+    for tag, extra in (("default", []), ("no_grad_norm", ["--no_grad_norm"])):
+        for double in (False, True):
+            args = get_args(extra, S=S)
+            ref_optim.set_model_args(args, S)
+            with quiet():
+                net, losses = ref_models.load_model(args)
+            if double:
+                net.double()
+                args.dtype = torch.DoubleTensor
+            with quiet():
+                ref_optim.set_content_targets(net, content, args)
+                ref_optim.set_style_targets(net, [style], args)
+                ref_optim.set_temporal_targets(net, warp, warp_weights=weights, args=args)
+            for m in losses:
+                m.mode = "loss"
+            x = torch.nn.Parameter(init.clone().type(args.dtype))
+            net(x)
+            names, vals, total = [], [], 0
+            for m in losses:
+                names.append(m.name)
+                vals.append(0.0 if isinstance(m.loss, int) else float(m.loss.detach()))
+                if not isinstance(m.loss, int):
+                    total = total + m.loss
+            total.backward()
+            suffix = "_f64" if double else ""
+            save(f"feval_temporal_{tag}_S{S}{suffix}", loss_names=np.array(names), loss_values=np.array(vals, dtype=np.float64),
+                 total=np.float64(float(total.detach())), grad=x.grad.detach().numpy().copy(),
+                 temporal_target=net.temporal_losses[0].target.numpy().copy())
+            print(f"    {tag}{suffix}: losses {dict(zip(names, vals))}")
+    # trajectory with the temporal target in place (prebuilt net, as vid_img calls optimize)
+    res = {}
+    for opt, N in (("lbfgs", 6), ("adam", 6)):
+        for double in (False, True):
+            args = get_args([], optimizer=opt, S=S, N=N)
+            ref_optim.set_model_args(args, S)
+            with quiet():
+                net, losses = ref_models.load_model(args)
+            if double:
+                net.double()
+                args.dtype = torch.DoubleTensor
+            with quiet():
+                ref_optim.set_temporal_targets(net, warp, warp_weights=weights, args=args)
+                out = ref_optim.optimize(content, [style], init.clone(), N, args, net, losses).detach()
+            res[f"{opt}_N{N}_{'f64' if double else 'f32'}"] = out.numpy()
+    save(f"traj_temporal_S{S}", **res)
+    # .flo reader: synthetic smooth flow written with the reference's writer, read back by its reader at two sizes
+    import tempfile
+    import load as ref_load
+    g = torch.Generator().manual_seed(12)
+    h, w = 40, 56
+    flow = (torch.rand(h, w, 2, generator=g) * 6 - 3).numpy().astype(np.float32)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "a.flo")
+        ref_load.write_flow(flow, path)
+        raw = np.fromfile(path, dtype=np.uint8)
+        maps = {f"warp_{hh}x{ww}": ref_load.flow_warp_map(path, (hh, ww)).numpy() for hh, ww in ((40, 56), (64, 80))}
+    img = torch.rand(1, 3, 64, 80, generator=g) * 255 - 120
+    warped = torch.nn.functional.grid_sample(img, torch.from_numpy(maps["warp_64x80"]), padding_mode="border")
+    save("flow_warp_map", flow=flow, flo_file_bytes=raw, image=img.numpy(), warped=warped.numpy(), **maps)
+
+
+GROUPS = {"vid": gen_vid, "temporal": gen_temporal, "cli": gen_cli, "traj64v": gen_traj_variants64, "feval": gen_feval, "traj": gen_traj, "nin": gen_nin, "hist": gen_hist, "host": gen_host}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     want = sys.argv[1:] or ["all"]
     if "all" in want:
-        want = [g for g in GROUPS if g not in ("traj64v", "cli")] + ["cli"]
+        want = [g for g in GROUPS if g not in ("traj64v", "cli", "vid")] + ["cli", "vid"]
     for gname in want:
         GROUPS[gname]()
     meta = {"torch": torch.__version__, "threads": 1, "numpy": np.__version__,
