@@ -13,6 +13,7 @@ reliability PNGs under <output_dir>/flow, as the reference's flow networks leave
 loop runs: warped previous result as initialisation and as pixel-level temporal target (sequential, one rank).
 `img_vid` (README of the reference: "not sure if this is actually working") is not provided.
 """
+import concurrent.futures
 import glob
 import math
 import os
@@ -161,6 +162,14 @@ def _vid_img_flow(args, output_dir, frames, style_images_big, content_size):
         th.cuda.empty_cache()
 
 
+def _finish_frame(out, content, path, original_colors):
+    """Writing one finished frame (reference style.py:294-297): deprocess, optional colour transfer, PNG."""
+    disp = load.deprocess(out.clone())
+    if original_colors == 1:
+        disp = load.original_colors(load.deprocess(content.clone()), disp)
+    disp.save(path)
+
+
 def vid_img(args):
     """Per-frame stylisation.  With a flow cache under <output_dir>/flow the reference's temporally consistent loop
     runs (sequential, rank 0); without one the frames are independent and are sharded over the ranks of the job."""
@@ -180,6 +189,7 @@ def vid_img(args):
     passes = max(1, args.passes_per_scale)
 
     prev_size = None
+    writer, pending = concurrent.futures.ThreadPoolExecutor(max_workers=2), {}
     for size_n, (current_size, num_iters) in enumerate(zip(args.image_sizes, args.num_iters)):
         print("\nCurrent size {}px".format(current_size))
         os.makedirs(output_dir + "/" + str(current_size), exist_ok=True)
@@ -206,17 +216,20 @@ def vid_img(args):
                 else:  # previous result of this frame: last pass of the previous size, or previous pass of this size
                     src = ("%s/%s/%s_%s.png" % (output_dir, prev_size, passes, name(frame)) if pass_n == 0 else
                            "%s/%s/%s_%s.png" % (output_dir, current_size, pass_n, name(frame)))
+                    if src in pending:  # still being written by the background writer
+                        pending.pop(src).result()
                     pastiche = F.interpolate(load.preprocess(src), size=content.size()[2:], mode="bilinear",
                                              align_corners=False)
                 out = optim.optimize(content, style_images, pastiche, num_iters // passes, args, net, losses)
-                out = match_histogram(out.detach().cpu(), style_images_big[0], mode=args.match_histograms)
-                disp = load.deprocess(out.clone())
-                if args.original_colors == 1:
-                    disp = load.original_colors(load.deprocess(content.clone()), disp)
-                disp.save(str(args.output))
+                out = match_histogram(out.detach().cpu(), style_images_big[0], mode=args.match_histograms)  # global RNG: stays here
+                # deprocessing and PNG encoding of this frame run beside the next frame's optimisation
+                pending[str(args.output)] = writer.submit(_finish_frame, out, content, str(args.output), args.original_colors)
         prev_size = current_size
         del net
         th.cuda.empty_cache()
+    for fut in pending.values():  # surface any error of the background writer
+        fut.result()
+    writer.shutdown()
     dist.barrier()
 
 
