@@ -113,26 +113,32 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
     const int in_plane = p.H * p.W;
     const int64_t out_plane = (int64_t)p.OH * p.OW;
     const float* __restrict__ xin = p.x + (int64_t)n * p.Cin * in_plane;
-    // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin by linear id, so XCD k takes the k-th contiguous
-    // band of tiles (row-major) and the halo rows / columns that neighbouring tiles share are hits in ITS L2
+    // Persistent workgroups with an XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin by linear id, so
+    // XCD k owns the k-th contiguous band of tiles (row-major; halo rows / columns shared by neighbouring tiles are hits
+    // in ITS L2) and workgroup `slot` of that XCD walks the band with stride `slots`.  The K loop below runs over the
+    // flattened (tile, chunk) sequence: the first chunk of the next tile is prefetched behind the last chunk of the
+    // current one, so prologue, epilogue and workgroup turn-around are paid once per workgroup, not once per tile
+    // (measured before: 17 us per 38 us of K loop on conv1_2).
     const int tiles_total = p.tiles_x * ((p.OH + X6_PH - 1) / X6_PH);
     const int per_xcd = (tiles_total + 7) >> 3;
-    const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (tile >= tiles_total) return;  // grid.x is rounded up to a multiple of 8 (whole workgroup leaves: no barrier is skipped)
-    const int x0 = (tile % p.tiles_x) * 32, y0 = (tile / p.tiles_x) * X6_PH;
+    const int slots = gridDim.x >> 3;  // grid.x is a multiple of 8
+    const int band_hi = min(((int)(blockIdx.x & 7) + 1) * per_xcd, tiles_total);
+    int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= band_hi) return;  // whole workgroup leaves: no barrier is skipped
 
-    // staging descriptor of this thread's patch position: a 32-bit byte offset inside a channel plane (clamped into the
-    // image; positions in the zero padding are blanked when the chunk is written to LDS)
+    // staging descriptor of this thread's patch position for the tile being STAGED (the current tile, or the next one while
+    // its first chunk is prefetched): a 32-bit byte offset inside a channel plane (clamped into the image; positions in the
+    // zero padding are blanked when the chunk is written to LDS)
     unsigned p_byte = 0;
     bool pos_ok = false;
-    if (tid < X6_NPOS) {
+    auto set_stage = [&](int t) {
+        const int x0 = (t % p.tiles_x) * 32, y0 = (t / p.tiles_x) * X6_PH;
         const int r = tid / X6_PC, col = tid - r * X6_PC;
         const int iy = y0 + r - p.pad, ix = x0 + col - p.pad;
-        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
-            p_byte = (unsigned)(iy * p.W + ix) * 4u;
-            pos_ok = true;
-        }
-    }
+        pos_ok = tid < X6_NPOS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        p_byte = pos_ok ? (unsigned)(iy * p.W + ix) * 4u : 0u;
+    };
+    set_stage(tile);
     float rp[8];
     int rp_c0 = 0;  // first channel of the chunk held in rp
     auto load_patch = [&](int c0) {
@@ -177,6 +183,7 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
     // half B = taps 4-8 (pieces 12-26, read by k-steps 2-4).  Every wave issues exactly 3 (A) or 4 (B) LDS-DMA
     // instructions so that the counted vmcnt waits below are the same for all waves (wave 3 repeats piece 26).
     const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned lane16 = lane * 16;
     auto dma_half = [&](int ch, bool second) {
         const unsigned char* src = bank + ((int64_t)ch * ntile + cotile) * X6_W_BYTES;
         const int first = second ? 12 : 0, count = second ? 4 : 3, last = second ? 26 : 11;
@@ -184,12 +191,13 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
             const int q = min(first + wv + 4 * i, last);
             // LDS-DMA issued from inline asm so that hipcc does not drain it with vmcnt(0) at the next ds_read
             // (cdna_hip_programming.md §5.7; M0 = wave-uniform LDS byte address, lane i lands at M0 + 16*i)
-            const unsigned char* g = src + q * 1024 + lane * 16;
+            // scalar base + 32-bit lane offset: no per-lane 64-bit address to keep (or spill) across the loop
+            const unsigned char* g = src + q * 1024;
             const unsigned lds_dst = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(Wl + q * 1024);
             unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep)
-                         : "v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_dst))
+                         : "v"(lane16), "s"(__builtin_amdgcn_readfirstlane(lds_dst)), "s"(g)
                          : "memory");
         }
     };
@@ -207,18 +215,22 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
     // two-level accumulation (TL): fold the running sums into a master accumulator (plain fp32 VALU adds, round to
     // nearest) every FLUSH chunks so that no MFMA accumulation chain is longer than FLUSH*5*6 additions
     constexpr int FLUSH = 1;  // measured: 1 halves the pixel-gradient error of 4 (the bf16 MFMA adder truncates toward zero)
-    // The accumulators start from the bias (loaded here, behind the prologue's memory latency) instead of zero, so the
-    // epilogue has no dependent loads.  Split-K partial sums start from zero: the finish kernel adds the bias once.
+    // The accumulators start from the bias (loaded behind the prologue's / the previous epilogue's memory latency) instead
+    // of zero, so the epilogue has no dependent loads.  Split-K partial sums start from zero: the finish kernel adds the
+    // bias once.
     f32x16 acc[2], master[TL ? 2 : 1];
-    {
+    auto init_acc = [&]() {
         const bool with_bias = p.bias != nullptr && p.ksplit <= 1;  // wave-uniform
+        const float* bias = p.bias;
+        int cbase = co0;
+        asm volatile("" : "+s"(bias), "+s"(cbase));  // opaque: 32 hoisted per-lane addresses would live across the tile loop
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = co0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int co = cbase + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 float b0 = 0.f;
-                if (with_bias) b0 = p.bias[min(co, p.Cout - 1)];
+                if (with_bias) b0 = bias[min(co, p.Cout - 1)];
                 if constexpr (TL) {
                     master[t][r] = b0;
                     acc[t][r] = 0.f;
@@ -226,7 +238,8 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
                     acc[t][r] = b0;
                 }
             }
-    }
+    };
+    init_acc();
 
     auto kstep = [&](int s) {
         bf16x8 b[3], a[2][3];
@@ -270,6 +283,7 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
 #ifdef MAUA_X6_STAMP  // diagnostic build only (tools/x6_clock.py): shader clock = d(s_memtime) / d(s_memrealtime) x 100 MHz
     const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long st_w[6] = {0, 0, 0, 0, 0, 0}, st_t;
+    int st_chunks = 1;
 #define ST_BEGIN() st_t = __builtin_amdgcn_s_memtime()
 #define ST_END(i) st_w[i] += __builtin_amdgcn_s_memtime() - st_t
 #else
@@ -280,86 +294,27 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
     // the arbiter always prefers the same (oldest) wave of a SIMD, which then finishes ~20 % early and leaves the matrix
     // pipe to fewer and fewer waves; measured on conv4_2 the last wave ended 139 us after the first.
     const int tg_slot = (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 16 << 6 | 4) & 3);  // hwreg(HW_REG_HW_ID, 16, 4)
-    for (int ch = ch_begin; ch < nchunks; ++ch) {
-        const bool more = ch + 1 < nchunks;
-        switch ((tg_slot + ch) & 3) {
-            case 0: __builtin_amdgcn_s_setprio(0); break;
-            case 1: __builtin_amdgcn_s_setprio(1); break;
-            case 2: __builtin_amdgcn_s_setprio(2); break;
-            default: __builtin_amdgcn_s_setprio(3); break;
-        }
-        if (more) load_patch((ch + 1) * 8);
-        kstep(0);
-        kstep(1);
-        // B(ch) must have landed (all waves) before k-step 2; A(ch)'s readers are done after this barrier
-        ST_BEGIN();
-        if (more) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        ST_END(0);
-        ST_BEGIN();
-        __builtin_amdgcn_s_barrier();
-        ST_END(1);
-        if (more) dma_half(ch + 1, false);
-        kstep(2);
-        kstep(3);
-        kstep(4);
-        if (more) split_patch();
-        if constexpr (TL) {
-            if (((ch - ch_begin) & (FLUSH - 1)) == FLUSH - 1 || !more) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        master[t][r] += acc[t][r];
-                        acc[t][r] = 0.f;
-                    }
-            }
-        }
-        ST_BEGIN();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // X2: every wave is done reading the patch and half B
-        ST_END(2);
-        if (more) {
-            ST_BEGIN();
-            write_patch();
-            dma_half(ch + 1, true);
-            ST_END(3);
-            ST_BEGIN();
-            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");  // A(ch+1) landed, patch writes done
-            ST_END(4);
-            ST_BEGIN();
-            __builtin_amdgcn_s_barrier();  // X3
-            ST_END(5);
-        }
-    }
-
-#ifdef MAUA_X6_STAMP
-    if (p.ws && p.ksplit <= 1 && lane == 0) {  // the stamps go to a buffer nothing else reads
-        const unsigned long long st_c1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
-        unsigned long long* st = reinterpret_cast<unsigned long long*>(p.ws) +
-                                 2 * (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x * 4 + blockIdx.x * 4 + wave);
-        st[0] = st_c1 - st_c0;
-        st[1] = st_r1 - st_r0;
-        st[2 * (size_t)gridDim.x * gridDim.y * gridDim.z * 4] = st_r0;      // absolute 100 MHz stamps: second / third planes
-        st[4 * (size_t)gridDim.x * gridDim.y * gridDim.z * 4] = st_r1;
-        st[2 * (size_t)gridDim.x * gridDim.y * gridDim.z * 4 + 1] = st_enter;
-        for (int i = 0; i < 6; ++i) st[2 * (4 + i) * (size_t)gridDim.x * gridDim.y * gridDim.z * 4] = st_w[i];
-    }
-#endif
-    // epilogue: lane holds pixel column j of row y0+wave; register r is output channel (r&3)+8*(r>>2)+4*half of block t
-    float* __restrict__ yout = p.y + (int64_t)n * p.Cout * out_plane;
-    const float* __restrict__ om = p.omask ? p.omask + (int64_t)n * p.Cout * out_plane : nullptr;
+    // epilogue of one tile: lane holds pixel column j of row y0+wave; register r is output channel (r&3)+8*(r>>2)+4*half of
+    // block t.  No LDS access, so it can run while the next tile's first chunk is already staged.
+    auto epilogue = [&](int t_done) {
+    const int x0 = (t_done % p.tiles_x) * 32, y0 = (t_done / p.tiles_x) * X6_PH;
+    // opaque copy: keeps the per-channel address arithmetic inside the epilogue (hoisted out of the tile loop it costs 64
+    // live 64-bit values, i.e. spills)
+    long long oplane = out_plane;
+    asm volatile("" : "+s"(oplane));
+    float* __restrict__ yout = p.y + (int64_t)n * p.Cout * oplane;
+    const float* __restrict__ om = p.omask ? p.omask + (int64_t)n * p.Cout * oplane : nullptr;
     const int oy = y0 + wave, ox = x0 + j;
     const bool pvalid = oy < p.OH && ox < p.OW;
     const int64_t opix = (int64_t)oy * p.OW + ox;
     if (p.ksplit > 1) {  // split-K: raw partial sums, finished by x6_splitk_finish_kernel in split order
-        float* wsp = p.ws + (int64_t)blockIdx.z * p.Cout * out_plane;
+        float* wsp = p.ws + (int64_t)blockIdx.z * p.Cout * oplane;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (pvalid && co < p.Cout) wsp[(int64_t)co * out_plane + opix] = TL ? master[t][r] : acc[t][r];
+                if (pvalid && co < p.Cout) wsp[(int64_t)co * oplane + opix] = TL ? master[t][r] : acc[t][r];
             }
         return;
     }
@@ -367,7 +322,7 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
     // wave-uniform channel offsets: a store costs one 64-bit add, no multiplies, no branch.
     if (pvalid) {
         const bool full = co0 + X6_COT <= p.Cout;  // wave-uniform: every channel of the tile exists
-        const int64_t lane_off = (int64_t)(co0 + 4 * half) * out_plane + opix;
+        const int64_t lane_off = (int64_t)(co0 + 4 * half) * oplane + opix;
         float* __restrict__ yl = yout + lane_off;
         const float* __restrict__ oml = OM ? om + lane_off : nullptr;
 #pragma unroll
@@ -378,7 +333,7 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int cr = t * 32 + (r & 3) + 8 * (r >> 2);  // compile-time channel offset inside the tile
-                const int64_t o = (full || co0 + cr + 4 * half < p.Cout) ? (int64_t)cr * out_plane : 0;
+                const int64_t o = (full || co0 + cr + 4 * half < p.Cout) ? (int64_t)cr * oplane : 0;
                 // compile-time switches: with run-time flags hipcc branches around every load and waits for each one
                 prev[r] = 0.f;
                 msk[r] = 1.f;
@@ -395,16 +350,100 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
             }
             if (full) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) yl[(int64_t)(t * 32 + (r & 3) + 8 * (r >> 2)) * out_plane] = outv[r];
+                for (int r = 0; r < 16; ++r) yl[(int64_t)(t * 32 + (r & 3) + 8 * (r >> 2)) * oplane] = outv[r];
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int cr = t * 32 + (r & 3) + 8 * (r >> 2);
-                    if (co0 + cr + 4 * half < p.Cout) yl[(int64_t)cr * out_plane] = outv[r];
+                    if (co0 + cr + 4 * half < p.Cout) yl[(int64_t)cr * oplane] = outv[r];
                 }
             }
         }
     }
+    };
+    int ch = ch_begin;
+    for (;;) {
+        const bool last = ch + 1 >= nchunks;          // last chunk of the current tile
+        const int ntile = tile + slots;               // next tile of this workgroup
+        const bool more = !last || ntile < band_hi;   // there is a chunk to prefetch
+        const int nch = last ? ch_begin : ch + 1;     // ... this one (of `ntile` when `last`)
+        switch ((tg_slot + ch) & 3) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
+        if (more) {
+            if (last) set_stage(ntile);
+            load_patch(nch * 8);
+        }
+        kstep(0);
+        kstep(1);
+        // B(ch) must have landed (all waves) before k-step 2; A(ch)'s readers are done after this barrier.  vmcnt(8) leaves
+        // only the 8 patch loads above in flight: everything older (B(ch), a previous tile's epilogue stores) is waited for.
+        ST_BEGIN();
+        if (more) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        ST_END(0);
+        ST_BEGIN();
+        __builtin_amdgcn_s_barrier();
+        ST_END(1);
+        if (more) dma_half(nch, false);
+        kstep(2);
+        kstep(3);
+        kstep(4);
+        if (more) split_patch();
+        if constexpr (TL) {  // FLUSH = 1: fold every chunk
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    master[t][r] += acc[t][r];
+                    acc[t][r] = 0.f;
+                }
+        }
+        ST_BEGIN();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // X2: every wave is done reading the patch and half B
+        ST_END(2);
+        if (more) {
+            ST_BEGIN();
+            write_patch();
+            dma_half(nch, true);
+            ST_END(3);
+            ST_BEGIN();
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");  // A(next) landed, patch writes done
+            ST_END(4);
+            ST_BEGIN();
+            __builtin_amdgcn_s_barrier();  // X3
+            ST_END(5);
+        }
+        if (last) {
+            epilogue(tile);
+            if (!more) break;
+            tile = ntile;
+            init_acc();
+        }
+        ch = nch;
+#ifdef MAUA_X6_STAMP
+        ++st_chunks;
+#endif
+    }
+
+#ifdef MAUA_X6_STAMP
+    if (p.ws && p.ksplit <= 1 && lane == 0) {  // the stamps go to a buffer nothing else reads
+        const unsigned long long st_c1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(p.ws) +
+                                 2 * (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x * 4 + blockIdx.x * 4 + wave);
+        st[0] = st_c1 - st_c0;
+        st[1] = st_r1 - st_r0;
+        st[2 * (size_t)gridDim.x * gridDim.y * gridDim.z * 4] = st_r0;      // absolute 100 MHz stamps: second / third planes
+        st[4 * (size_t)gridDim.x * gridDim.y * gridDim.z * 4] = st_r1;
+        st[2 * (size_t)gridDim.x * gridDim.y * gridDim.z * 4 + 1] = st_enter;
+        for (int i = 0; i < 6; ++i) st[2 * (4 + i) * (size_t)gridDim.x * gridDim.y * gridDim.z * 4] = st_w[i];
+        st[6 * (size_t)gridDim.x * gridDim.y * gridDim.z * 4 + 1] = (unsigned long long)st_chunks;
+    }
+#endif
 #ifdef MAUA_X6_STAMP
     if (p.ws && p.ksplit <= 1 && lane == 0) {
         const unsigned long long st_issued = __builtin_amdgcn_s_memrealtime();
@@ -436,7 +475,16 @@ int conv_x6_launch(const ConvArgs& a, int n, hipStream_t stream) {
     ks = 1;  // the workspace is the stamp buffer in the diagnostic build
 #endif
     p.ksplit = ks;
-    dim3 grid((unsigned)(((tiles + 7) / 8) * 8), (unsigned)((a.Cout + X6_COT - 1) / X6_COT), (unsigned)(n * ks));
+    // Persistent workgroups: enough of them to fill the chip once (4 per CU x 256 CUs), each walking several tiles of its
+    // XCD band; MAUA_X6_PERSIST=0 launches one workgroup per tile instead (A/B switch).
+    const int64_t cot = (a.Cout + X6_COT - 1) / X6_COT, per_xcd = (tiles + 7) / 8;
+    static const bool persist = !(getenv("MAUA_X6_PERSIST") && atoi(getenv("MAUA_X6_PERSIST")) == 0);
+    int64_t g8 = per_xcd;
+    if (persist) {
+        g8 = (1024 + cot * n * ks * 8 - 1) / (cot * n * ks * 8);
+        g8 = g8 < 1 ? 1 : (g8 > per_xcd ? per_xcd : g8);
+    }
+    dim3 grid((unsigned)(g8 * 8), (unsigned)cot, (unsigned)(n * ks));
     const bool tl = (a.Cin + 7) / 8 > 4, acc = ks == 1 && a.accumulate != 0, om = ks == 1 && a.omask != nullptr;
 #define MAUA_X6_LAUNCH(TL_, ACC_, OM_)                                                                      \
     do {                                                                                                    \

@@ -34,7 +34,12 @@ vp = ctypes.c_void_p
 assert L.maua_conv_pack_filters_x6(vp(w.data_ptr()), vp(bank.data_ptr()), None, cout, cin, None) == 0
 y = torch.empty(1, cout, H, H, device="cuda")
 tiles = ((H + 31) // 32) * ((H + 3) // 4)
-nwg = ((tiles + 7) // 8 * 8) * ((cout + 63) // 64)
+cot = (cout + 63) // 64
+per_xcd = (tiles + 7) // 8
+g8 = min(per_xcd, max(1, -(-1024 // (cot * 8))))  # the launcher's persistent grid (conv_x6_launch)
+if os.environ.get("MAUA_X6_PERSIST") == "0":
+    g8 = per_xcd
+nwg = g8 * 8 * cot
 stamps = torch.zeros(nwg * 4 * 2 * 10, dtype=torch.int64, device="cuda")
 
 
@@ -60,14 +65,14 @@ for _ in range(20):
 e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / 20
-allp = stamps.view(10, -1, 2).cpu()
+allp = stamps.view(10, -1, 2).cpu()  # planes of nwg*4 (wave) entries; the kernel indexes them with ITS grid size
 s = allp[0]
 live = s[:, 1] > 0
 r0, r1 = allp[1][:, 0][live].double(), allp[2][:, 0][live].double()
 s = s[live]
 clk = (s[:, 0].double() / s[:, 1].double() * 0.1)  # GHz
 cyc = s[:, 0].double()
-nchunks = (cin + 7) // 8
+nchunks = int(allp[3][:, 1][live].double().median())  # chunks this wave went through (all its tiles)
 mfma_cycles = nchunks * 60 * 32
 print(f"x6 {cin}->{cout} @{H}: {us:.1f} us/launch after {n} launches; waves stamped {len(s)}")
 print(f"  shader clock (median over waves) {clk.median():.3f} GHz  [p10 {clk.quantile(0.1):.3f}, p90 {clk.quantile(0.9):.3f}]")
