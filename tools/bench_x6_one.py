@@ -13,6 +13,11 @@ cin, cout, H = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 x = torch.randn(1, cin, H, H, device="cuda")
 w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
+if os.environ.get("X6_ZERO") == "1":  # DVFS probe: same instruction stream on all-zero operands (MI355X_MICROARCH.md, DVFS item 1)
+    x.zero_()
+    w.zero_()
+if os.environ.get("X6_ZERO") == "x":
+    x.zero_()
 f6, b6 = hip.conv_pack_filters_x6(w)
 y = torch.empty(1, cout, H, H, device="cuda")
 for _ in range(3):
