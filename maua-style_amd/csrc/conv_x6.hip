@@ -9,7 +9,7 @@
 //
 // Geometry: workgroup = 4 waves = 64 output channels x (4 rows x 32 px); wave = 64 co x one 32-px row (two 32x32
 // accumulators).  K is consumed in chunks of 8 input channels; one MFMA k-step (K = 16) = two taps x 8 channels (lane
-// half h takes tap 2s+h; the ninth tap pairs with a zero A operand).  LDS holds ONE chunk: three bf16 images of the
+// half h takes tap 2s+h; the ninth tap runs alone at K = 8, v_mfma_f32_32x32x8_bf16_1k).  LDS holds ONE chunk: three bf16 images of the
 // patch [part][pos][8ch] (16 B per position: conflict-free b128 reads and writes) and the filter slice
 // [tap][co][part][8ch] (48-byte lane stride: conflict-free) = 37.6 KB, so four workgroups share a CU (4 waves/SIMD)
 // and hide each other's barriers.  The filter bank is pre-split on the device once (maua_conv_pack_filters_x6) in
@@ -92,12 +92,9 @@ __global__ void pack_x6_kernel(const float* __restrict__ w, unsigned short* __re
 
 template <bool TL, bool ACC, bool OM, bool C8>
 __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
-    constexpr int ZERO_BYTES = (32 * 3 + 3) * 16;  // what a lane's A reads of one k-step span: (t*32*3 + part)*16 + 16
-    __shared__ __attribute__((aligned(16))) unsigned char smem[X6_PATCH_BYTES + X6_W_BYTES + ZERO_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[X6_PATCH_BYTES + X6_W_BYTES];
     unsigned char* Pl = smem;                    // [part][pos][16 B]
     unsigned char* Wl = smem + X6_PATCH_BYTES;   // [tap][co][part][16 B]
-    // zero block behind the filters: A operand of the upper lane half in the fifth k-step (the ninth tap has no partner)
-    for (int i = threadIdx.x * 4; i < ZERO_BYTES; i += 256 * 4) *reinterpret_cast<unsigned*>(Wl + X6_W_BYTES + i) = 0u;
 
 #ifdef MAUA_X6_STAMP
     const unsigned long long st_enter = __builtin_amdgcn_s_memrealtime();
@@ -209,8 +206,13 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
         const int tap = min(2 * s + half, 8);
         const int ky = tap / 3, kx = tap - 3 * ky;
         b_byte[s] = ((wave + ky) * X6_PC + j + kx) * 16;
-        a_byte[s] = (2 * s + half > 8) ? X6_W_BYTES : ((tap * X6_COT + j) * 3) * 16;
+        a_byte[s] = ((tap * X6_COT + j) * 3) * 16;
     }
+    // the ninth tap has no partner: it runs alone at K = 8 (v_mfma_f32_32x32x8_bf16_1k), lane half h taking channels
+    // 4h..4h+3 of that tap.  Same cycles as a K = 16 step padded with zeros, but 8-byte fragment reads and half the
+    // multipliers switching: the kernel is power-bound, measured -2 % time.
+    b_byte[4] = ((wave + 2) * X6_PC + j + 2) * 16 + half * 8;
+    a_byte[4] = ((8 * X6_COT + j) * 3) * 16 + half * 8;
 
     // two-level accumulation (TL): fold the running sums into a master accumulator (plain fp32 VALU adds, round to
     // nearest) every FLUSH chunks so that no MFMA accumulation chain is longer than FLUSH*5*6 additions
@@ -241,6 +243,27 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
     };
     init_acc();
 
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    auto kstep_tap9 = [&]() {
+        s16x4 b[3], a[2][3];
+#pragma unroll
+        for (int part = 0; part < 3; ++part)
+            b[part] = *reinterpret_cast<const s16x4*>(Pl + part * X6_NPOS_PAD * 16 + b_byte[4]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int part = 0; part < 3; ++part)
+                a[t][part] = *reinterpret_cast<const s16x4*>(Wl + a_byte[4] + (t * 32 * 3 + part) * 16);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a[t][2], b[0], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a[t][1], b[1], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a[t][0], b[2], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a[t][1], b[0], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a[t][0], b[1], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a[t][0], b[0], acc[t], 0, 0, 0);
+        }
+    };
     auto kstep = [&](int s) {
         bf16x8 b[3], a[2][3];
 #pragma unroll
@@ -391,7 +414,7 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
         if (more) dma_half(nch, false);
         kstep(2);
         kstep(3);
-        kstep(4);
+        kstep_tap9();
         if (more) split_patch();
         if constexpr (TL) {  // FLUSH = 1: fold every chunk
 #pragma unroll
