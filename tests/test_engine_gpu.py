@@ -305,3 +305,65 @@ def test_temporal_trajectory_vs_fp64_arbiter(weight_files, opt):
     floor = rel_l2(g[f"{opt}_N{N}_f32"], g[f"{opt}_N{N}_f64"])
     err = rel_l2(out, g[f"{opt}_N{N}_f64"])
     assert err <= max(1e-3, 2 * floor), (err, floor)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# SURVEY 8(f)-4 at module level: loss modules on a batch of B = 2 frames (static + dynamic style terms)
+# ---------------------------------------------------------------------------------------------------------
+def batch_inputs(B=2, C=16, H=12, W=10):
+    """Same construction as tools/make_golden.py::batch_inputs."""
+    g = torch.Generator().manual_seed(41)
+    style_feats = torch.relu(torch.randn(B, C, H, W, generator=g))
+    feats = torch.relu(torch.randn(B, C, H, W, generator=g))
+    content_feats = torch.relu(torch.randn(1, C, H, W, generator=g))
+    return style_feats, feats, content_feats
+
+
+@pytest.mark.parametrize("cov", [False, True])
+@pytest.mark.parametrize("norm", [False, True])
+def test_style_loss_module_on_two_frames(cov, norm):
+    import loss
+    g = gold("loss_modules_B2")
+    style_feats, feats, _ = batch_inputs()
+    m = loss.StyleLoss(100.0, use_covariance=cov, normalize=norm, video_style_factor=100)
+    m.name, m.blend_weight = "style 4", 1.0
+    m.mode = "capture"
+    m(style_feats.cuda())
+    tag = f"cov{int(cov)}_norm{int(norm)}"
+    assert rel_l2(m.target.cpu(), g[f"style_target_{tag}"]) <= 1e-5
+    assert rel_l2(m.video_target.cpu(), g[f"style_video_target_{tag}"]) <= 1e-5
+    m.mode = "loss"
+    m.loss = 0
+    x = feats.cuda().requires_grad_(True)
+    m(x)
+    m.loss.backward()
+    want = float(g[f"style_loss_{tag}"])
+    assert abs(float(m.loss) - want) <= 1e-4 * abs(want)
+    assert rel_l2(x.grad.cpu(), g[f"style_grad_{tag}"]) <= 1e-4
+
+
+@pytest.mark.parametrize("norm", [False, True])
+def test_content_loss_module_on_two_frames(norm):
+    import loss
+    g = gold("loss_modules_B2")
+    _, feats, content_feats = batch_inputs()
+    c = loss.ContentLoss(5.0, normalize=norm)
+    c.name = "cont 29"
+    c.mode = "capture"
+    c(content_feats.cuda())
+    c.mode = "loss"
+    x = feats.cuda().requires_grad_(True)
+    c(x)
+    c.loss.backward()
+    want = float(g[f"content_loss_norm{int(norm)}"])
+    assert abs(float(c.loss) - want) <= 1e-5 * abs(want)
+    assert rel_l2(x.grad.cpu(), g[f"content_grad_norm{int(norm)}"]) <= 1e-5
+
+
+def test_gram_matrix_module_on_two_frames():
+    import loss
+    g = gold("loss_modules_B2")
+    _, feats, _ = batch_inputs()
+    gm = loss.GramMatrix()
+    assert rel_l2(gm(feats.cuda()).cpu(), g["gram_b2"]) <= 1e-5
+    assert rel_l2(gm(feats.cuda(), use_covariance=True).cpu(), g["gram_b2_cov"]) <= 1e-5

@@ -681,7 +681,55 @@ def gen_temporal():
     save("flow_warp_map", flow=flow, flo_file_bytes=raw, image=img.numpy(), warped=warped.numpy(), **maps)
 
 
-GROUPS = {"vid": gen_vid, "temporal": gen_temporal, "cli": gen_cli, "traj64v": gen_traj_variants64, "feval": gen_feval, "traj": gen_traj, "nin": gen_nin, "hist": gen_hist, "host": gen_host}
+def batch_inputs(B=2, C=16, H=12, W=10):
+    g = torch.Generator().manual_seed(41)
+    style_feats = torch.relu(torch.randn(B, C, H, W, generator=g))
+    feats = torch.relu(torch.randn(B, C, H, W, generator=g))
+    content_feats = torch.relu(torch.randn(1, C, H, W, generator=g))
+    return style_feats, feats, content_feats
+
+
+def gen_batch():
+    """SURVEY 8(f)-4 at module level: StyleLoss static + dynamic terms and ContentLoss on a batch of B = 2 frames
+    (loss.py:32-64, 141-181), the reference's modules driven directly."""
+    print("[batch] loss modules on B = 2 frames")
+    style_feats, feats, content_feats = batch_inputs()
+    res = {}
+    for cov in (False, True):
+        for norm in (False, True):
+            m = ref_loss.StyleLoss(100.0, use_covariance=cov, normalize=norm, video_style_factor=100)
+            m.name, m.blend_weight = "style 4", 1.0
+            m.mode = "capture"
+            m(style_feats)
+            m.mode = "loss"
+            m.loss = 0
+            x = feats.clone().requires_grad_(True)
+            m(x)
+            m.loss.backward()
+            tag = f"cov{int(cov)}_norm{int(norm)}"
+            res[f"style_loss_{tag}"] = np.float64(float(m.loss.detach()))
+            res[f"style_grad_{tag}"] = x.grad.numpy().copy()
+            res[f"style_target_{tag}"] = m.target.numpy().copy()
+            res[f"style_video_target_{tag}"] = m.video_target.numpy().copy()
+            print(f"    {tag}: loss {float(m.loss.detach()):.6e}  target {tuple(m.target.shape)}  video_target {tuple(m.video_target.shape)}")
+    for norm in (False, True):
+        c = ref_loss.ContentLoss(5.0, normalize=norm)
+        c.name = "cont 29"
+        c.mode = "capture"
+        c(content_feats)
+        c.mode = "loss"
+        x = feats.clone().requires_grad_(True)
+        c(x)
+        c.loss.backward()
+        res[f"content_loss_norm{int(norm)}"] = np.float64(float(c.loss.detach()))
+        res[f"content_grad_norm{int(norm)}"] = x.grad.numpy().copy()
+    gm = ref_loss.GramMatrix()
+    res["gram_b2"] = gm(feats).numpy().copy()
+    res["gram_b2_cov"] = gm(feats, use_covariance=True).numpy().copy()
+    save("loss_modules_B2", **res)
+
+
+GROUPS = {"batch": gen_batch, "vid": gen_vid, "temporal": gen_temporal, "cli": gen_cli, "traj64v": gen_traj_variants64, "feval": gen_feval, "traj": gen_traj, "nin": gen_nin, "hist": gen_hist, "host": gen_host}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
