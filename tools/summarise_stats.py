@@ -1,0 +1,26 @@
+"""rocprofv3 kernel_stats.csv -> markdown table (profiles/rocprof_r01_summary.md).
+    python tools/summarise_stats.py STATS.csv ITERATIONS > profiles/rocprof_r01_summary.md"""
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+iters = int(sys.argv[2])
+print("# rocprofv3 --kernel-trace --stats, round 1 (final state of the round)\n")
+print("Command (on the MI355X box, from /tmp with TMPDIR=/tmp):")
+print("`rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_final -o fin -- python3 bench.py --steps 20 --warmup 2 "
+      "--no_cpu_baseline --no_hip_graph`")
+print(f"({iters} iterations in total: 100 history-filling + 2 warm-up + 20 timed; 1024x1024, L-BFGS, eager launches so that every kernel "
+      "appears under its own name; the JSON line of this run is `bench_r01_under_rocprof.json`, the unprofiled runs "
+      "`bench_r01_final_1024_lbfgs.json` (hipGraph replay, the product default) and `bench_r01_final_1024_lbfgs_eager.json`).  "
+      "The conv_x6_kernel averages here are the figures `bench.py`'s `roofline.avg_launch_ms` must agree with.\n")
+print("| kernel | calls | total ms | avg us | % | ms / iteration |")
+print("|---|---|---|---|---|---|")
+for r in rows[:28]:
+    name = r["Name"].replace("|", "\\|")
+    if len(name) > 96:
+        name = name[:96] + "..."
+    print(f"| `{name}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} | "
+          f"{float(r['Percentage']):.2f} | {float(r['TotalDurationNs']) / 1e6 / iters:.3f} |")
+print("\nPMC passes (separate `rocprofv3 --pmc` runs of `bench.py --steps 4 --warmup 1 --no_prefill --no_cpu_baseline --no_hip_graph`): "
+      "`pmc_r01_traffic.json` (memory-side request counters, L2 hit rate, SQ wait / busy counters per kernel, "
+      "`tools/pmc_summary.py`), `pmc_r01_calibration.json` (known-byte-count kernels), `pmc_r01_traffic_before_xcd_mapping.json`.")
