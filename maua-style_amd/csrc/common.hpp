@@ -59,7 +59,7 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
 // Fixed-order second stage: one workgroup sums `n` per-block partials (doubles) in index order.
 __global__ void finish_sum_kernel(const double* __restrict__ partial, int n, float scale, float* __restrict__ out);
 
-// Arguments of the MFMA implicit-GEMM convolution (conv_mfma.hip); also used by gram.hip for gf += D F.
+// Arguments of the MFMA implicit-GEMM convolution (conv_mfma2.hip, conv_x6.hip); also used by gram.hip for gf += D F.
 struct ConvArgs {
     const float* x;
     const float* mask;  // nullable: x is read as x * (mask > 0)
@@ -78,7 +78,6 @@ int conv_mfma_dispatch(const ConvArgs& a, int ks, int n, hipStream_t stream);
 int conv3x3_few_out(const ConvArgs& a, int n, hipStream_t stream);
 int conv_splitk_finish(const ConvArgs& a, int n, int ksplit, hipStream_t stream);  // y = act(bias + sum of a.ws partials) ...
 int conv_mfma2_choose_split(const ConvArgs& a, int ks, int n);                     // 1 = no split  // 3x3, stride 1, Cout <= 4 (conv_direct.hip)
-int conv_mfma2_dispatch(const ConvArgs& a, int ks, int n, hipStream_t stream);
 int conv_direct_fwd(const float* x, const float* mask, const float* wf, const float* bias, float* y, int n, int cin, int h,
                     int w, int cout, int oh, int ow, int kh, int kw, int stride, int pad, int relu, int accumulate,
                     hipStream_t stream);

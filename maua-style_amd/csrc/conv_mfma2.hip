@@ -1,5 +1,5 @@
-// Second-generation stride-1 implicit-GEMM convolution on the fp32 matrix cores (same math and tile shape as
-// conv_mfma.hip, restructured around what its profile showed: 61 % / 42 % MFMA utilisation forward / backward).
+// Stride-1 implicit-GEMM convolution on the fp32 matrix cores (second generation: the first one reached 61 % / 42 %
+// MFMA utilisation forward / backward; this is the restructuring its profile suggested).
 //
 //   * channel-interleaved LDS images: patch[pos][8] and filters[tap][co][8], where the 8 floats of a position are
 //     the chunk's 8 input channels ordered (half, cp) with channel = 2*cp + half.  One ds_read_b128 then feeds the
@@ -358,7 +358,7 @@ int conv_mfma2_choose_split(const ConvArgs& a, int ks, int n) {
     return s < 2 ? 1 : s;
 }
 
-int conv_mfma2_dispatch(const ConvArgs& a0, int ks, int n, hipStream_t stream) {
+int conv_mfma_dispatch(const ConvArgs& a0, int ks, int n, hipStream_t stream) {
     ConvArgs a = a0;
     a.ksplit = a.ws ? conv_mfma2_choose_split(a, ks, n) : 1;
     const int64_t opix = (int64_t)a.OH * a.OW;

@@ -1,6 +1,6 @@
 // Gram / covariance matrix G = scale * Fc Fc^T of a feature map F[C][HW] (reference loss.py:67-91) as a symmetric
 // rank-HW update on the fp32 matrix cores, and its backward gf (+)= D (F - mean) through the 1x1 path of
-// conv_mfma.hip.
+// conv_mfma2.hip.
 //
 // Forward: the (C/64)(C/64+1)/2 upper-triangular 64x64 tiles are split along HW over `ksplit` workgroups each
 // (split-K); every workgroup writes its partial tile to a slab and a second kernel adds the slabs in index order,
