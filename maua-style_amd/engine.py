@@ -311,6 +311,32 @@ class StyleEngine:
             hip.fill_(g[0], 0.0)
         hip.sum_small(self.slots, self.total)
 
+    def capture_content(self, x):
+        """optim.set_content_targets on the fused plan: one forward pass (convs and pools only, preallocated buffers) and
+        a copy of every content layer's activation into its module's `.target` (ContentLoss 'capture', loss.py:61-62).
+        Same kernels as the module-by-module pass, without its per-module launches and allocations."""
+        self._prepare(x)
+        a = self.act
+        a[0] = x
+        want = [s for s in self.steps if s.kind == "content" and "temporal" not in getattr(s.mod, "name", "")]
+        last = max((self.steps.index(s) for s in want), default=-1)
+        for s in self.steps[:last + 1]:
+            if s.kind == "conv":
+                if self.x6_fwd and self._x6_ok(s, s.mod.out_channels):
+                    b6, _ = s.mod.banks6()
+                    hip.conv3x3_x6(a[s.src], b6, s.mod.bias_device(), s.mod.out_channels, s.pad, s.relu, out=a[s.dst],
+                                   workspace=self.ws)
+                else:
+                    wf, _ = s.mod.banks()
+                    hip.conv2d_fwd(a[s.src], wf, s.mod.bias_device(), s.k, s.stride, s.pad, s.relu, out=a[s.dst],
+                                   workspace=self.ws)
+            elif s.kind == "relu":
+                hip.relu_(a[s.src])
+            elif s.kind == "pool":
+                hip.pool2d_fwd(a[s.src], s.k, s.stride, s.ceil, s.mode, out=a[s.dst])
+        for s in want:
+            s.mod.target = a[s.src].detach().clone()
+
     def feval(self, x, capture=False):
         """Evaluate at `x` (1,3,H,W fp32 on the GPU).  Returns (per-module loss slots in `losses` order, total
         loss, gradient) - device tensors owned by the engine, overwritten by the next call; no host sync."""

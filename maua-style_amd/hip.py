@@ -101,7 +101,12 @@ def _ptr(t):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """hipStream_t of torch's current stream on the current device.  The raw getters are ~20x cheaper than building a
+    torch.cuda.Stream object per launch (19 us, which made eager iterations at 512x512 CPU-bound)."""
+    try:
+        return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    except AttributeError:  # private API moved: the public, slower spelling
+        return torch.cuda.current_stream().cuda_stream
 
 
 def _f32(t, name):

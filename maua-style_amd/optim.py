@@ -20,6 +20,7 @@ import config as config_mod
 import engine as engine_mod
 import hip
 import models
+from utils import limit_host_threads
 
 PBAR = tqdm.tqdm(file=sys.stdout, smoothing=0.1, disable=not sys.stdout.isatty())
 
@@ -33,13 +34,33 @@ def _device_image(image, args):
     return image.to(device="cuda", dtype=th.float32).contiguous()
 
 
+def _engine_of(net):
+    """The fused engine of a loss network (built once per network; None when its module layout is not covered)."""
+    eng = getattr(net, "_maua_engine", None)
+    if eng is None and not getattr(net, "_maua_engine_refused", False):
+        try:
+            eng = engine_mod.StyleEngine(net, net.content_losses + net.style_losses + net.tv_losses + net.temporal_losses)
+            net._maua_engine = eng
+        except (engine_mod.UnsupportedNet, AttributeError):
+            net._maua_engine_refused = True
+    return eng
+
+
 def set_content_targets(net, content_image, args):
     """One forward pass with the content modules in 'capture' mode (reference optim.py:22-32)."""
     _describe("Capturing content targets...", args)
+    image = _device_image(content_image, args)
+    eng = _engine_of(net)
+    if eng is not None and image.shape[0] == 1:
+        try:
+            eng.capture_content(image)
+            return
+        except engine_mod.UnsupportedNet:
+            pass
     for mod in net.content_losses:
         mod.mode = "capture"
     with th.no_grad():
-        net(_device_image(content_image, args))
+        net(image)
     for mod in net.content_losses:
         mod.mode = "none"
 
@@ -110,10 +131,13 @@ def lbfgs_moves(num_iters):
     return num_iters
 
 
+GRAPH_MIN_ITERS = 128
+
+
 class PixelOptimizer:
     """The iteration loop for one image: fused feval + device-side optimizer step."""
 
-    def __init__(self, net, losses, init, args):
+    def __init__(self, net, losses, init, args, planned_iters=None):
         self.args = args
         try:
             self.engine = getattr(net, "_maua_engine", None) or engine_mod.StyleEngine(net, losses)
@@ -132,8 +156,13 @@ class PixelOptimizer:
             raise ValueError(f"unknown optimizer {self.kind}")
         # The whole iteration (25+ convolutions, Grams, losses, the optimiser sweeps: ~120 launches, every scalar on the
         # device) is replayed from one captured hipGraph.  MAUA_HIP_GRAPH=0 or an attached engine timer runs it eagerly.
+        # Capturing costs ~30 ms (torch synchronises, collects garbage and empties its cache around a capture) and a replay
+        # saves ~0.25 ms of launch gaps per iteration: runs shorter than GRAPH_MIN_ITERS (vid_img's 25-50 iterations per
+        # call) launch eagerly.
         hg = getattr(args, "hip_graph", None)
-        self.use_graph = (os.environ.get("MAUA_HIP_GRAPH", "1") != "0") if hg is None else bool(hg)
+        if hg is None:
+            hg = os.environ.get("MAUA_HIP_GRAPH", "1") != "0" and (planned_iters is None or planned_iters >= GRAPH_MIN_ITERS)
+        self.use_graph = bool(hg)
         self._graph = None
 
     def feval(self):
@@ -201,6 +230,7 @@ def optimize(content, styles, init, num_iters, args, net=None, losses=None):
     """Optimise `init` towards `content` / `styles`; returns a CPU fp32 tensor shaped like `init`."""
     if "_vid" in args.transfer_type:
         raise NotImplementedError("img_vid (sliding style-video windows) is outside this build's scope")
+    limit_host_threads()
     if init.shape[0] != 1:
         raise NotImplementedError("one frame per call (the reference's img_img / vid_img call pattern)")
 
@@ -229,7 +259,7 @@ def optimize(content, styles, init, num_iters, args, net=None, losses=None):
         for mod in net.content_losses + net.style_losses + net.temporal_losses:
             mod.strength = mod.strength / max(mod.target.size())
 
-    opt = PixelOptimizer(net, losses, init, args)
+    opt = PixelOptimizer(net, losses, init, args, planned_iters=num_iters)
     if args.optimizer == "lbfgs":
         _describe("Running optimization with L-BFGS", args)
         steps = lbfgs_moves(num_iters)

@@ -29,7 +29,7 @@ import dist
 import load
 import models
 import optim
-from utils import match_histogram, name
+from utils import limit_host_threads, match_histogram, name
 
 
 def _scaled_styles(style_images_big, content_area, args):
@@ -41,6 +41,7 @@ def _scaled_styles(style_images_big, content_area, args):
 
 
 def img_img(args):
+    limit_host_threads()
     style_images_big = load.process_style_images(args)
     content_image_big = match_histogram(load.preprocess(args.content), style_images_big, mode=args.match_histograms)
     content_size = np.array(content_image_big.size()[-2:])
@@ -173,6 +174,7 @@ def _finish_frame(out, content, path, original_colors):
 def vid_img(args):
     """Per-frame stylisation.  With a flow cache under <output_dir>/flow the reference's temporally consistent loop
     runs (sequential, rank 0); without one the frames are independent and are sharded over the ranks of the job."""
+    limit_host_threads()
     rank, _, world = dist.init()
     output_dir = args.output_dir + "/" + name(args.content) + "_" + "_".join([name(s) for s in args.style])
     frames = load.process_content_frames(args.content)

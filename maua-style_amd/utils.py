@@ -89,3 +89,14 @@ def match_histogram(target_tensor, source_tensor, eps=1e-2, mode="avg"):
                 matched = m
         out += matched.permute(0, 3, 2, 1) / len(sources)
     return out
+
+
+def limit_host_threads(limit=16):
+    """The host side of the path only touches 3-channel images (resizing, histogram matching, PNG coding).  On a
+    256-core MI355X host torch defaults to 128 intra-op threads, and fork/join overhead then dominates those small ops
+    (measured on BASELINE config 4: 2.7 s instead of 0.1 s of host work per frame).  MAUA_HOST_THREADS overrides."""
+    import os
+    import torch
+    want = int(os.environ.get("MAUA_HOST_THREADS", limit))
+    if want > 0 and torch.get_num_threads() > want:
+        torch.set_num_threads(want)
