@@ -18,14 +18,25 @@ constexpr int GRS = GK + 4;  // LDS row stride (floats): 16-byte aligned rows, 4
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Row means in two fixed-order stages: grid (C, RM_SPLIT) partial sums in fp64, then one small kernel adds each row's
+// partials in index order (one workgroup per row could not fill the chip: 96 rows of 64516 values took 64 us).
+constexpr int RM_SPLIT = 16;
 __global__ void __launch_bounds__(256)
-row_mean_kernel(const float* __restrict__ f, float* __restrict__ mean, int64_t HW) {
+row_mean_partial_kernel(const float* __restrict__ f, double* __restrict__ partial, int64_t HW) {
     __shared__ double scratch[16];
     const float* row = f + (int64_t)blockIdx.x * HW;
+    const int64_t per = (HW + RM_SPLIT - 1) / RM_SPLIT, lo = blockIdx.y * per, hi = min(HW, lo + per);
     double acc = 0.0;
-    for (int64_t i = threadIdx.x; i < HW; i += blockDim.x) acc += (double)row[i];
+    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) acc += (double)row[i];
     acc = block_sum(acc, scratch);
-    if (threadIdx.x == 0) mean[blockIdx.x] = (float)(acc / (double)HW);
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * RM_SPLIT + blockIdx.y] = acc;
+}
+__global__ void row_mean_finish_kernel(const double* __restrict__ partial, float* __restrict__ mean, int C, int64_t HW) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double acc = 0.0;
+    for (int k = 0; k < RM_SPLIT; ++k) acc += partial[(int64_t)c * RM_SPLIT + k];
+    mean[c] = (float)(acc / (double)HW);
 }
 
 // One workgroup = one upper-triangular 64x64 tile pair (ti <= tj) x one slice of HW.  Each of the 4 waves owns a 32x32
@@ -316,7 +327,9 @@ size_t maua_gram_workspace_bytes(int c, int64_t hw) {
     int npairs, ksplit;
     int64_t chunk;
     gram_plan(c, hw, &npairs, &ksplit, &chunk);
-    return (size_t)npairs * ksplit * GT * GT * sizeof(float) + (size_t)((c + 63) / 64 * 64) * sizeof(float);
+    const size_t slabs = (size_t)npairs * ksplit * GT * GT * sizeof(float) + (size_t)((c + 63) / 64 * 64) * sizeof(float);
+    const size_t row_partials = (size_t)c * RM_SPLIT * sizeof(double);  // covariance form: reused before the slabs
+    return slabs > row_partials ? slabs : row_partials;
 }
 
 int maua_gram_fwd(const float* f, float* gram, float* row_mean_out, int c, int64_t hw, float scale, int center,
@@ -330,8 +343,13 @@ int maua_gram_fwd(const float* f, float* gram, float* row_mean_out, int c, int64
     gram_plan(c, hw, &npairs, &ksplit, &chunk);
     hipStream_t s = (hipStream_t)stream;
     if (center) {
-        hipLaunchKernelGGL(row_mean_kernel, dim3(c), dim3(256), 0, s, f, row_mean_out, hw);
-        int rc = check_launch("row_mean_kernel");
+        // the partial sums live at the start of the workspace, which the Gram slabs overwrite afterwards (same stream)
+        hipLaunchKernelGGL(row_mean_partial_kernel, dim3(c, RM_SPLIT), dim3(256), 0, s, f, (double*)workspace, hw);
+        int rc = check_launch("row_mean_partial_kernel");
+        if (rc) return rc;
+        hipLaunchKernelGGL(row_mean_finish_kernel, dim3((c + 255) / 256), dim3(256), 0, s, (const double*)workspace, row_mean_out,
+                           c, hw);
+        rc = check_launch("row_mean_finish_kernel");
         if (rc) return rc;
     }
     const bool vec = (hw % 4 == 0) && ((uintptr_t)f % 16 == 0);

@@ -137,6 +137,49 @@ __global__ void pool_bwd_kernel(const float* __restrict__ gy, const float* __res
     }
 }
 
+// Max-pool backward with compile-time window / stride (NIN's 3x3 stride-2 ceil-mode pools): same gather form and tie rule
+// as the generic kernel, but the window loops unroll, the divisions by the stride become shifts and the indices come
+// from a 3-D grid (x, y, plane).  Overlapping windows make a scatter form need float atomics, i.e. an order that changes
+// from run to run; the gather form stays bit-reproducible.
+template <int K, int S>
+__global__ void __launch_bounds__(256)
+pool_max_bwd_ks_kernel(const float* __restrict__ gy, const float* __restrict__ x, float* __restrict__ gx, int H, int W, int OH,
+                       int OW, int relu_mask) {
+    const int ix = blockIdx.x * 256 + threadIdx.x, iy = blockIdx.y;
+    if (ix >= W) return;
+    const float* plane = x + (int64_t)blockIdx.z * H * W;
+    const float* gplane = gy + (int64_t)blockIdx.z * OH * OW;
+    const int oy_lo = max(0, (iy - K + S) / S), oy_hi = min(OH - 1, iy / S);
+    const int ox_lo = max(0, (ix - K + S) / S), ox_hi = min(OW - 1, ix / S);
+    const int self = iy * W + ix;
+    float acc = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < (K + S - 1) / S; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < (K + S - 1) / S; ++dx) {
+            const int oy = oy_lo + dy, ox = ox_lo + dx;
+            if (oy > oy_hi || ox > ox_hi) continue;
+            const int y0 = oy * S, x0 = ox * S;
+            if (y0 > iy || y0 + K <= iy || x0 > ix || x0 + K <= ix) continue;
+            int best = y0 * W + x0;
+            float bv = plane[best];
+#pragma unroll
+            for (int yy = 0; yy < K; ++yy)
+#pragma unroll
+                for (int xx = 0; xx < K; ++xx) {
+                    if (y0 + yy >= H || x0 + xx >= W) continue;
+                    const float v = plane[(y0 + yy) * W + x0 + xx];
+                    if (v > bv || v != v) {
+                        bv = v;
+                        best = (y0 + yy) * W + x0 + xx;
+                    }
+                }
+            if (best == self) acc += gplane[oy * OW + ox];
+        }
+    if (relu_mask && !(plane[self] > 0.f)) acc = 0.f;
+    gx[(int64_t)blockIdx.z * H * W + self] = acc;
+}
+
 // 2x2 stride-2 max pooling on even-sized planes (every VGG pool): one thread per window, 8-byte accesses, no divisions.
 // grid = (ceil(OW/256), OH, planes).  Same tie rule as window_argmax: scan order (0,0),(0,1),(1,0),(1,1), first max wins.
 __global__ void __launch_bounds__(256)
@@ -331,6 +374,11 @@ int maua_pool2d_bwd(const float* gy, const float* x, float* gx, int n, int c, in
         hipLaunchKernelGGL(pool2x2_bwd_kernel, dim3((ow + 255) / 256, oh, n * c), dim3(256), 0, (hipStream_t)stream, gy, x, gx, w,
                            ow, relu_mask_by_x);
         return check_launch("pool2x2_bwd_kernel");
+    }
+    if (mode == 0 && k == 3 && stride == 2 && (int64_t)n * c <= 65535 && h <= 65535) {
+        hipLaunchKernelGGL((pool_max_bwd_ks_kernel<3, 2>), dim3((w + 255) / 256, h, n * c), dim3(256), 0, (hipStream_t)stream, gy,
+                           x, gx, h, w, oh, ow, relu_mask_by_x);
+        return check_launch("pool_max_bwd_ks_kernel");
     }
     const int64_t total = (int64_t)n * c * h * w;
     hipLaunchKernelGGL(pool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, gy, x, gx, (int64_t)n * c,
