@@ -185,3 +185,28 @@ def test_vid_img_calls_against_fp64_arbiter(weight_files, tmp_path):
         err = rel_l2(out, g["out64_" + fname])
         print(fname, "err", err, "floor", floor)
         assert err <= max(1e-3, 2 * floor), (fname, err, floor)
+
+
+def test_bench_prints_one_contract_line(tmp_path):
+    """bench.py's output contract (one JSON line with metric / value / roofline / cpu_baseline ...) on a small size."""
+    env = dict(os.environ)
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--size", "128", "--steps", "4", "--warmup", "1",
+                          "--history", "5"], capture_output=True, text=True, env=env, timeout=900, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - 1e3 / d["ms_per_step"]) <= 1e-2 * d["value"]
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-3
+    c = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] in ("port", "reference") and c["value"] > 0
