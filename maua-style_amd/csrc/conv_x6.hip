@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
     const int in_plane = p.H * p.W;
     const int64_t out_plane = (int64_t)p.OH * p.OW;
     const float* __restrict__ xin = p.x + (int64_t)n * p.Cin * in_plane;
-    // Persistent workgroups with an XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin by linear id, so
+    // XCD-aware tile order (and optionally persistent workgroups): workgroups are dealt to the 8 XCDs round-robin by linear id, so
     // XCD k owns the k-th contiguous band of tiles (row-major; halo rows / columns shared by neighbouring tiles are hits
     // in ITS L2) and workgroup `slot` of that XCD walks the band with stride `slots`.  The K loop below runs over the
     // flattened (tile, chunk) sequence: the first chunk of the next tile is prefetched behind the last chunk of the
@@ -479,14 +479,27 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
 #endif
 }
 
-// split the K loop over several workgroups when the output grid alone cannot fill the chip (4 workgroups per CU)
+// Split the K loop over several workgroups when the output grid quantises badly against the chip's 1024 workgroup slots
+// (4 per CU x 256 CUs): e.g. conv4_x of a 724-px image is 552 workgroups - 54 % of one round - and of a 1448-px image
+// 2208 = 2.16 rounds.  Cost model per candidate split: rounds x (chunks per workgroup + 1.5 chunk-times of prologue /
+// epilogue) x 5 us per chunk, plus the finish kernel's traffic (ks partial reads + one write at ~5 TB/s).
 static int x6_choose_split(const ConvArgs& a, int n) {
     const int64_t wgs = (int64_t)((a.OW + 31) / 32) * ((a.OH + X6_PH - 1) / X6_PH) * ((a.Cout + X6_COT - 1) / X6_COT) * n;
     const int nchunks = (a.Cin + 7) / 8;
-    if (wgs >= 512 || nchunks < 8) return 1;
-    int ks = (int)((1024 + wgs - 1) / wgs);
-    if (ks > nchunks / 4) ks = nchunks / 4;  // keep at least 4 chunks per workgroup
-    return ks < 2 ? 1 : ks;
+    if (wgs >= 4096 || nchunks < 8) return 1;
+    const double out_mb = (double)n * a.Cout * a.OH * a.OW * 4.0 / 1e6;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int ks = 1; ks <= 16 && ks <= nchunks / 4; ++ks) {
+        const double rounds = (double)((wgs * ks + 1023) / 1024);
+        double cost = rounds * ((double)((nchunks + ks - 1) / ks) + 1.5) * 5.0;
+        if (ks > 1) cost += (ks + 1) * out_mb / 5.0 + 5.0;  // finish kernel: MB / (5 TB/s) in us, plus its launch
+        if (cost < best_cost * 0.97) {  // prefer the smaller split unless the gain is real
+            best_cost = cost;
+            best = ks;
+        }
+    }
+    return best;
 }
 
 int conv_x6_launch(const ConvArgs& a, int n, hipStream_t stream) {
@@ -498,10 +511,12 @@ int conv_x6_launch(const ConvArgs& a, int n, hipStream_t stream) {
     ks = 1;  // the workspace is the stamp buffer in the diagnostic build
 #endif
     p.ksplit = ks;
-    // Persistent workgroups: enough of them to fill the chip once (4 per CU x 256 CUs), each walking several tiles of its
-    // XCD band; MAUA_X6_PERSIST=0 launches one workgroup per tile instead (A/B switch).
+    // One workgroup per tile by default (the hardware's dynamic scheduling copes best with grids that do not divide the
+    // 1024 workgroup slots evenly).  MAUA_X6_PERSIST=1 launches persistent workgroups instead - enough to fill the chip
+    // once, each walking several tiles of its XCD band with cross-tile prefetch; measured equal on 1024x1024 (the other
+    // workgroups of a CU already hide a workgroup's prologue / epilogue), and it loses on uneven tile counts.
     const int64_t cot = (a.Cout + X6_COT - 1) / X6_COT, per_xcd = (tiles + 7) / 8;
-    static const bool persist = !(getenv("MAUA_X6_PERSIST") && atoi(getenv("MAUA_X6_PERSIST")) == 0);
+    static const bool persist = getenv("MAUA_X6_PERSIST") && atoi(getenv("MAUA_X6_PERSIST")) != 0;
     int64_t g8 = per_xcd;
     if (persist) {
         g8 = (1024 + cot * n * ks * 8 - 1) / (cot * n * ks * 8);

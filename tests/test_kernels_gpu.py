@@ -4,12 +4,14 @@ fp32 tolerance: rel-L2 <= 2e-5 for contractions (the summation order differs fro
 9*512), exact equality where the op is a selection (pooling forward, ReLU).
 """
 import math
+import os
+import tempfile
 
 import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import rel_l2
+from conftest import PKG, REPO, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -382,6 +384,28 @@ def test_conv3x3_x6_split_k_matches_single_pass(hip, cin, cout, H, W):
     assert rel_l2(one.cpu(), ref) <= 2e-6 and rel_l2(split.cpu(), ref) <= 2e-6
     assert rel_l2(split.cpu(), one.cpu().double()) <= 5e-7
     assert torch.equal(split, split2)
+
+
+def test_conv3x3_x6_persistent_workgroups_subprocess():
+    """MAUA_X6_PERSIST=1 (read once per process): several tiles per workgroup with cross-tile prefetch, in-loop epilogue
+    and accumulator re-initialisation must give the same bits as one workgroup per tile."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch, math; sys.path[:0] = [%r, %r]; import hip\n"
+        "g = torch.Generator().manual_seed(3)\n"
+        "x = torch.randn(1, 64, 300, 260, generator=g).cuda(); w = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).cuda()\n"
+        "b = torch.randn(64, generator=g).cuda(); f6, _ = hip.conv_pack_filters_x6(w)\n"
+        "y = hip.conv3x3_x6(x, f6, b, 64, 1, True); torch.cuda.synchronize()\n"
+        "torch.save(y.cpu(), sys.argv[1])\n") % (REPO, PKG)
+    outs = []
+    for flag in ("0", "1"):
+        path = os.path.join(tempfile.mkdtemp(), "y.pt")
+        env = dict(os.environ, MAUA_X6_PERSIST=flag)
+        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append(torch.load(path))
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_conv3x3_x6_is_deterministic(hip):

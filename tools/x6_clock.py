@@ -37,7 +37,7 @@ tiles = ((H + 31) // 32) * ((H + 3) // 4)
 cot = (cout + 63) // 64
 per_xcd = (tiles + 7) // 8
 g8 = min(per_xcd, max(1, -(-1024 // (cot * 8))))  # the launcher's persistent grid (conv_x6_launch)
-if os.environ.get("MAUA_X6_PERSIST") == "0":
+if os.environ.get("MAUA_X6_PERSIST", "0") == "0":
     g8 = per_xcd
 nwg = g8 * 8 * cot
 stamps = torch.zeros(nwg * 4 * 2 * 10, dtype=torch.int64, device="cuda")
