@@ -142,8 +142,20 @@ gram_partial_kernel(const float* __restrict__ f, const float* __restrict__ mean,
     }
 }
 
+// First level of the slab sum when there are many slabs (relu1_1 at 1024x1024: 745): grid (pairs, 16, groups), every thread
+// adds the GF_FOLD slabs of its group in index order (fp64) and leaves the sum in the group's first slab.  Fixed order.
+constexpr int GF_FOLD = 32;
 __global__ void __launch_bounds__(256)
-gram_finish_kernel(const float* __restrict__ partial, float* __restrict__ gram, int C, int ksplit, float scale) {
+gram_fold_kernel(float* __restrict__ partial, int ksplit) {
+    float* base = partial + (int64_t)blockIdx.x * ksplit * (GT * GT) + blockIdx.y * 256 + threadIdx.x;
+    const int k0 = blockIdx.z * GF_FOLD, k1 = min(k0 + GF_FOLD, ksplit);
+    double sd = 0.0;
+    for (int k = k0; k < k1; ++k) sd += (double)base[(int64_t)k * (GT * GT)];
+    base[(int64_t)k0 * (GT * GT)] = (float)sd;
+}
+
+__global__ void __launch_bounds__(256)
+gram_finish_kernel(const float* __restrict__ partial, float* __restrict__ gram, int C, int ksplit, int kstride, float scale) {
     // grid = (tile pairs, 16): every thread owns ONE element of the 64x64 tile and adds its `ksplit` slab values in
     // index order (fixed order -> deterministic); consecutive threads read consecutive addresses of each slab.
     int pair = blockIdx.x, ti = 0;
@@ -158,17 +170,8 @@ gram_finish_kernel(const float* __restrict__ partial, float* __restrict__ gram, 
     int er = e / GT, ec = e % GT;
     // diagonal tiles: block (1,0) was not computed, read its mirror image from block (0,1)
     const int src = (ti == tj && er >= 32 && ec < 32) ? ec * GT + er : e;
-    double sd = 0.0;  // up to ~800 slabs: fp64 keeps the split-K sum exact to fp32 rounding
-    int k = 0;
-    for (; k + 4 <= ksplit; k += 4) {
-        const float v0 = base[(int64_t)(k + 0) * (GT * GT) + src], v1 = base[(int64_t)(k + 1) * (GT * GT) + src];
-        const float v2 = base[(int64_t)(k + 2) * (GT * GT) + src], v3 = base[(int64_t)(k + 3) * (GT * GT) + src];
-        sd += (double)v0;
-        sd += (double)v1;
-        sd += (double)v2;
-        sd += (double)v3;
-    }
-    for (; k < ksplit; ++k) sd += (double)base[(int64_t)k * (GT * GT) + src];
+    double sd = 0.0;  // fp64 keeps the split-K sum exact to fp32 rounding; slabs k = 0, kstride, 2 kstride, ...
+    for (int k = 0; k < ksplit; k += kstride) sd += (double)base[(int64_t)k * (GT * GT) + src];
     const float s = (float)(sd * (double)scale);
     const int gi = ti * GT + er, gj = tj * GT + ec;
     if (gi < C && gj < C) {
@@ -361,7 +364,16 @@ int maua_gram_fwd(const float* f, float* gram, float* row_mean_out, int c, int64
                            center ? row_mean_out : nullptr, (float*)workspace, c, hw, ksplit, chunk);
     int rc = check_launch("gram_partial_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(gram_finish_kernel, dim3(npairs, GT * GT / 256), dim3(256), 0, s, (const float*)workspace, gram, c, ksplit, scale);
+    int kstride = 1;
+    if (ksplit > 2 * GF_FOLD) {
+        hipLaunchKernelGGL(gram_fold_kernel, dim3(npairs, GT * GT / 256, (ksplit + GF_FOLD - 1) / GF_FOLD), dim3(256), 0, s,
+                           (float*)workspace, ksplit);
+        rc = check_launch("gram_fold_kernel");
+        if (rc) return rc;
+        kstride = GF_FOLD;
+    }
+    hipLaunchKernelGGL(gram_finish_kernel, dim3(npairs, GT * GT / 256), dim3(256), 0, s, (const float*)workspace, gram, c, ksplit,
+                       kstride, scale);
     return check_launch("gram_finish_kernel");
 }
 
