@@ -199,11 +199,11 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
         }
     };
 
-    // fragment addresses: tap of this lane half for k-step s is 2s + half (clamped to 8 for the padding k-step)
+    // fragment addresses: tap of this lane half for k-step s < 4 is 2s + half
     int b_byte[5], a_byte[5];
 #pragma unroll
-    for (int s = 0; s < 5; ++s) {
-        const int tap = min(2 * s + half, 8);
+    for (int s = 0; s < 4; ++s) {
+        const int tap = 2 * s + half;
         const int ky = tap / 3, kx = tap - 3 * ky;
         b_byte[s] = ((wave + ky) * X6_PC + j + kx) * 16;
         a_byte[s] = ((tap * X6_COT + j) * 3) * 16;
@@ -215,8 +215,8 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
     a_byte[4] = ((8 * X6_COT + j) * 3) * 16 + half * 8;
 
     // two-level accumulation (TL): fold the running sums into a master accumulator (plain fp32 VALU adds, round to
-    // nearest) every FLUSH chunks so that no MFMA accumulation chain is longer than FLUSH*5*6 additions
-    constexpr int FLUSH = 1;  // measured: 1 halves the pixel-gradient error of 4 (the bf16 MFMA adder truncates toward zero)
+    // nearest) after EVERY chunk, so no MFMA accumulation chain is longer than 5 x 6 instructions.  Measured: folding every
+    // chunk halves the pixel-gradient error of folding every fourth (the bf16 MFMA adder truncates toward zero).
     // The accumulators start from the bias (loaded behind the prologue's / the previous epilogue's memory latency) instead
     // of zero, so the epilogue has no dependent loads.  Split-K partial sums start from zero: the finish kernel adds the
     // bias once.
@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
         kstep(3);
         kstep_tap9();
         if (more) split_patch();
-        if constexpr (TL) {  // FLUSH = 1: fold every chunk
+        if constexpr (TL) {  // fold every chunk
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
