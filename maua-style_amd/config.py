@@ -19,6 +19,8 @@ from utils import name
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
+DEFAULT_FFMPEG_ARGS = "config/ffmpeg-libx264.json"
+
 # (flag, kwargs) in the reference's order (config.py:15-89); types and defaults are part of the interface
 _FLAGS = [
     # input options
@@ -86,7 +88,7 @@ _FLAGS = [
     ("save_iter", dict(type=int, default=0)),
     ("save_args", dict(action="store_true")),
     ("load_args", dict(type=str, default=None)),
-    ("ffmpeg_args", dict(type=str, default="config/ffmpeg-libx264.json")),
+    ("ffmpeg_args", dict(type=str, default=DEFAULT_FFMPEG_ARGS)),
     ("scaling_args", dict(type=str, default="config/scaling-img.json",
                           help="multi-network multi-scale model-parallel configuration")),
     ("uniq", dict(action="store_true")),
@@ -137,8 +139,16 @@ def get_args(argv=None):
 
     args.output = f"{args.output_dir}/{stem}"
 
-    with open(_resolve(args.ffmpeg_args), "r") as f:
-        ffargs = json.load(f)
+    # Encoder settings are carried on `args.ffmpeg` as in the reference (config.py:129-132) although this build never
+    # encodes video.  The stock preset is built in, so the default path needs no file; any other path is read.
+    path = _resolve(args.ffmpeg_args)
+    if os.path.exists(path):
+        with open(path, "r") as f:
+            ffargs = json.load(f)
+    elif args.ffmpeg_args == DEFAULT_FFMPEG_ARGS:
+        ffargs = {"c:v": "libx264", "preset": "slow", "pix_fmt": "yuv420p"}
+    else:
+        raise FileNotFoundError(path)
     ffargs["framerate"] = args.fps
     args.ffmpeg = ffargs
     return postprocess(args)
