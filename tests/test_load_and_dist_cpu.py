@@ -133,3 +133,12 @@ def test_flow_warp_map_matches_reference_fixture(tmp_path):
         raise AssertionError("bad magic accepted")
     except ValueError:
         pass
+
+
+def test_original_colors_matches_reference_fixture():
+    """--original_colors: Y of the generated image, CbCr of the (resized) content image (reference load.py:236-240)."""
+    from PIL import Image
+    import load
+    g = np.load(os.path.join(GOLDEN, "cli_config1.npz"))
+    out = load.original_colors(Image.fromarray(g["origcol_content"]), Image.fromarray(g["origcol_generated"]))
+    assert np.array_equal(np.asarray(out), g["origcol_out"])

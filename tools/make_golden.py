@@ -468,6 +468,13 @@ def gen_cli():
     probe = torch.rand(1, 3, 16, 16, generator=g) * 300 - 150  # exercises the clamp on both sides
     res["deprocess_probe_in"] = probe.numpy()
     res["deprocess_probe_out"] = np.asarray(ref_load.deprocess(probe.clone()))
+    # --original_colors: luminance of the result, chroma of the content (load.py:236-240), different sizes on purpose
+    from PIL import Image
+    gc = torch.Generator().manual_seed(33)
+    img_c = Image.fromarray((torch.rand(24, 40, 3, generator=gc) * 255).byte().numpy())
+    img_g = Image.fromarray((torch.rand(32, 48, 3, generator=gc) * 255).byte().numpy())
+    res["origcol_content"], res["origcol_generated"] = np.asarray(img_c), np.asarray(img_g)
+    res["origcol_out"] = np.asarray(ref_load.original_colors(img_c, img_g))
     captured = {}
     real_opt = ref_optim.optimize
 
