@@ -367,3 +367,20 @@ def test_gram_matrix_module_on_two_frames():
     gm = loss.GramMatrix()
     assert rel_l2(gm(feats.cuda()).cpu(), g["gram_b2"]) <= 1e-5
     assert rel_l2(gm(feats.cuda(), use_covariance=True).cpu(), g["gram_b2_cov"]) <= 1e-5
+
+
+@pytest.mark.parametrize("case,model,opt,S,flags", [
+    ("nin_lbfgs", "nin", "lbfgs", 128, NIN_FLAGS + ["--use_covariance"]),
+    ("avgpool_lbfgs", "vgg19", "lbfgs", 64, ["--pooling", "avg"]),
+    ("avgpool_adam", "vgg19", "adam", 64, ["--pooling", "avg"]),
+])
+def test_more_trajectories_vs_fp64_arbiter(weight_files, case, model, opt, S, flags):
+    """NIN + covariance under L-BFGS (BASELINE config 5's optimiser) and average pooling, 6 iterations, trajectory rule."""
+    import optim
+    g = gold("traj_extra")
+    args = product_args(weight_files, flags, model=model, optimizer=opt, S=S, N=6)
+    content, style, init = synth.images(S)
+    out = optim.optimize(content, [style], init.clone(), 6, args)
+    floor = rel_l2(g[f"{case}_N6_f32"], g[f"{case}_N6_f64"])
+    err = rel_l2(out, g[f"{case}_N6_f64"])
+    assert err <= max(1e-3, 2 * floor), (case, err, floor)

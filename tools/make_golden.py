@@ -736,7 +736,24 @@ def gen_batch():
     save("loss_modules_B2", **res)
 
 
-GROUPS = {"batch": gen_batch, "vid": gen_vid, "temporal": gen_temporal, "cli": gen_cli, "traj64v": gen_traj_variants64, "feval": gen_feval, "traj": gen_traj, "nin": gen_nin, "hist": gen_hist, "host": gen_host}
+def gen_traj_extra():
+    """More trajectories: NIN + covariance under L-BFGS (config 5's optimiser), and VGG-19 with --pooling avg."""
+    print("[traj_extra] NIN L-BFGS, average pooling")
+    res = {}
+    nin_extra = ["--style_layers", "relu1,relu3,relu5,relu7,relu9,relu11", "--content_layers", "relu8", "--use_covariance"]
+    for double in (False, True):
+        tag = "f64" if double else "f32"
+        res[f"nin_lbfgs_N6_{tag}"] = run_traj(128, 6, "lbfgs", double, extra=nin_extra, model=NIN_PATH).numpy()
+        res[f"avgpool_lbfgs_N6_{tag}"] = run_traj(64, 6, "lbfgs", double, extra=["--pooling", "avg"]).numpy()
+        res[f"avgpool_adam_N6_{tag}"] = run_traj(64, 6, "adam", double, extra=["--pooling", "avg"]).numpy()
+    for k in sorted(res):
+        if k.endswith("f32"):
+            a, b = torch.from_numpy(res[k]).double(), torch.from_numpy(res[k[:-3] + "f64"])
+            print(f"    {k[:-4]}: f32 vs f64 {float((a - b).norm() / b.norm()):.3e}")
+    save("traj_extra", **res)
+
+
+GROUPS = {"traj_extra": gen_traj_extra, "batch": gen_batch, "vid": gen_vid, "temporal": gen_temporal, "cli": gen_cli, "traj64v": gen_traj_variants64, "feval": gen_feval, "traj": gen_traj, "nin": gen_nin, "hist": gen_hist, "host": gen_host}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
