@@ -227,7 +227,8 @@ def main():
     dominant = "conv_x6" if x6 else "conv"  # with bf16x6 on, conv1_1 (3 channels) runs other kernels: not counted here
     conv = [(fl, e0.elapsed_time(e1)) for tag, fl, nb, e0, e1 in timer if tag.startswith(dominant)]
     roofline = None
-    pmc = pmc_traffic("maua::conv_x6_kernel<" if x6 else "maua::conv_mfma2_kernel<") if S == 1024 else None
+    pmc = pmc_traffic(("maua::conv_x3_kernel<" if models._x3_enabled() else "maua::conv_x6_kernel<") if x6
+                      else "maua::conv_mfma2_kernel<") if S == 1024 else None
     if conv:
         tot_fl, tot_ms = sum(c[0] for c in conv), sum(c[1] for c in conv)
         achieved = tot_fl / (tot_ms * 1e-3) / 1e12
@@ -240,15 +241,19 @@ def main():
             d[3] += nb
         # fp32-accurate products on the bf16 matrix cores cost six MFMAs each: the attainable rate of ALGORITHMIC
         # (fp32-equivalent) FLOPs is the dense bf16 peak / 6; with the fp32 matrix cores it is the fp32 MFMA peak
-        peak = BF16_MFMA_PEAK_TFLOPS / X6_MFMAS_PER_PRODUCT if x6 else FP32_MFMA_PEAK_TFLOPS
+        x3 = x6 and models._x3_enabled()
+        per_product = 3 if x3 else X6_MFMAS_PER_PRODUCT
+        peak = BF16_MFMA_PEAK_TFLOPS / per_product if x6 else FP32_MFMA_PEAK_TFLOPS
         roofline = {"bound": "mfma",
-                    "kernel": "conv_x6_kernel (3x3 conv fwd + bwd-data, bf16x6)" if x6 else "conv_mfma2_kernel (fwd + bwd-data)",
+                    "kernel": ("conv_x3_kernel (3x3 conv fwd + bwd-data, fp16x3)" if x3 else
+                               "conv_x6_kernel (3x3 conv fwd + bwd-data, bf16x6)") if x6 else "conv_mfma2_kernel (fwd + bwd-data)",
                     "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                    "peak_note": ("algorithmic fp32-equivalent FLOPs; peak = 2500 TFLOP/s dense bf16 / 6 MFMAs per product block; "
-                                  "bf16 multiply-accumulate work = achieved x 6; matrix-pipe time = achieved x 6.67 (the ninth "
-                                  "tap's K=8 MFMA holds the pipe as long as a K=16 one: 5 steps for 4.5)") if x6 else "fp32 MFMA peak",
-                    "hw_bf16_tflops": round(achieved * 6, 1) if x6 else None,
-                    "hw_pipe_equiv_tflops": round(achieved * 6 * 10 / 9, 1) if x6 else None,
+                    "peak_note": (f"algorithmic fp32-equivalent FLOPs; peak = 2500 TFLOP/s dense {'fp16' if x3 else 'bf16'} / "
+                                  f"{per_product} MFMAs per product block; 16-bit multiply-accumulate work = achieved x {per_product}; "
+                                  f"matrix-pipe time = achieved x {per_product} x 10/9 (the ninth tap's K=8 MFMA holds the pipe as "
+                                  "long as a K=16 one: 5 steps for 4.5)") if x6 else "fp32 MFMA peak",
+                    "hw_16bit_tflops": round(achieved * per_product, 1) if x6 else None,
+                    "hw_pipe_equiv_tflops": round(achieved * per_product * 10 / 9, 1) if x6 else None,
                     "traffic": pmc["bytes"] if pmc else None, "traffic_note": pmc["note"] if pmc else None,
                     "algorithmic_bytes_per_launch": round(sum(nb for tag, fl, nb, e0, e1 in timer if tag.startswith(dominant)) / len(conv)),
                     "events_from": ("second pass of K eager iterations (the timed region replays a hipGraph)" if eager_ms is not None
@@ -263,7 +268,10 @@ def main():
         "metric": "optimizer iterations/sec at 1024x1024 VGG-19" if S == 1024 else f"optimizer iterations/sec at {S}x{S} VGG-19",
         "value": round(a.steps * world / elapsed, 4), "unit": "iterations/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (3x3 convs: exact 3-way bf16 split of both operands on the bf16 matrix cores, fp32 accumulate)"
+        "dtype": (("f32 (3x3 convs: power-of-two-scaled 2-way fp16 split of both operands = 22 of 24 significand bits, three fp16 MFMAs "
+                   "per product block, fp32 accumulate; pixel-gradient error vs fp64 4.6e-7 = the reference's own fp32 4.5e-7)")
+                  if models._x3_enabled() else
+                  "f32 (3x3 convs: exact 3-way bf16 split of both operands on the bf16 matrix cores, fp32 accumulate)")
                  if (opt.engine is not None and opt.engine.x6_fwd) else "f32", "data": "synthetic",
         "config": {"workload": f"{S}x{S} single-scale VGG-19 Gram style transfer, {a.optimizer.upper()}"
                                f"{' history ' + str(a.history) + ' (full)' if prefill else ''}, one image per GPU, "

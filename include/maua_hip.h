@@ -91,6 +91,19 @@ int maua_conv3x3_x6(const float* x, const void* bank, const float* bias, const f
                     int cin, int h, int w, int cout, int pad, int relu, int accumulate, void* workspace,
                     size_t workspace_bytes, maua_stream_t stream);
 
+/* ---- the same convolution on the fp16 matrix cores: a power-of-two-scaled fp32 value as two fp16 parts (22 of 24
+ *      significant bits, representation error 7e-8 of the result: below fp32 accumulation noise), three MFMAs per
+ *      product block (conv_x3.hip).  Filters are scaled once per layer by `w_scale` (a power of two with
+ *      |w| * w_scale < 64, chosen by the caller when packing); activations are scaled inside the kernel per workgroup
+ *      and 8-channel chunk.  Arguments as maua_conv3x3_x6. ---- */
+size_t maua_conv_x3_bank_bytes(int cout_produced, int cin_consumed);
+int maua_conv_pack_filters_x3(const float* w_oihw, void* bank_fwd, void* bank_bwd, int cout, int cin, float w_scale,
+                              maua_stream_t stream);
+size_t maua_conv_x3_workspace_bytes(int n, int cin, int h, int w, int cout, int pad);
+int maua_conv3x3_x3(const float* x, const void* bank, float w_scale, const float* bias, const float* out_relu_mask, float* y,
+                    int n, int cin, int h, int w, int cout, int pad, int relu, int accumulate, void* workspace,
+                    size_t workspace_bytes, maua_stream_t stream);
+
 /* ---- ReLU on its own (module path; the engine fuses it into the convs): models.py:130 ------------- */
 int maua_relu_fwd(float* x_inplace, int64_t count, maua_stream_t stream);
 int maua_relu_bwd(const float* gy, const float* y, float* gx, int64_t count, maua_stream_t stream);

@@ -147,7 +147,9 @@ class StyleEngine:
                          hip.conv_workspace_bytes(n, cout, oh, ow, cin, s.k, 1, s.k - 1 - s.pad))
                 if s.k == 3:
                     ws = max(ws, hip.conv_x6_workspace_bytes(n, cin, h, w, cout, s.pad),
-                             hip.conv_x6_workspace_bytes(n, cout, oh, ow, cin, 2 - s.pad))
+                             hip.conv_x6_workspace_bytes(n, cout, oh, ow, cin, 2 - s.pad),
+                             hip.conv_x3_workspace_bytes(n, cin, h, w, cout, s.pad),
+                             hip.conv_x3_workspace_bytes(n, cout, oh, ow, cin, 2 - s.pad))
         self.ws = torch.empty(ws, dtype=torch.uint8, device=dev)
         self.x_static = torch.empty(self.shape, device=dev)
 
@@ -225,9 +227,8 @@ class StyleEngine:
             if s.kind == "conv":
                 fl, nb = self._conv_work(s, a[s.src].shape, a[s.dst].shape, False)
                 if self.x6_fwd and self._x6_ok(s, s.mod.out_channels):
-                    b6, _ = s.mod.banks6()
-                    self._timed("conv_x6_fwd", fl, nb, lambda: hip.conv3x3_x6(
-                        a[s.src], b6, s.mod.bias_device(), s.mod.out_channels, s.pad, s.relu, out=a[s.dst], workspace=self.ws))
+                    self._timed("conv_x6_fwd", fl, nb, lambda: models_mod.conv3x3_mfma(
+                        a[s.src], s.mod, False, out=a[s.dst], relu=s.relu, workspace=self.ws))
                 else:
                     wf, _ = s.mod.banks()
                     self._timed("conv_other_fwd", fl, nb, lambda: hip.conv2d_fwd(
@@ -290,10 +291,8 @@ class StyleEngine:
                 fl, nb = self._conv_work(s, a[s.src].shape, a[s.dst].shape, True)
                 im = a[s.src] if premask(s) else None
                 if self.x6_bwd and self._x6_ok(s, s.mod.in_channels):
-                    _, b6 = s.mod.banks6()
-                    self._timed("conv_x6_bwd", fl, nb, lambda: hip.conv3x3_x6(
-                        g[s.dst], b6, None, s.mod.in_channels, 2 - s.pad, False, out=g[s.src], out_relu_mask=im,
-                        workspace=self.ws))
+                    self._timed("conv_x6_bwd", fl, nb, lambda: models_mod.conv3x3_mfma(
+                        g[s.dst], s.mod, True, out=g[s.src], out_relu_mask=im, workspace=self.ws))
                 else:
                     _, wb = s.mod.banks()
                     self._timed("conv_other_bwd", fl, nb, lambda: hip.conv2d_bwd_data(
@@ -323,9 +322,7 @@ class StyleEngine:
         for s in self.steps[:last + 1]:
             if s.kind == "conv":
                 if self.x6_fwd and self._x6_ok(s, s.mod.out_channels):
-                    b6, _ = s.mod.banks6()
-                    hip.conv3x3_x6(a[s.src], b6, s.mod.bias_device(), s.mod.out_channels, s.pad, s.relu, out=a[s.dst],
-                                   workspace=self.ws)
+                    models_mod.conv3x3_mfma(a[s.src], s.mod, False, out=a[s.dst], relu=s.relu, workspace=self.ws)
                 else:
                     wf, _ = s.mod.banks()
                     hip.conv2d_fwd(a[s.src], wf, s.mod.bias_device(), s.k, s.stride, s.pad, s.relu, out=a[s.dst],

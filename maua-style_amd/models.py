@@ -37,13 +37,38 @@ def _x6_mode():
     return mode in ("1", "fwd"), mode in ("1", "bwd")
 
 
+def _x3_enabled():
+    """MAUA_CONV_X3: "1" (default) = the fp32-accurate 3x3 convolution runs as fp16x3 (two-part fp16 split, three MFMAs per
+    product block, conv_x3.hip); "0" = bf16x6 (three-part bf16 split, six MFMAs, conv_x6.hip).  Measured pixel-gradient
+    error against the fp64 reference: 4.6e-7 / 2.6e-7; the reference's own fp32 arithmetic: 4.5e-7."""
+    import os
+    return os.environ.get("MAUA_CONV_X3", "1") == "1"
+
+
+def conv3x3_mfma(x, mod, backward, out=None, out_relu_mask=None, relu=False, workspace=None):
+    """The fp32-accurate reduced-width matrix-core convolution of a 3x3 stride-1 layer (forward, or backward-data when
+    `backward`): fp16x3 or bf16x6 according to MAUA_CONV_X3."""
+    pad = mod.padding[0]
+    if backward:
+        cout, p, bias = mod.in_channels, 2 - pad, None
+    else:
+        cout, p, bias = mod.out_channels, pad, mod.bias_device()
+    if _x3_enabled():
+        bf, bb, wsc = mod.banks3()
+        return hip.conv3x3_x3(x, bb if backward else bf, wsc, bias, cout, p, relu, out=out, out_relu_mask=out_relu_mask,
+                              workspace=workspace)
+    bf, bb = mod.banks6()
+    return hip.conv3x3_x6(x, bb if backward else bf, bias, cout, p, relu, out=out, out_relu_mask=out_relu_mask,
+                          workspace=workspace)
+
+
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mod):
         ctx.mod, ctx.in_shape = mod, x.shape
         k, stride, pad = mod.kernel_size[0], mod.stride[0], mod.padding[0]
         if _x6_mode()[0] and k == 3 and stride == 1 and pad <= 2 and mod.out_channels > 32:
-            return hip.conv3x3_x6(x.contiguous(), mod.banks6()[0], mod.bias_device(), mod.out_channels, pad, False)
+            return conv3x3_mfma(x.contiguous(), mod, False)
         return hip.conv2d_fwd(x.contiguous(), mod.banks()[0], mod.bias_device(), k, stride, pad, False)
 
     @staticmethod
@@ -51,7 +76,7 @@ class _ConvFn(torch.autograd.Function):
         mod = ctx.mod
         k, stride, pad = mod.kernel_size[0], mod.stride[0], mod.padding[0]
         if _x6_mode()[1] and k == 3 and stride == 1 and pad <= 2 and mod.in_channels > 32:
-            return hip.conv3x3_x6(gy.contiguous(), mod.banks6()[1], None, mod.in_channels, 2 - pad, False), None
+            return conv3x3_mfma(gy.contiguous(), mod, True), None
         gx = hip.conv2d_bwd_data(gy.contiguous(), None, mod.banks()[1], mod.weight.detach(), ctx.in_shape, k, stride, pad)
         return gx, None
 
@@ -77,6 +102,14 @@ class Conv2d(nn.Conv2d):
             self._banks6 = hip.conv_pack_filters_x6(self.weight.detach().contiguous())
             self._bank6_key = key
         return self._banks6
+
+    def banks3(self):
+        """fp16x2 pre-split, pre-scaled banks (forward, backward-data, filter scale) of the fp16 three-product path."""
+        key = (self.weight.data_ptr(), self.weight._version, self.weight.device)
+        if getattr(self, "_bank3_key", None) != key:
+            self._banks3 = hip.conv_pack_filters_x3(self.weight.detach().contiguous())
+            self._bank3_key = key
+        return self._banks3
 
     def bias_device(self):
         return None if self.bias is None else self.bias.detach()

@@ -18,17 +18,23 @@ if os.environ.get("X6_ZERO") == "1":  # DVFS probe: same instruction stream on a
     w.zero_()
 if os.environ.get("X6_ZERO") == "x":
     x.zero_()
-f6, b6 = hip.conv_pack_filters_x6(w)
+use_x3 = os.environ.get("X3") == "1"  # the fp16 three-product kernel instead of bf16x6
+if use_x3:
+    f3, b3, wsc = hip.conv_pack_filters_x3(w)
+    run = lambda: hip.conv3x3_x3(x, f3, wsc, None, cout, 1, True, out=y)
+else:
+    f6, b6 = hip.conv_pack_filters_x6(w)
+    run = lambda: hip.conv3x3_x6(x, f6, None, cout, 1, True, out=y)
 y = torch.empty(1, cout, H, H, device="cuda")
 for _ in range(3):
-    hip.conv3x3_x6(x, f6, None, cout, 1, True, out=y)
+    run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(reps):
-    hip.conv3x3_x6(x, f6, None, cout, 1, True, out=y)
+    run()
 e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / reps
 fl = 2.0 * 9 * cin * cout * H * H
-print(f"x6 {cin}->{cout} @{H}: {us:.1f} us  {fl / us / 1e6:.1f} TF algorithmic  ({fl / us / 1e6 * 60 / 9:.0f} TF bf16 hw)")
+print(f"{'x3' if use_x3 else 'x6'} {cin}->{cout} @{H}: {us:.1f} us  {fl / us / 1e6:.1f} TF algorithmic")

@@ -19,6 +19,13 @@ __global__ void __launch_bounds__(256) k(const float* src, float* out, unsigned 
         b[j] = (__bf16)(zero ? 0.f : src[(lane * 8 + j + 777) & 4095]);
     }
     for (int j = 0; j < 4; ++j) { a4[j] = __builtin_bit_cast(short, a[j]); b4[j] = __builtin_bit_cast(short, b[j]); }
+    if (SHAPE == 4) {  // real fp16 values with full 11-bit mantissas
+        for (int j = 0; j < 8; ++j) {
+            const _Float16 ha = (_Float16)(zero ? 0.f : src[(lane * 8 + j) & 4095] * 37.f), hb = (_Float16)(zero ? 0.f : src[(lane * 8 + j + 777) & 4095] * 3.f);
+            a[j] = __builtin_bit_cast(__bf16, ha);
+            b[j] = __builtin_bit_cast(__bf16, hb);
+        }
+    }
     f32x16 A0 = {0}, A1 = {0};
     f32x4 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0}, c4 = {0}, c5 = {0}, c6 = {0}, c7 = {0};
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
@@ -34,6 +41,9 @@ __global__ void __launch_bounds__(256) k(const float* src, float* out, unsigned 
             M32("v_mfma_f32_16x16x32_bf16", a, b, c2); M32("v_mfma_f32_16x16x32_bf16", a, b, c3);
             M32("v_mfma_f32_16x16x32_bf16", a, b, c4); M32("v_mfma_f32_16x16x32_bf16", a, b, c5);
             M32("v_mfma_f32_16x16x32_bf16", a, b, c6); M32("v_mfma_f32_16x16x32_bf16", a, b, c7);
+        } else if (SHAPE == 4) {  // fp16 operands (same bit patterns reinterpreted: random mantissas)
+            M32("v_mfma_f32_32x32x16_f16", a, b, A0); M32("v_mfma_f32_32x32x16_f16", a, b, A1);
+            M32("v_mfma_f32_32x32x16_f16", a, b, A0); M32("v_mfma_f32_32x32x16_f16", a, b, A1);
         } else {
             M32("v_mfma_f32_16x16x16bf16_1k", a4, b4, c0); M32("v_mfma_f32_16x16x16bf16_1k", a4, b4, c1);
             M32("v_mfma_f32_16x16x16bf16_1k", a4, b4, c2); M32("v_mfma_f32_16x16x16bf16_1k", a4, b4, c3);
@@ -72,6 +82,7 @@ int main() {
         run<1>("v_mfma_f32_32x32x8bf16_1k", 2.0 * 32 * 32 * 8, 4, src, out, st, zero);
         run<2>("v_mfma_f32_16x16x32_bf16", 2.0 * 16 * 16 * 32, 8, src, out, st, zero);
         run<3>("v_mfma_f32_16x16x16bf16_1k", 2.0 * 16 * 16 * 16, 8, src, out, st, zero);
+        run<4>("v_mfma_f32_32x32x16_f16", 2.0 * 32 * 32 * 16, 4, src, out, st, zero);
     }
     return 0;
 }
