@@ -62,17 +62,25 @@ def test_full_size_directional_derivative(setup):
     assert abs(fd - slope) <= 2e-2 * abs(slope), (fd, slope)
 
 
+@pytest.mark.parametrize("kernel", ["x3", "x6"])
 @pytest.mark.parametrize("cin,cout,side", [(64, 64, 1024), (512, 512, 128)])
-def test_full_size_x6_conv_is_exactly_homogeneous(cin, cout, side):
+def test_full_size_split_conv_is_exactly_homogeneous(cin, cout, side, kernel):
+    """Scaling the input by a power of two commutes with the bf16 three-way split, with the fp16 two-way split (its
+    per-chunk scale absorbs the factor exactly) and with every fp32 addition: bit-equal outputs."""
     import hip
     g = torch.Generator().manual_seed(5)
     x = dev(torch.randn(1, cin, side, side, generator=g))
     w = dev(torch.randn(cout, cin, 3, 3, generator=g) * math.sqrt(2.0 / (9 * cin)))
-    bank_f, bank_b = hip.conv_pack_filters_x6(w)
-    y1 = hip.conv3x3_x6(x, bank_f, None, cout, 1, False)
-    y4 = hip.conv3x3_x6(x * 4.0, bank_f, None, cout, 1, False)
-    gx1 = hip.conv3x3_x6(y1, bank_b, None, cin, 1, False)
-    gx2 = hip.conv3x3_x6(y1 * 0.5, bank_b, None, cin, 1, False)
+    if kernel == "x6":
+        bank_f, bank_b = hip.conv_pack_filters_x6(w)
+        conv = lambda t, bank, co: hip.conv3x3_x6(t, bank, None, co, 1, False)
+    else:
+        bank_f, bank_b, wsc = hip.conv_pack_filters_x3(w)
+        conv = lambda t, bank, co: hip.conv3x3_x3(t, bank, wsc, None, co, 1, False)
+    y1 = conv(x, bank_f, cout)
+    y4 = conv(x * 4.0, bank_f, cout)
+    gx1 = conv(y1, bank_b, cin)
+    gx2 = conv(y1 * 0.5, bank_b, cin)
     torch.cuda.synchronize()
     assert torch.equal(y4, y1 * 4.0)
     assert torch.equal(gx2, gx1 * 0.5)

@@ -386,6 +386,85 @@ def test_conv3x3_x6_split_k_matches_single_pass(hip, cin, cout, H, W):
     assert torch.equal(split, split2)
 
 
+# ---------------------------------------------------------------------------------------------------------
+# fp16x3 convolution (two-part fp16 split with per-workgroup, per-chunk scaling): same cases and bounds as bf16x6
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cin,cout,H,W,pad", X6_CASES)
+def test_conv3x3_x3_forward_and_backward(hip, cin, cout, H, W, pad):
+    x = rnd(2, cin, H, W, seed=1)
+    w = rnd(cout, cin, 3, 3, seed=2, scale=math.sqrt(2.0 / (9 * cin)))
+    b = rnd(cout, seed=3, scale=0.1)
+    ref = torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=pad))
+    bank_f, bank_b, wsc = hip.conv_pack_filters_x3(dev(w))
+    assert math.log2(wsc) == int(math.log2(wsc)) and 32 <= float(w.abs().max()) * wsc < 64
+    y = hip.conv3x3_x3(dev(x), bank_f, wsc, dev(b), cout, pad, True)
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape
+    assert rel_l2(y.cpu(), ref) <= 2e-6
+    gy = rnd(*ref.shape, seed=4)
+    refb = torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), padding=pad)
+    mask = rnd(*x.shape, seed=6)
+    gx = hip.conv3x3_x3(dev(gy), bank_b, wsc, None, cin, 2 - pad, False, out_relu_mask=dev(mask))
+    torch.cuda.synchronize()
+    assert rel_l2(gx.cpu(), refb * (mask > 0)) <= 2e-6
+    base = rnd(*x.shape, seed=5)
+    gx2 = hip.conv3x3_x3(dev(gy), bank_b, wsc, None, cin, 2 - pad, False, out=dev(base.clone()), accumulate=True)
+    gx3 = hip.conv3x3_x3(dev(gy), bank_b, wsc, None, cin, 2 - pad, False, out=dev(base.clone()), accumulate=True)
+    torch.cuda.synchronize()
+    assert rel_l2(gx2.cpu(), refb + base.double()) <= 2e-6
+    assert torch.equal(gx2, gx3)
+
+
+@pytest.mark.parametrize("cin,cout,H,W", [(512, 512, 16, 16), (256, 256, 33, 40), (512, 64, 8, 8)])
+def test_conv3x3_x3_split_k_matches_single_pass(hip, cin, cout, H, W):
+    assert hip.conv_x3_workspace_bytes(1, cin, H, W, cout, 1) > 0
+    assert hip.conv_x3_workspace_bytes(1, 64, 1024, 1024, 64, 1) == 0
+    x = rnd(1, cin, H, W, seed=1)
+    w = rnd(cout, cin, 3, 3, seed=2, scale=math.sqrt(2.0 / (9 * cin)))
+    b = rnd(cout, seed=3, scale=0.1)
+    base, mask = rnd(1, cout, H, W, seed=5), rnd(1, cout, H, W, seed=6)
+    ref = (torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1) + base.double())) * (mask > 0)
+    bank_f, _, wsc = hip.conv_pack_filters_x3(dev(w))
+    none = torch.empty(0, dtype=torch.uint8, device="cuda")
+    one = hip.conv3x3_x3(dev(x), bank_f, wsc, dev(b), cout, 1, True, out=dev(base.clone()), accumulate=True,
+                         out_relu_mask=dev(mask), workspace=none)
+    split = hip.conv3x3_x3(dev(x), bank_f, wsc, dev(b), cout, 1, True, out=dev(base.clone()), accumulate=True,
+                           out_relu_mask=dev(mask))
+    torch.cuda.synchronize()
+    assert rel_l2(one.cpu(), ref) <= 2e-6 and rel_l2(split.cpu(), ref) <= 2e-6
+    assert rel_l2(split.cpu(), one.cpu().double()) <= 5e-7
+
+
+@pytest.mark.parametrize("kind", ["wide_range", "tiny", "huge", "zeros", "one_hot"])
+def test_conv3x3_x3_scaling_survives_extreme_inputs(hip, kind):
+    """fp16 has 5 exponent bits: the per-chunk power-of-two scaling must keep every magnitude usable.  Gradients spanning
+    ten decades, values near the fp32 extremes, all-zero tiles and a single non-zero element."""
+    cin, cout, H, W = 64, 64, 40, 40
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(1, cin, H, W, generator=g)
+    if kind == "wide_range":
+        x = x * torch.exp(torch.randn(1, cin, H, W, generator=g) * 4.0) * 1e-6 * (torch.rand(1, cin, H, W, generator=g) > 0.5)
+    elif kind == "tiny":
+        x = x * 1e-30
+    elif kind == "huge":
+        x = x * 1e30
+    elif kind == "zeros":
+        x = torch.zeros_like(x)
+    elif kind == "one_hot":
+        x = torch.zeros_like(x)
+        x[0, 17, 20, 21] = 3.0e-12
+    w = rnd(cout, cin, 3, 3, seed=2, scale=math.sqrt(2.0 / (9 * cin)))
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    bank_f, _, wsc = hip.conv_pack_filters_x3(dev(w))
+    y = hip.conv3x3_x3(dev(x), bank_f, wsc, None, cout, 1, False)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+    if kind == "zeros":
+        assert float(y.abs().max()) == 0.0
+    else:
+        assert rel_l2(y.cpu(), ref) <= 2e-6
+
+
 def test_conv3x3_x6_persistent_workgroups_subprocess():
     """MAUA_X6_PERSIST=1 (read once per process): several tiles per workgroup with cross-tile prefetch, in-loop epilogue
     and accumulator re-initialisation must give the same bits as one workgroup per tile."""
