@@ -18,8 +18,8 @@
 // Everything else follows conv_x6.hip: workgroup = 4 waves = 64 output channels x (4 rows x 32 px), K chunks of 8 input
 // channels, one k-step = two taps (the ninth alone at K = 8), one LDS chunk (patch [part][pos][8ch] 6.5 KB + filters
 // [tap][part][co][8ch] 18 KB), filter halves streamed by LDS-DMA behind the k-steps, counted vmcnt, XCD-aware tile
-// order, deterministic split-K.  Needs the two-level accumulation, i.e. it is used for Cin > 32; narrower layers
-// (conv1_1) stay on conv_x6.hip.
+// order, deterministic split-K.  The fp32 master accumulator is always present here (it is where the per-chunk scales
+// meet), so one variant serves every channel count (conv1_1's three channels are a single, partly empty chunk).
 #include <stdlib.h>
 
 #include "common.hpp"
