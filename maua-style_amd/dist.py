@@ -23,10 +23,12 @@ def init(backend=None):
     Returns (rank, local_rank, world).  One process per GPU; the device is chosen before any collective."""
     rank, local_rank, world = env_rank()
     if world > 1 and not td.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:  # MAUA_DIST_BACKEND=gloo: several ranks sharing one GPU (testing the N > 1 paths on a 1-GPU box)
+            backend = os.environ.get("MAUA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
+        elif torch.cuda.is_available():
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         td.init_process_group(backend=backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
@@ -84,10 +86,14 @@ def broadcast_style_targets(net, src=0):
             shape = torch.tensor(list(t.shape) + [0] * (4 - t.dim()), dtype=torch.int64, device=_coll_device())
             td.broadcast(shape, src=src)
             dims = [int(v) for v in shape.tolist() if v > 0]
-            if td.get_rank() != src:
-                t = torch.empty(dims, dtype=torch.float32, device=_coll_device()) if dims else torch.Tensor()
+            if td.get_rank() != src:  # targets live where the network computes (the GPU), whatever the backend moves them with
+                t = torch.empty(dims, dtype=torch.float32, device=_compute_device()) if dims else torch.Tensor()
                 setattr(mod, name, t)
     broadcast_tensors([getattr(m, n) for m in net.style_losses for n in ("target", "video_target")], src)
+
+
+def _compute_device():
+    return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
 
 
 def _coll_device():

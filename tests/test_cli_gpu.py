@@ -210,3 +210,21 @@ def test_bench_prints_one_contract_line(tmp_path):
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] in ("port", "reference") and c["value"] > 0
+
+
+def test_bench_two_ranks_share_one_gpu(tmp_path):
+    """The N > 1 code path of bench.py (process group, one broadcast of weights and style targets, barriers, max over
+    ranks, rank 0 prints) with two ranks on this box's single GPU over gloo (MAUA_DIST_BACKEND; RCCL needs one GPU per
+    rank).  The 8-GPU launch differs only in the backend and the device index."""
+    env = dict(os.environ, MAUA_DIST_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29541", os.path.join(REPO, "bench.py"), "--gpus", "2", "--size", "128",
+                          "--steps", "4", "--warmup", "1", "--history", "5"], capture_output=True, text=True, env=env,
+                         timeout=900, cwd=str(tmp_path))
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) <= 1e-2 * d["value"]
+    assert "x2" in d["config"]["parallelism"]
