@@ -228,3 +228,31 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) <= 1e-2 * d["value"]
     assert "x2" in d["config"]["parallelism"]
+
+
+def test_vid_img_sharded_over_two_ranks_matches_one_rank(tmp_path, weight_files):
+    """Frame sharding of the flow-less vid_img over two ranks (sharing this box's GPU over gloo): the same files, bit for
+    bit, as the single-process run - frames are independent problems and rank 0's weights are broadcast."""
+    import synth
+    import load
+    frames_dir = tmp_path / "clip"
+    frames_dir.mkdir()
+    for i, f in enumerate(synth.frames(5, 48)):
+        load.deprocess(f[None].clone()).save(frames_dir / f"{i:05d}.png")
+    scaling = tmp_path / "scaling.json"
+    scaling.write_text(json.dumps({"100000": {"gpu": "0", "multidevice": False}}))
+    flags = ["--transfer_type", "vid_img", "--content", str(frames_dir), "--style", os.path.join(REPO, "tests", "synth_style_256.png"),
+             "--image_sizes", "48", "--num_iters", "6", "--passes_per_scale", "2", "--init", "content", "--model_file",
+             weight_files["vgg19"], "--disable_check", "--scaling_args", str(scaling), "--seed", "0", "--no_hist_match"]
+    one, two = tmp_path / "one", tmp_path / "two"
+    r = run_style(flags + ["--output_dir", str(one)], cwd=PKG)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ, MAUA_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29543", os.path.join(PKG, "style.py")] + flags + ["--output_dir", str(two)],
+                       capture_output=True, text=True, env=env, timeout=900, cwd=PKG)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    a, b = one / "clip_synth_style_256" / "48", two / "clip_synth_style_256" / "48"
+    assert sorted(os.listdir(a)) == sorted(os.listdir(b)) == sorted(f"{p}_{i:05d}.png" for p in (1, 2) for i in range(5))
+    for f in os.listdir(a):
+        assert np.array_equal(np.asarray(Image.open(a / f)), np.asarray(Image.open(b / f))), f
