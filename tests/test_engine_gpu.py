@@ -384,3 +384,25 @@ def test_more_trajectories_vs_fp64_arbiter(weight_files, case, model, opt, S, fl
     floor = rel_l2(g[f"{case}_N6_f32"], g[f"{case}_N6_f64"])
     err = rel_l2(out, g[f"{case}_N6_f64"])
     assert err <= max(1e-3, 2 * floor), (case, err, floor)
+
+
+def test_pixel_gradient_is_as_close_to_fp64_as_the_reference_fp32(weight_files):
+    """The split-precision convolutions claim fp32-level accuracy: the whole-network pixel gradient must sit as close to the
+    fp64 reference as the reference's own fp32 arithmetic does (fixtures hold both), not merely inside a loose tolerance."""
+    import engine
+    import optim
+    for S, name, temporal in ((32, "feval_vgg19_S32_default", False), (64, "feval_temporal_default_S64", True)):
+        g32, g64 = gold(name), gold(name + "_f64")
+        args = product_args(weight_files, S=S)
+        content, style, init = synth.images(S)
+        net, losses = build(args, content, [style], S)
+        if temporal:
+            for m in losses:
+                m.mode = "none"
+            optim.set_temporal_targets(net, *temporal_inputs(S), args=args)
+            for m in losses:
+                m.mode = "loss"
+        _, _, grad = engine.StyleEngine(net, losses).feval(init.cuda())
+        torch.cuda.synchronize()
+        ours, theirs = rel_l2(grad.cpu(), g64["grad"]), rel_l2(g32["grad"], g64["grad"])
+        assert ours <= 1.5 * theirs, (S, ours, theirs)
