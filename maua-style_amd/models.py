@@ -39,8 +39,9 @@ def _x6_mode():
 
 def _x3_enabled():
     """MAUA_CONV_X3: "1" (default) = the fp32-accurate 3x3 convolution runs as fp16x3 (two-part fp16 split, three MFMAs per
-    product block, conv_x3.hip); "0" = bf16x6 (three-part bf16 split, six MFMAs, conv_x6.hip).  Measured pixel-gradient
-    error against the fp64 reference: 4.6e-7 / 2.6e-7; the reference's own fp32 arithmetic: 4.5e-7."""
+    product block, conv_x3.hip; the 3-channel image layer keeps the exact bf16x6 products); "0" = bf16x6 everywhere
+    (three-part bf16 split, six MFMAs, conv_x6.hip).  Measured pixel-gradient error against the fp64 reference:
+    2.8e-7 / 2.6e-7; the reference's own fp32 arithmetic: 4.5e-7 (4.6e-7 if the image layer ran on fp16x3 too)."""
     import os
     return os.environ.get("MAUA_CONV_X3", "1") == "1"
 
@@ -53,7 +54,10 @@ def conv3x3_mfma(x, mod, backward, out=None, out_relu_mask=None, relu=False, wor
         cout, p, bias = mod.in_channels, 2 - pad, None
     else:
         cout, p, bias = mod.out_channels, pad, mod.bias_device()
-    if _x3_enabled():
+    consumed = mod.out_channels if backward else mod.in_channels
+    if _x3_enabled() and consumed > 4:
+        # (the image layer, 3 input channels, stays on the exact bf16x6 products: it differences neighbouring pixels of large
+        # common magnitude - the one place where the 2 bits fp16x3 drops could show - and costs one partly empty chunk)
         bf, bb, wsc = mod.banks3()
         return hip.conv3x3_x3(x, bb if backward else bf, wsc, bias, cout, p, relu, out=out, out_relu_mask=out_relu_mask,
                               workspace=workspace)
