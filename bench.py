@@ -268,11 +268,16 @@ def main():
         "metric": "optimizer iterations/sec at 1024x1024 VGG-19" if S == 1024 else f"optimizer iterations/sec at {S}x{S} VGG-19",
         "value": round(a.steps * world / elapsed, 4), "unit": "iterations/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": (("f32 (3x3 convs: power-of-two-scaled 2-way fp16 split of both operands = 22 of 24 significand bits, three fp16 MFMAs "
-                   "per product block, fp32 accumulate; image layer on exact bf16x6 products; pixel-gradient error vs fp64 2.8e-7, the reference's own fp32: 4.5e-7)")
-                  if models._x3_enabled() else
-                  "f32 (3x3 convs: exact 3-way bf16 split of both operands on the bf16 matrix cores, fp32 accumulate)")
-                 if (opt.engine is not None and opt.engine.x6_fwd) else "f32", "data": "synthetic",
+        "dtype": (("f32 (fp16x3 split-precision MFMA, fp32 accumulate)" if models._x3_enabled() else
+                   "f32 (bf16x6 split-precision MFMA, fp32 accumulate)")
+                  if (opt.engine is not None and opt.engine.x6_fwd) else "f32"),
+        "dtype_note": ((("3x3 convs: power-of-two-scaled 2-way fp16 split of both operands = 22 of 24 significand bits, three fp16 MFMAs "
+                         "per product block, fp32 accumulate; image layer on exact bf16x6 products; pixel-gradient error vs fp64 2.8e-7, "
+                         "the reference's own fp32: 4.5e-7") if models._x3_enabled() else
+                        "3x3 convs: exact 3-way bf16 split of both operands on the bf16 matrix cores, fp32 accumulate; pixel-gradient "
+                        "error vs fp64 2.6e-7, the reference's own fp32: 4.5e-7")
+                       if (opt.engine is not None and opt.engine.x6_fwd) else None),
+        "data": "synthetic",
         "config": {"workload": f"{S}x{S} single-scale VGG-19 Gram style transfer, {a.optimizer.upper()}"
                                f"{' history ' + str(a.history) + ' (full)' if prefill else ''}, one image per GPU, "
                                "content 5 / style 100 / tv 1e-3, normalize_gradients, seeded synthetic weights and images",
