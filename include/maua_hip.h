@@ -104,6 +104,17 @@ int maua_conv3x3_x3(const float* x, const void* bank, float w_scale, const float
                     int n, int cin, int h, int w, int cout, int pad, int relu, int accumulate, void* workspace,
                     size_t workspace_bytes, maua_stream_t stream);
 
+/* ---- 1x1 convolution / channel-mixing product y[co][p] (+)= sum_ci w[co][ci] x[ci][p] in the same fp16x3 arithmetic
+ *      (conv1x1_x3.hip): NIN's 1x1 layers (models.py:84-110; backward-data passes the transposed weights) and the Gram
+ *      backward D x (F - mean) of loss.py:91.  Both operands are plain fp32; the kernel scales and splits them per
+ *      workgroup and 32-channel chunk, so weights that change every call need no packing.  x: [n][cin][hw],
+ *      w_rowmajor: [cout][cin], y: [n][cout][hw]; bias / out_relu_mask nullable; x_channel_shift (nullable, [cin]) is
+ *      subtracted from x first (the Gram's centring).  maua_gram_bwd routes here unless MAUA_GRAM_BWD_X3=0. ---- */
+size_t maua_conv1x1_x3_workspace_bytes(int n, int cin, int64_t hw, int cout);
+int maua_conv1x1_x3(const float* x, const float* x_channel_shift, const float* w_rowmajor, const float* bias,
+                    const float* out_relu_mask, float* y, int n, int cin, int64_t hw, int cout, int relu, int accumulate,
+                    void* workspace, size_t workspace_bytes, maua_stream_t stream);
+
 /* ---- ReLU on its own (module path; the engine fuses it into the convs): models.py:130 ------------- */
 int maua_relu_fwd(float* x_inplace, int64_t count, maua_stream_t stream);
 int maua_relu_bwd(const float* gy, const float* y, float* gx, int64_t count, maua_stream_t stream);
@@ -145,7 +156,9 @@ int maua_mse_weighted_fwd_bwd(const float* x, const float* weights, const float*
 
 /* Backward of the Gram loss into the feature map: gf[C][hw] (+)= D[C][C] (symmetric) * (f - mean) ;
  * autograd of torch.mm(x, x.t()) at loss.py:91 with the MSE gradient D (scaled by the caller).  relu_mask (nullable,
- * shape of gf): result zeroed where it is <= 0. */
+ * shape of gf): result zeroed where it is <= 0.  Runs as maua_conv1x1_x3 with x_channel_shift = row_mean (fp16x3
+ * arithmetic; workspace of maua_gram_workspace_bytes lets small maps split the channel loop); MAUA_GRAM_BWD_X3=0 keeps
+ * the fp32-MFMA kernel. */
 int maua_gram_bwd(const float* d_sym, const float* f, const float* row_mean, const float* relu_mask, float* gf, int c,
                   int64_t hw, int accumulate, void* workspace, size_t workspace_bytes, maua_stream_t stream);
 

@@ -78,6 +78,8 @@ int conv_mfma_dispatch(const ConvArgs& a, int ks, int n, hipStream_t stream);
 int conv3x3_few_out(const ConvArgs& a, int n, hipStream_t stream);
 int conv_splitk_finish(const ConvArgs& a, int n, int ksplit, hipStream_t stream);
 int conv_x3_launch(const ConvArgs& a, int n, float w_scale, hipStream_t stream);  // conv_x3.hip  // y = act(bias + sum of a.ws partials) ...
+int conv1x1_x3_launch(const ConvArgs& a, const float* xshift, int n, hipStream_t stream);  // conv1x1_x3.hip (a.w = [Cout][Cin], a.H*a.W pixels)
+size_t conv1x1_x3_workspace(int n, int cin, int64_t hw, int cout);
 int conv_mfma2_choose_split(const ConvArgs& a, int ks, int n);                     // 1 = no split  // 3x3, stride 1, Cout <= 4 (conv_direct.hip)
 int conv_direct_fwd(const float* x, const float* mask, const float* wf, const float* bias, float* y, int n, int cin, int h,
                     int w, int cout, int oh, int ow, int kh, int kw, int stride, int pad, int relu, int accumulate,

@@ -5,6 +5,8 @@
 // Forward: the (C/64)(C/64+1)/2 upper-triangular 64x64 tiles are split along HW over `ksplit` workgroups each
 // (split-K); every workgroup writes its partial tile to a slab and a second kernel adds the slabs in index order,
 // scales, and mirrors the result - a deterministic reduction without float atomics.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace maua {
@@ -332,7 +334,9 @@ size_t maua_gram_workspace_bytes(int c, int64_t hw) {
     gram_plan(c, hw, &npairs, &ksplit, &chunk);
     const size_t slabs = (size_t)npairs * ksplit * GT * GT * sizeof(float) + (size_t)((c + 63) / 64 * 64) * sizeof(float);
     const size_t row_partials = (size_t)c * RM_SPLIT * sizeof(double);  // covariance form: reused before the slabs
-    return slabs > row_partials ? slabs : row_partials;
+    const size_t bwd_split = hw < (1ll << 30) ? conv1x1_x3_workspace(1, c, hw, c) : 0;  // maua_gram_bwd's split channel loop
+    size_t need = slabs > row_partials ? slabs : row_partials;
+    return need > bwd_split ? need : bwd_split;
 }
 
 int maua_gram_fwd(const float* f, float* gram, float* row_mean_out, int c, int64_t hw, float scale, int center,
@@ -381,6 +385,26 @@ int maua_gram_bwd(const float* d_sym, const float* f, const float* row_mean, con
                   int64_t hw, int accumulate, void* workspace, size_t workspace_bytes, maua_stream_t stream) {
     MAUA_REQUIRE(d_sym && f && gf && c > 0 && hw > 0, MAUA_E_INVAL, "gram_bwd: bad args");
     MAUA_REQUIRE(hw < (1ll << 31), MAUA_E_UNSUPPORTED, "gram_bwd: plane too large");
+    static const bool use_x3 = [] {
+        const char* e = getenv("MAUA_GRAM_BWD_X3");
+        return !(e && e[0] == '0');
+    }();
+    if (use_x3 && hw < (1ll << 30)) {
+        // fp16x3 product (conv1x1_x3.hip): D is symmetric, so its rows serve as [cout][cin]; centring folded into the staging
+        ConvArgs a{};
+        a.x = f;
+        a.w = d_sym;
+        a.omask = relu_mask;
+        a.y = gf;
+        a.Cin = c;
+        a.Cout = c;
+        a.H = 1;
+        a.W = (int)hw;
+        a.accumulate = accumulate;
+        const size_t need = conv1x1_x3_workspace(1, c, hw, c);
+        a.ws = (workspace && need && workspace_bytes >= need) ? (float*)workspace : nullptr;
+        return conv1x1_x3_launch(a, row_mean, 1, (hipStream_t)stream);
+    }
     if (hw % 4 == 0 && c % 4 == 0 && (uintptr_t)f % 16 == 0 && (uintptr_t)d_sym % 16 == 0) {
         constexpr size_t lds = 2ull * (GB_KC * GB_PX + GB_KC * GB_CO) * sizeof(float);
         dim3 grid((unsigned)((hw + GB_PX - 1) / GB_PX), (unsigned)((c + GB_CO - 1) / GB_CO));

@@ -32,6 +32,8 @@ SIGNATURES = {
     "maua_conv_x6_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "maua_conv_x3_bank_bytes": (c_sz, [c_i, c_i]),
     "maua_conv_pack_filters_x3": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_p]),
+    "maua_conv1x1_x3_workspace_bytes": (c_sz, [c_i, c_i, c_i64, c_i]),
+    "maua_conv1x1_x3": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i64, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "maua_conv_x3_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "maua_conv3x3_x3": (c_i, [c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "maua_conv3x3_x6": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
@@ -219,6 +221,26 @@ def conv3x3_x3(x, bank, w_scale, bias, cout, pad, relu, out=None, out_relu_mask=
     wp, wn = _ws_args(workspace, conv_x3_workspace_bytes(n, cin, h, w, cout, pad) if workspace is None else 0, x.device)
     _check(lib().maua_conv3x3_x3(_ptr(_f32(x, "x")), bank.data_ptr(), float(w_scale), _ptr(bias), _ptr(out_relu_mask), _ptr(out), n,
                                  cin, h, w, cout, pad, int(relu), int(accumulate), wp, wn, _stream()), "maua_conv3x3_x3")
+    return out
+
+
+def conv1x1_x3_workspace_bytes(n, cin, hw, cout):
+    return lib().maua_conv1x1_x3_workspace_bytes(n, cin, hw, cout)
+
+
+def conv1x1_x3(x, w_rowmajor, bias=None, relu=False, out=None, out_relu_mask=None, accumulate=False, workspace=None,
+               x_shift=None):
+    """y[n][co][p] (+)= sum_ci w[co][ci] x[n][ci][p] in fp16x3 arithmetic; x is [n, cin, ...] (any trailing plane shape);
+    x_shift ([cin], optional) is subtracted from x first."""
+    n, cin = x.shape[:2]
+    hw = x[0, 0].numel()
+    cout = w_rowmajor.shape[0]
+    assert w_rowmajor.numel() == cout * cin and w_rowmajor.is_contiguous()
+    if out is None:
+        out = torch.empty((n, cout) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
+    wp, wn = _ws_args(workspace, conv1x1_x3_workspace_bytes(n, cin, hw, cout) if workspace is None else 0, x.device)
+    _check(lib().maua_conv1x1_x3(_ptr(_f32(x, "x")), _ptr(x_shift), _ptr(_f32(w_rowmajor, "w")), _ptr(bias), _ptr(out_relu_mask), _ptr(out), n, cin,
+                                 hw, cout, int(relu), int(accumulate), wp, wn, _stream()), "maua_conv1x1_x3")
     return out
 
 

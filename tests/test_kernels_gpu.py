@@ -465,6 +465,120 @@ def test_conv3x3_x3_scaling_survives_extreme_inputs(hip, kind):
         assert rel_l2(y.cpu(), ref) <= 2e-6
 
 
+# ---------------------------------------------------------------------------------------------------------
+# fp16x3 1x1 convolution / channel-mixing product (both operands split in the kernel): NIN's 1x1 layers, Gram backward
+# ---------------------------------------------------------------------------------------------------------
+P1_CASES = [(96, 96, 40, 41), (256, 256, 27, 27), (100, 70, 9, 37), (64, 64, 64, 65), (1024, 1000, 6, 7), (32, 128, 1, 5),
+            (384, 384, 13, 13), (8, 8, 16, 16)]
+
+
+@pytest.mark.parametrize("cin,cout,H,W", P1_CASES)
+def test_conv1x1_x3_forward_and_backward(hip, cin, cout, H, W):
+    x = rnd(2, cin, H, W, seed=1)
+    w = rnd(cout, cin, seed=2, scale=math.sqrt(2.0 / cin))
+    b = rnd(cout, seed=3, scale=0.1)
+    ref = torch.relu(torch.einsum("oc,nchw->nohw", w.double(), x.double()) + b.double()[None, :, None, None])
+    y = hip.conv1x1_x3(dev(x), dev(w), dev(b), relu=True)
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape
+    assert rel_l2(y.cpu(), ref) <= 2e-6
+    gy = rnd(*ref.shape, seed=4)
+    refb = torch.einsum("oc,nohw->nchw", w.double(), gy.double())
+    mask, base = rnd(*x.shape, seed=6), rnd(*x.shape, seed=5)
+    wt = dev(w.t().contiguous())
+    gx = hip.conv1x1_x3(dev(gy), wt, out_relu_mask=dev(mask))
+    torch.cuda.synchronize()
+    assert rel_l2(gx.cpu(), refb * (mask > 0)) <= 2e-6
+    gx2 = hip.conv1x1_x3(dev(gy), wt, out=dev(base.clone()), accumulate=True)
+    gx3 = hip.conv1x1_x3(dev(gy), wt, out=dev(base.clone()), accumulate=True)
+    torch.cuda.synchronize()
+    assert rel_l2(gx2.cpu(), refb + base.double()) <= 2e-6
+    assert torch.equal(gx2, gx3)
+
+
+@pytest.mark.parametrize("cin,cout,hw", [(128, 128, 4096), (100, 100, 777), (512, 512, 1024)])
+def test_conv1x1_x3_channel_shift_is_the_gram_centring(hip, cin, cout, hw):
+    """y = W (x - shift) with the shift applied before the split: features with a mean well above their spread (post-ReLU
+    maps) keep full accuracy - the subtraction is exact in fp32 terms and only the centred values are split."""
+    x = torch.relu(rnd(1, cin, hw, seed=1)) + 5.0
+    shift = x[0].mean(1)
+    w = rnd(cout, cin, seed=2)
+    w = w + w.t() if cin == cout else w
+    ref = torch.einsum("oc,ncp->nop", w.double(), (x - shift[None, :, None]).double())
+    y = hip.conv1x1_x3(dev(x), dev(w), x_shift=dev(shift))
+    torch.cuda.synchronize()
+    assert rel_l2(y.cpu(), ref) <= 2e-6
+
+
+def test_gram_bwd_fp32_route_subprocess():
+    """MAUA_GRAM_BWD_X3=0 (read once per process) keeps the fp32-MFMA Gram backward; both routes agree to fp32 level."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch; sys.path[:0] = [%r, %r]; import hip\n"
+        "g = torch.Generator().manual_seed(3)\n"
+        "f = torch.relu(torch.randn(1, 128, 64, 72, generator=g)).cuda(); d = torch.randn(128, 128, generator=g); d = (d + d.t()).cuda()\n"
+        "gram, mean = hip.gram_fwd(f, 1e-3, True)\n"
+        "gf = hip.gram_bwd(d, f, mean, torch.zeros(128, 64 * 72, device='cuda'), False, relu_mask=f); torch.cuda.synchronize()\n"
+        "torch.save(gf.cpu(), sys.argv[1])\n") % (REPO, PKG)
+    outs = []
+    for flag in ("0", "1"):
+        path = os.path.join(tempfile.mkdtemp(), "gf.pt")
+        env = dict(os.environ, MAUA_GRAM_BWD_X3=flag)
+        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append(torch.load(path))
+    assert not torch.equal(outs[0], outs[1])  # different arithmetic really ran
+    assert rel_l2(outs[1], outs[0].double()) <= 2e-6
+
+
+@pytest.mark.parametrize("cin,cout,hw", [(512, 512, 4096), (1024, 1024, 36), (256, 64, 1000)])
+def test_conv1x1_x3_split_k_matches_single_pass(hip, cin, cout, hw):
+    assert hip.conv1x1_x3_workspace_bytes(1, cin, hw, cout) > 0
+    assert hip.conv1x1_x3_workspace_bytes(1, 64, 1 << 20, 64) == 0
+    x = rnd(1, cin, hw, seed=1)
+    w = rnd(cout, cin, seed=2, scale=math.sqrt(2.0 / cin))
+    b = rnd(cout, seed=3, scale=0.1)
+    base, mask = rnd(1, cout, hw, seed=5), rnd(1, cout, hw, seed=6)
+    ref = torch.relu(torch.einsum("oc,ncp->nop", w.double(), x.double()) + b.double()[None, :, None] + base.double()) * (mask > 0)
+    none = torch.empty(0, dtype=torch.uint8, device="cuda")
+    one = hip.conv1x1_x3(dev(x), dev(w), dev(b), relu=True, out=dev(base.clone()), accumulate=True, out_relu_mask=dev(mask),
+                         workspace=none)
+    split = hip.conv1x1_x3(dev(x), dev(w), dev(b), relu=True, out=dev(base.clone()), accumulate=True, out_relu_mask=dev(mask))
+    torch.cuda.synchronize()
+    assert rel_l2(one.cpu(), ref) <= 2e-6 and rel_l2(split.cpu(), ref) <= 2e-6
+    assert rel_l2(split.cpu(), one.cpu().double()) <= 5e-7
+
+
+@pytest.mark.parametrize("kind", ["wide_range", "tiny", "huge", "zeros", "one_hot", "wide_weights"])
+def test_conv1x1_x3_scaling_survives_extreme_inputs(hip, kind):
+    cin, cout, hw = 128, 128, 1600
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(1, cin, hw, generator=g)
+    w = rnd(cout, cin, seed=2, scale=math.sqrt(2.0 / cin))
+    if kind == "wide_range":
+        x = x * torch.exp(torch.randn(1, cin, hw, generator=g) * 4.0) * 1e-6 * (torch.rand(1, cin, hw, generator=g) > 0.5)
+    elif kind == "tiny":
+        x = x * 1e-30
+    elif kind == "huge":
+        x = x * 1e30
+    elif kind == "zeros":
+        x = torch.zeros_like(x)
+    elif kind == "one_hot":
+        x = torch.zeros_like(x)
+        x[0, 17, 420] = 3.0e-12
+    elif kind == "wide_weights":  # a Gram difference whose rows span many decades (fresh style targets vs a noise image)
+        w = w * torch.exp(torch.randn(cout, 1, generator=g) * 5.0) * 1e-4
+    ref = torch.einsum("oc,ncp->nop", w.double(), x.double())
+    y = hip.conv1x1_x3(dev(x), dev(w))
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+    if kind == "zeros":
+        assert float(y.abs().max()) == 0.0
+    else:
+        assert rel_l2(y.cpu(), ref) <= 2e-6
+
+
 def test_conv3x3_x6_persistent_workgroups_subprocess():
     """MAUA_X6_PERSIST=1 (read once per process): several tiles per workgroup with cross-tile prefetch, in-loop epilogue
     and accumulator re-initialisation must give the same bits as one workgroup per tile."""
