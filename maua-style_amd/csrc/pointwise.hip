@@ -137,47 +137,71 @@ __global__ void pool_bwd_kernel(const float* __restrict__ gy, const float* __res
     }
 }
 
-// Max-pool backward with compile-time window / stride (NIN's 3x3 stride-2 ceil-mode pools): same gather form and tie rule
-// as the generic kernel, but the window loops unroll, the divisions by the stride become shifts and the indices come
-// from a 3-D grid (x, y, plane).  Overlapping windows make a scatter form need float atomics, i.e. an order that changes
-// from run to run; the gather form stays bit-reproducible.
-template <int K, int S>
+// Max-pool backward for 3x3 windows at stride 2 (NIN's ceil-mode pools, reference models.py:77-80): gather form with
+// the generic kernel's tie rule (first maximum in scan order, NaN wins), so it stays bit-reproducible - a scatter form
+// would need float atomics over the overlapping windows.  A workgroup owns a 32 x 32 block of input pixels: it stages
+// the 35 x 35 inputs under the 17 x 17 windows that touch the block in LDS, finds every window's arg-max ONCE (the
+// per-pixel form re-scans up to four windows = 36 loads per pixel), then each pixel collects the gradient of the at
+// most four windows that cover it and elected it, in ascending (oy, ox) order.  HBM traffic: x once (+ halo), gy once,
+// gx once.
+constexpr int P3_TO = 16, P3_TI = 2 * P3_TO + 3, P3_TW = P3_TO + 1;
+
 __global__ void __launch_bounds__(256)
-pool_max_bwd_ks_kernel(const float* __restrict__ gy, const float* __restrict__ x, float* __restrict__ gx, int H, int W, int OH,
+pool3s2_max_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x, float* __restrict__ gx, int H, int W, int OH,
                        int OW, int relu_mask) {
-    const int ix = blockIdx.x * 256 + threadIdx.x, iy = blockIdx.y;
-    if (ix >= W) return;
+    __shared__ float xt[P3_TI * P3_TI];
+    __shared__ int warg[P3_TW * P3_TW];
+    __shared__ float wgrad[P3_TW * P3_TW];
+    const int tid = threadIdx.x;
+    const int oy0 = blockIdx.y * P3_TO, ox0 = blockIdx.x * P3_TO;
+    const int iy0 = 2 * oy0 - 2, ix0 = 2 * ox0 - 2;  // tile origin: two pixels of halo for the windows of row / column -1
     const float* plane = x + (int64_t)blockIdx.z * H * W;
     const float* gplane = gy + (int64_t)blockIdx.z * OH * OW;
-    const int oy_lo = max(0, (iy - K + S) / S), oy_hi = min(OH - 1, iy / S);
-    const int ox_lo = max(0, (ix - K + S) / S), ox_hi = min(OW - 1, ix / S);
-    const int self = iy * W + ix;
-    float acc = 0.f;
+    for (int i = tid; i < P3_TI * P3_TI; i += 256) {
+        const int ty = i / P3_TI, tx = i - ty * P3_TI;
+        const int Y = iy0 + ty, X = ix0 + tx;
+        xt[i] = (Y >= 0 && Y < H && X >= 0 && X < W) ? plane[Y * W + X] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < P3_TW * P3_TW; i += 256) {
+        const int wy = i / P3_TW, wx = i - wy * P3_TW;
+        const int oy = oy0 - 1 + wy, ox = ox0 - 1 + wx;
+        int arg = -1;
+        float g = 0.f;
+        if (oy >= 0 && oy < OH && ox >= 0 && ox < OW) {
+            g = gplane[oy * OW + ox];
+            int best = 2 * wy * P3_TI + 2 * wx;
+            float bv = xt[best];
 #pragma unroll
-    for (int dy = 0; dy < (K + S - 1) / S; ++dy)
+            for (int yy = 0; yy < 3; ++yy)
 #pragma unroll
-        for (int dx = 0; dx < (K + S - 1) / S; ++dx) {
-            const int oy = oy_lo + dy, ox = ox_lo + dx;
-            if (oy > oy_hi || ox > ox_hi) continue;
-            const int y0 = oy * S, x0 = ox * S;
-            if (y0 > iy || y0 + K <= iy || x0 > ix || x0 + K <= ix) continue;
-            int best = y0 * W + x0;
-            float bv = plane[best];
-#pragma unroll
-            for (int yy = 0; yy < K; ++yy)
-#pragma unroll
-                for (int xx = 0; xx < K; ++xx) {
-                    if (y0 + yy >= H || x0 + xx >= W) continue;
-                    const float v = plane[(y0 + yy) * W + x0 + xx];
+                for (int xx = 0; xx < 3; ++xx) {
+                    if (2 * oy + yy >= H || 2 * ox + xx >= W) continue;
+                    const int idx = (2 * wy + yy) * P3_TI + 2 * wx + xx;
+                    const float v = xt[idx];
                     if (v > bv || v != v) {
                         bv = v;
-                        best = (y0 + yy) * W + x0 + xx;
+                        best = idx;
                     }
                 }
-            if (best == self) acc += gplane[oy * OW + ox];
+            arg = best;
         }
-    if (relu_mask && !(plane[self] > 0.f)) acc = 0.f;
-    gx[(int64_t)blockIdx.z * H * W + self] = acc;
+        warg[i] = arg;
+        wgrad[i] = g;
+    }
+    __syncthreads();
+    for (int i = tid; i < 4 * P3_TO * P3_TO; i += 256) {
+        const int py = 2 + i / (2 * P3_TO), px = 2 + i % (2 * P3_TO);
+        const int Y = iy0 + py, X = ix0 + px;
+        if (Y >= H || X >= W) continue;
+        const int self = py * P3_TI + px;
+        float acc = 0.f;
+        for (int wy = (py - 1) / 2; wy <= py / 2; ++wy)
+            for (int wx = (px - 1) / 2; wx <= px / 2; ++wx)
+                if (warg[wy * P3_TW + wx] == self) acc += wgrad[wy * P3_TW + wx];
+        if (relu_mask && !(xt[self] > 0.f)) acc = 0.f;
+        gx[(int64_t)blockIdx.z * H * W + Y * W + X] = acc;
+    }
 }
 
 // 2x2 stride-2 max pooling on even-sized planes (every VGG pool): one thread per window, 8-byte accesses, no divisions.
@@ -375,10 +399,10 @@ int maua_pool2d_bwd(const float* gy, const float* x, float* gx, int n, int c, in
                            ow, relu_mask_by_x);
         return check_launch("pool2x2_bwd_kernel");
     }
-    if (mode == 0 && k == 3 && stride == 2 && (int64_t)n * c <= 65535 && h <= 65535) {
-        hipLaunchKernelGGL((pool_max_bwd_ks_kernel<3, 2>), dim3((w + 255) / 256, h, n * c), dim3(256), 0, (hipStream_t)stream, gy,
-                           x, gx, h, w, oh, ow, relu_mask_by_x);
-        return check_launch("pool_max_bwd_ks_kernel");
+    if (mode == 0 && k == 3 && stride == 2 && (int64_t)n * c <= 65535 && h <= 65535 * 32) {
+        hipLaunchKernelGGL(pool3s2_max_bwd_kernel, dim3((w + 2 * P3_TO - 1) / (2 * P3_TO), (h + 2 * P3_TO - 1) / (2 * P3_TO), n * c),
+                           dim3(256), 0, (hipStream_t)stream, gy, x, gx, h, w, oh, ow, relu_mask_by_x);
+        return check_launch("pool3s2_max_bwd_kernel");
     }
     const int64_t total = (int64_t)n * c * h * w;
     hipLaunchKernelGGL(pool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, gy, x, gx, (int64_t)n * c,

@@ -66,6 +66,22 @@ def conv3x3_mfma(x, mod, backward, out=None, out_relu_mask=None, relu=False, wor
                           workspace=workspace)
 
 
+def conv1x1_is_mfma(mod, backward):
+    """Whether a layer's pass runs on the fp16x3 1x1 kernel (conv1x1_x3.hip): 1x1, stride 1, no padding (NIN's cccp layers,
+    reference models.py:84-110), the split-precision path enabled for that pass and fp16x3 selected."""
+    k, stride, pad = mod.kernel_size[0], mod.stride[0], mod.padding[0]
+    produced = mod.in_channels if backward else mod.out_channels
+    return _x6_mode()[1 if backward else 0] and _x3_enabled() and k == 1 and stride == 1 and pad == 0 and produced > 32
+
+
+def conv1x1_mfma(x, mod, backward, out=None, out_relu_mask=None, relu=False, workspace=None):
+    """1x1 layer on the fp16 matrix cores in fp16x3 arithmetic; backward-data multiplies by the transposed weights."""
+    w2d, w2d_t = mod.mats()
+    if backward:
+        return hip.conv1x1_x3(x, w2d_t, None, False, out=out, out_relu_mask=out_relu_mask, workspace=workspace)
+    return hip.conv1x1_x3(x, w2d, mod.bias_device(), relu, out=out, out_relu_mask=out_relu_mask, workspace=workspace)
+
+
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mod):
@@ -73,6 +89,8 @@ class _ConvFn(torch.autograd.Function):
         k, stride, pad = mod.kernel_size[0], mod.stride[0], mod.padding[0]
         if _x6_mode()[0] and k == 3 and stride == 1 and pad <= 2 and mod.out_channels > 32:
             return conv3x3_mfma(x.contiguous(), mod, False)
+        if conv1x1_is_mfma(mod, False):
+            return conv1x1_mfma(x.contiguous(), mod, False)
         return hip.conv2d_fwd(x.contiguous(), mod.banks()[0], mod.bias_device(), k, stride, pad, False)
 
     @staticmethod
@@ -81,6 +99,8 @@ class _ConvFn(torch.autograd.Function):
         k, stride, pad = mod.kernel_size[0], mod.stride[0], mod.padding[0]
         if _x6_mode()[1] and k == 3 and stride == 1 and pad <= 2 and mod.in_channels > 32:
             return conv3x3_mfma(gy.contiguous(), mod, True), None
+        if conv1x1_is_mfma(mod, True):
+            return conv1x1_mfma(gy.contiguous(), mod, True), None
         gx = hip.conv2d_bwd_data(gy.contiguous(), None, mod.banks()[1], mod.weight.detach(), ctx.in_shape, k, stride, pad)
         return gx, None
 
@@ -114,6 +134,15 @@ class Conv2d(nn.Conv2d):
             self._banks3 = hip.conv_pack_filters_x3(self.weight.detach().contiguous())
             self._bank3_key = key
         return self._banks3
+
+    def mats(self):
+        """1x1 layers: the weights as plain matrices ([cout][cin], [cin][cout]) for the fp16x3 1x1 kernel."""
+        key = (self.weight.data_ptr(), self.weight._version, self.weight.device)
+        if getattr(self, "_mats_key", None) != key:
+            w2d = self.weight.detach().reshape(self.out_channels, self.in_channels).contiguous()
+            self._mats = (w2d, w2d.t().contiguous())
+            self._mats_key = key
+        return self._mats
 
     def bias_device(self):
         return None if self.bias is None else self.bias.detach()

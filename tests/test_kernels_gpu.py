@@ -135,7 +135,8 @@ def test_conv_rejects_bad_arguments(hip):
 
 
 @pytest.mark.parametrize("C,H,W,k,s,ceil", [(64, 32, 32, 2, 2, False), (5, 7, 9, 2, 2, False), (96, 30, 30, 3, 2, True),
-                                            (16, 31, 29, 3, 2, True), (8, 63, 63, 3, 2, True), (4, 3, 3, 3, 2, True)])
+                                            (16, 31, 29, 3, 2, True), (8, 63, 63, 3, 2, True), (4, 3, 3, 3, 2, True),
+                                            (3, 253, 253, 3, 2, True), (2, 127, 90, 3, 2, True), (2, 64, 33, 3, 2, False)])
 @pytest.mark.parametrize("mode", ["max", "avg"])
 def test_pool(hip, C, H, W, k, s, ceil, mode):
     x = torch.relu(rnd(2, C, H, W, seed=7))  # post-ReLU inputs: many exact ties at zero
@@ -621,6 +622,21 @@ def test_conv_bwd_producer_side_relu_mask(hip, cin, cout, H, W, k, stride, pad):
     gx = hip.conv2d_bwd_data(dev(gy), None, wb, dev(w), x.shape, k, stride, pad, in_relu_mask=dev(x))
     torch.cuda.synchronize()
     assert rel_l2(gx.cpu(), ref) <= TOL
+
+
+def test_pool3x3s2_backward_with_relu_mask_equals_unmasked_times_mask(hip):
+    """The LDS-tiled 3x3 stride-2 kernel: bit-equal to gradient * (x > 0), and bit-reproducible (gather form, no atomics)."""
+    x = torch.relu(rnd(2, 6, 127, 125, seed=7))
+    gy = rnd(2, 6, 63, 62, seed=8)
+    plain = hip.pool2d_bwd(dev(gy), dev(x), 3, 2, True, "max")
+    masked = hip.pool2d_bwd(dev(gy), dev(x), 3, 2, True, "max", relu_mask_by_x=True)
+    again = hip.pool2d_bwd(dev(gy), dev(x), 3, 2, True, "max", relu_mask_by_x=True)
+    torch.cuda.synchronize()
+    assert torch.equal(masked.cpu(), plain.cpu() * (x > 0))
+    assert torch.equal(masked, again)
+    xr = x.clone().requires_grad_(True)
+    F.max_pool2d(xr, 3, 2, 0, ceil_mode=True).backward(gy)
+    assert rel_l2(plain.cpu(), xr.grad) <= 1e-6
 
 
 def test_masks_on_pool_mse_gram_backward(hip):
