@@ -112,9 +112,8 @@ class StyleEngine:
     def _prepare(self, x):
         if self.shape == tuple(x.shape):
             return
-        if x.shape[0] != 1:
-            raise UnsupportedNet("the fused plan optimises one frame per call (B = 1), like img_img / vid_img")
         dev = x.device
+        B = x.shape[0]
         self.shape = tuple(x.shape)
         self.graph = None
         shapes = {0: tuple(x.shape)}
@@ -127,18 +126,36 @@ class StyleEngine:
                 shapes[s.dst] = (n, c, hip.pool_out_size(h, s.k, s.stride, s.ceil), hip.pool_out_size(w, s.k, s.stride, s.ceil))
         self.act = {k: (None if k == 0 else torch.empty(v, device=dev)) for k, v in shapes.items()}
         self.gbuf = {k: torch.empty(v, device=dev) for k, v in shapes.items()}
-        self.slots = torch.zeros(max(len(self.losses), 1), device=dev)
+        # B > 1 (img_vid's windows of frames): every loss module has several terms - one per frame, plus the cross-frame
+        # dynamic Gram term of a StyleLoss - each with its own slot behind the per-module ones
+        self.terms = {}
+        n_slots = max(len(self.losses), 1)
+        if B > 1:
+            for s in self.steps:
+                if s.kind in ("style", "content"):
+                    count = B + (1 if s.kind == "style" else 0)
+                    self.terms[id(s)] = list(range(n_slots, n_slots + count))
+                    n_slots += count
+        self.slots_all = torch.zeros(n_slots, device=dev)
+        self.slots = self.slots_all[:max(len(self.losses), 1)]
         self.total = torch.zeros(1, device=dev)
         self.gram, self.dmat, self.mean = {}, {}, {}
+        self.gram_d, self.dmat_d, self.mean_d = {}, {}, {}
         ws = hip.reduce_workspace_bytes(max(t.numel() for t in self.gbuf.values()))
         for s in self.steps:
             if s.kind == "style":
                 c = shapes[s.src][1]
                 hw = shapes[s.src][2] * shapes[s.src][3]
-                self.gram[id(s)] = torch.empty(c, c, device=dev)
-                self.dmat[id(s)] = torch.empty(c, c, device=dev)
-                self.mean[id(s)] = torch.empty(c, device=dev) if s.mod.use_covariance else None
+                self.gram[id(s)] = torch.empty(B, c, c, device=dev) if B > 1 else torch.empty(c, c, device=dev)
+                self.dmat[id(s)] = torch.empty(B, c, c, device=dev) if B > 1 else torch.empty(c, c, device=dev)
+                self.mean[id(s)] = (torch.empty(B, c, device=dev) if B > 1 else torch.empty(c, device=dev)) \
+                    if s.mod.use_covariance else None
                 ws = max(ws, hip.gram_workspace_bytes(c, hw), 4 * c + 256)
+                if B > 1:  # the dynamic term's (B C) x (B C) Gram over the whole window
+                    self.gram_d[id(s)] = torch.empty(B * c, B * c, device=dev)
+                    self.dmat_d[id(s)] = torch.empty(B * c, B * c, device=dev)
+                    self.mean_d[id(s)] = torch.empty(B * c, device=dev) if s.mod.use_covariance else None
+                    ws = max(ws, hip.gram_workspace_bytes(B * c, hw), 4 * B * c + 256)
         for s in self.steps:  # split-K workspaces of the bf16x6 convs (forward and backward-data geometry)
             if s.kind == "conv" and s.stride == 1:
                 n, cin, h, w = shapes[s.src]
@@ -156,6 +173,21 @@ class StyleEngine:
         self.x_static = torch.empty(self.shape, device=dev)
 
     # -- one evaluation --------------------------------------------------------------------------------
+    def _style_terms(self, s, B):
+        """B > 1: ((loss weight, gradient weight) of one frame's static term, the same for the dynamic term or None).
+        loss.py:141-181: each frame's MSE enters with strength / B, the cross-frame one with video_style_factor * strength / B;
+        with `normalize` the gradient passes ScaleGradients (sign * strength^2) instead."""
+        m = s.mod
+        st, vsf = m.strength, m.video_style_factor
+        static = (st / B, _scale_grad_coeff(st / B, st) if m.normalize else st / B)
+        dynamic = None
+        if vsf > 0:
+            if m.video_target.nelement() == 0:
+                raise RuntimeError(f"{m.name}: dynamic style target not captured")
+            if m.video_target.shape[0] == B * m.target.shape[0]:  # otherwise the reference skips the term (loss.py:165-166)
+                dynamic = (vsf * st / B, _scale_grad_coeff(vsf * st / B, st) if m.normalize else vsf * st / B)
+        return static, dynamic
+
     def _coefficients(self, s):
         """(reported-loss weight, gradient weight) of a loss step for B = 1."""
         m = s.mod
@@ -182,6 +214,8 @@ class StyleEngine:
                 return False  # temporal module without a target (loss.py:46-47) or never captured
             if tuple(m.target.shape[1:]) != tuple(shapes_src[1:]):
                 return False  # loss.py:44
+            if shapes_src[0] > 1 and (m.weights is not None or m.target.shape[0] != 1):
+                raise UnsupportedNet("weighted / multi-frame-target ContentLoss on B > 1 frames runs on the module path")
             if m.weights is not None:
                 w = m.weights
                 if s.src != 0 or w.dim() != 4 or w.shape[0] != 1 or tuple(w.shape[2:]) != tuple(shapes_src[2:]) \
@@ -190,7 +224,8 @@ class StyleEngine:
             return True
         if m.target.nelement() == 0:
             raise RuntimeError(f"{m.name}: style target not captured")
-        if m.video_style_factor > 0 and m.video_target.nelement() != 0 and m.video_target.shape != m.target.shape:
+        if shapes_src[0] == 1 and m.video_style_factor > 0 and m.video_target.nelement() != 0 \
+                and m.video_target.shape != m.target.shape:
             raise UnsupportedNet("dynamic style target of another shape")
         return True
 
@@ -223,7 +258,7 @@ class StyleEngine:
     def _run(self, x):
         a, g = self.act, self.gbuf
         a[0] = x
-        hip.fill_(self.slots, 0.0)
+        hip.fill_(self.slots_all, 0.0)
         # ---------------- forward
         for s in self.steps:
             if s.kind == "conv":
@@ -242,6 +277,26 @@ class StyleEngine:
                 hip.relu_(a[s.src])
             elif s.kind == "pool":
                 hip.pool2d_fwd(a[s.src], s.k, s.stride, s.ceil, s.mode, out=a[s.dst])
+            elif s.kind == "style" and self._active(s, a[s.src].shape) and a[s.src].shape[0] > 1:
+                f = a[s.src]
+                B, c, n = f.shape[0], f.shape[1], f[0].nelement()
+                (lw, gw), dynamic = self._style_terms(s, B)
+                slots = self.terms[id(s)]
+                cov = s.mod.use_covariance
+                for b in range(B):  # static terms: one C x C Gram per frame against the shared target
+                    mean_b = self.mean[id(s)][b] if cov else None
+                    self._timed("gram_fwd", 2 * c * c * (n // c), n * 4 + c * c * 4, lambda: hip.gram_fwd(
+                        f[b:b + 1], 1.0 / n, cov, out=self.gram[id(s)][b], mean_out=mean_b, workspace=self.ws))
+                    hip.mse_fwd_bwd(self.gram[id(s)][b], s.mod.target, self.dmat[id(s)][b], lw / (c * c), gw * 4.0 / (c * c) / n,
+                                    False, self.slots_all[slots[b]:slots[b] + 1], workspace=self.ws)
+                if dynamic is not None:  # one (B C) x (B C) Gram over the window: rows are (frame, channel) pairs
+                    lwd, gwd = dynamic
+                    bc, nall = B * c, B * n
+                    self._timed("gram_fwd", 2 * bc * bc * (n // c), nall * 4 + bc * bc * 4, lambda: hip.gram_fwd(
+                        f.view(1, bc, f.shape[2], f.shape[3]), 1.0 / nall, cov, out=self.gram_d[id(s)],
+                        mean_out=self.mean_d[id(s)], workspace=self.ws))
+                    hip.mse_fwd_bwd(self.gram_d[id(s)], s.mod.video_target, self.dmat_d[id(s)], lwd / (bc * bc),
+                                    gwd * 4.0 / (bc * bc) / nall, False, self.slots_all[slots[B]:slots[B] + 1], workspace=self.ws)
             elif s.kind == "style" and self._active(s, a[s.src].shape):
                 f = a[s.src]
                 c, n = f.shape[1], f[0].nelement()
@@ -266,7 +321,40 @@ class StyleEngine:
 
         cur = None  # activation index whose gradient buffer currently holds d loss / d act
         for s in reversed(self.steps):
-            if s.kind == "style":
+            if s.kind == "style" and a[s.src].shape[0] > 1:
+                if self._active(s, a[s.src].shape):
+                    f = a[s.src]
+                    B, c, n = f.shape[0], f.shape[1], f[0].nelement()
+                    _, dynamic = self._style_terms(s, B)
+                    acc = cur == s.src
+                    cov = s.mod.use_covariance
+                    last_is_static = dynamic is None  # the last writer of a slice applies the producer's ReLU mask
+                    for b in range(B):
+                        rm = f[b] if (premask(s) and last_is_static) else None
+                        self._timed("gram_bwd", 2 * c * c * (n // c), n * 4 * 3 + c * c * 4, lambda: hip.gram_bwd(
+                            self.dmat[id(s)][b], f[b], self.mean[id(s)][b] if cov else None, g[s.src][b], acc, workspace=self.ws,
+                            relu_mask=rm))
+                    if dynamic is not None:
+                        bc = B * c
+                        self._timed("gram_bwd", 2 * bc * bc * (n // c), B * n * 4 * 3 + bc * bc * 4, lambda: hip.gram_bwd(
+                            self.dmat_d[id(s)], f, self.mean_d[id(s)], g[s.src], True, workspace=self.ws,
+                            relu_mask=f if premask(s) else None))
+                    cur = s.src
+            elif s.kind == "content" and a[s.src].shape[0] > 1:
+                if self._active(s, a[s.src].shape):
+                    # loss.py:48-58 loops over the frames: MSE of each frame against the single-frame target, entering with
+                    # strength / B (through ScaleGradients when normalising: sign * strength^2, no 1 / B)
+                    x = a[s.src]
+                    B, n = x.shape[0], x[0].nelement()
+                    st = s.mod.strength
+                    lw = st / B
+                    gw = _scale_grad_coeff(st / B, st) if s.mod.normalize else st / B
+                    slots = self.terms[id(s)]
+                    for b in range(B):
+                        hip.mse_fwd_bwd(x[b], s.mod.target[0], g[s.src][b], lw / n, gw * 2.0 / n, cur == s.src,
+                                        self.slots_all[slots[b]:slots[b] + 1], workspace=self.ws, mask_grad_by_x=premask(s))
+                    cur = s.src
+            elif s.kind == "style":
                 if self._active(s, a[s.src].shape):
                     f = a[s.src]
                     c, n = f.shape[1], f[0].nelement()
@@ -316,7 +404,11 @@ class StyleEngine:
                 cur = s.src
         if cur != 0:
             hip.fill_(g[0], 0.0)
-        hip.sum_small(self.slots, self.total)
+        hip.sum_small(self.slots_all, self.total)
+        for s in self.steps:  # B > 1: a module's reported loss is the sum of its terms (after the total, which has them once)
+            if id(s) in self.terms:
+                t = self.terms[id(s)]
+                self.slots_all[s.slot:s.slot + 1] = self.slots_all[t[0]:t[-1] + 1].sum(0, keepdim=True)
 
     def capture_content(self, x):
         """optim.set_content_targets on the fused plan: one forward pass (convs and pools only, preallocated buffers) and
@@ -345,7 +437,7 @@ class StyleEngine:
             s.mod.target = a[s.src].detach().clone()
 
     def feval(self, x, capture=False):
-        """Evaluate at `x` (1,3,H,W fp32 on the GPU).  Returns (per-module loss slots in `losses` order, total
+        """Evaluate at `x` (B,3,H,W fp32 on the GPU; B > 1 = a window of frames with per-frame and cross-frame style terms).  Returns (per-module loss slots in `losses` order, total
         loss, gradient) - device tensors owned by the engine, overwritten by the next call; no host sync."""
         self._prepare(x)
         if not capture:

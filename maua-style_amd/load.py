@@ -61,7 +61,15 @@ def save_tensor_to_file(tensor, args, iteration=None, size=None, filename=None):
         else:
             filename = f"{args.output}_{size}_{iteration}"
     if tensor.size()[0] > 1:
-        raise NotImplementedError("writing multi-frame tensors needs skvideo/ffmpeg, which this build does not have")
+        # The reference hands the clip to skvideo/ffmpeg as "<filename>.mp4" (load.py:65-69); codecs are out of scope here,
+        # so the same frames (mean added back, BGR -> RGB, clamped, truncated to 8 bits) go to a directory of PNGs named
+        # like the video would have been, which preprocess_video reads back.
+        os.makedirs(filename, exist_ok=True)
+        clip = tensor.detach().float().cpu() + _MEAN_BGR[None, :, None, None]
+        clip = clip[:, th.LongTensor([2, 1, 0])].permute(0, 2, 3, 1).clamp_(0, 255).byte().numpy()
+        for t, frame in enumerate(clip):
+            Image.fromarray(frame, mode="RGB").save(f"{filename}/frame_{t:05d}.png")
+        return
     img = deprocess(tensor.clone())
     if args.original_colors == 1:
         img = original_colors(deprocess(preprocess(args.content)), img)
@@ -77,6 +85,23 @@ def process_style_images(args):
         else:
             paths.append(entry)
     return [preprocess(p) for p in paths]
+
+
+def preprocess_video(video_path, fps=None):
+    """A clip as (T,3,H,W) network-space tensor (reference load.py:35-43).  The reference decodes with skvideo at `fps`
+    and falls back to a single image; here a clip is a directory of frame images (sorted by name), and a single image
+    is a one-frame clip."""
+    if os.path.isdir(video_path):
+        return th.cat([preprocess(p) for p in process_content_frames(video_path)], dim=0)
+    if os.path.splitext(video_path)[1].lower() in _EXT:
+        return preprocess(video_path)
+    raise NotImplementedError(f"{video_path}: decoding video files needs skvideo/ffmpeg; pass a directory of frame images")
+
+
+def process_style_videos(args):
+    """Every --style entry is one style clip (reference load.py:103-136: a list of videos, blend weights normalised to
+    sum to one - config.get_args has already done that here)."""
+    return [preprocess_video(entry, getattr(args, "fps", None)) for entry in args.style]
 
 
 def process_content_frames(content):

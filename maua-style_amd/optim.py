@@ -10,9 +10,11 @@ torch.optim.LBFGS's four host round trips per iteration are gone.  The loss is r
 `--print_iter` fires.
 """
 import json
+import math
 import os
 import sys
 
+import numpy as np
 import torch as th
 import tqdm
 
@@ -20,7 +22,7 @@ import config as config_mod
 import engine as engine_mod
 import hip
 import models
-from utils import limit_host_threads
+from utils import limit_host_threads, wrapping_slice
 
 PBAR = tqdm.tqdm(file=sys.stdout, smoothing=0.1, disable=not sys.stdout.isatty())
 
@@ -94,8 +96,23 @@ def set_style_targets(net, style_images, args):
 
 
 def set_style_video_targets(net, style_videos, args):
-    """Window-averaged video style targets (reference optim.py:69-90); img_vid only, outside this build."""
-    raise NotImplementedError("video style targets belong to the img_vid workflow, which this build does not cover")
+    """Style targets averaged over every window of `gram_frame_window` consecutive frames of each style video
+    (reference optim.py:69-90): the per-frame Gram target and, through StyleLoss.dynamic_loss, the cross-frame
+    (B*C) x (B*C) one.  The blend weight is divided by the number of windows, as the reference does."""
+    _describe("Capturing style video targets...", args)
+    window = int(args.gram_frame_window)
+    for mod in net.style_losses:
+        mod.reset_targets()
+        mod.mode = "capture"
+    for i, video in enumerate(style_videos):
+        n_windows = max(len(video) - window + 1, 1)
+        for mod in net.style_losses:
+            mod.blend_weight = args.style_blend_weights[i] / n_windows
+        for start in range(n_windows):
+            with th.no_grad():
+                net(_device_image(video[start:start + window], args))
+    for mod in net.style_losses:
+        mod.mode = "none"
 
 
 def set_model_args(args, current_size):
@@ -137,8 +154,9 @@ GRAPH_MIN_ITERS = 128
 class PixelOptimizer:
     """The iteration loop for one image: fused feval + device-side optimizer step."""
 
-    def __init__(self, net, losses, init, args, planned_iters=None):
+    def __init__(self, net, losses, init, args, planned_iters=None, grad_hook=None):
         self.args = args
+        self.grad_hook = grad_hook  # in-place edit of the gradient before the optimiser sees it (img_vid's overlap masking)
         try:
             self.engine = getattr(net, "_maua_engine", None) or engine_mod.StyleEngine(net, losses)
             net._maua_engine = self.engine
@@ -199,12 +217,16 @@ class PixelOptimizer:
             return self.engine.slots, self.engine.total
         a = self.args
         slots, total, grad = self.engine.feval(self.x)
+        if self.grad_hook is not None:
+            self.grad_hook(grad)
         self.state.iterate(self.x, grad, 1.0, float(a.lbfgs_tolerance_change))
         self.step_count += 1
         th.cuda.synchronize()
         graph = th.cuda.CUDAGraph()
         with th.cuda.graph(graph):
             self.engine._run(self.x)
+            if self.grad_hook is not None:
+                self.grad_hook(self.engine.gbuf[0])
             self.state.iterate(self.x, self.engine.gbuf[0], 1.0, float(a.lbfgs_tolerance_change))
         self._graph = graph
         return slots, total
@@ -217,6 +239,8 @@ class PixelOptimizer:
             except engine_mod.UnsupportedNet:
                 self.engine = None
         slots, total, grad = self.feval()
+        if self.grad_hook is not None:
+            self.grad_hook(grad)
         self.step_count += 1
         a = self.args
         if self.kind == "lbfgs":
@@ -226,10 +250,94 @@ class PixelOptimizer:
         return slots, total
 
 
+def _run_iterations(opt, num_iters, args, save_offset=0, save_total=None):
+    """The reference's `while i[0] <= iters: optimizer.step(feval)` loop (optim.py:196-241) on a PixelOptimizer."""
+    if args.optimizer == "lbfgs":
+        _describe("Running optimization with L-BFGS", args)
+        steps = lbfgs_moves(num_iters)
+    else:
+        _describe("Running optimization with ADAM", args)
+        steps = num_iters + 1  # `while i[0] <= iters` with i starting at 0 (optim.py:240)
+    for i in range(1, steps + 1):
+        slots, total = opt.step()
+        if not args.verbose and not (args.optimizer == "adam" and i == 1):
+            PBAR.update(1)
+        if args.print_iter > 0 and i % args.print_iter == 0 and args.verbose:
+            print(f"Iteration {i} / {args.num_iters}, Loss: {float(total)}")
+        if args.save_iter > 0 and (i % args.save_iter == 0 or i == num_iters):
+            import load
+            last = save_offset + i == (save_total if save_total is not None else num_iters)
+            load.save_tensor_to_file(opt.x.detach().cpu(), args, None if last else save_offset + i, opt.x.size(3))
+        if args.optimizer == "lbfgs" and i % 25 == 0 and opt.state.status()["stopped"]:
+            break  # g.d > -tolerance_change: the reference breaks out of LBFGS.step here
+
+
+def video_windows(init, styles, window):
+    """Start frames of the optimisation windows over the pastiche and of the matching windows over every style video
+    (reference optim.py:113-123): ceil(T / window) + 1 starts spaced linearly over each sequence's own length."""
+    num_windows = math.ceil(init.shape[0] / window)
+    seqs = [init] + list(styles)
+    framestep = np.array([seq.shape[0] - window / 2 for seq in seqs]) / num_windows
+    return [[math.ceil(framestep[k] * n) for n in range(num_windows + 1)] if seq.shape[0] != 1 else [0] * (num_windows + 1)
+            for k, seq in enumerate(seqs)]
+
+
+def _optimize_video(content, styles, init, num_iters, args, net=None, losses=None):
+    """optim.optimize for transfer types with '_vid' (reference optim.py:111-255): the pastiche is a clip, optimised
+    `gram_frame_window` frames at a time (one batch of B frames through the network: per-frame static style terms and
+    the cross-frame dynamic Gram term of StyleLoss.dynamic_loss, loss.py:164-181).  Windows overlap; frames already
+    styled by the previous window (and, at the wrap-around, by the first) get their gradient zeroed, and every window is
+    written back into the clip through the same wrapping index.  The window of B frames runs through
+    the fused plan (engine.StyleEngine with B > 1: per-frame static Gram terms plus one (B C) x (B C) dynamic Gram)."""
+    limit_host_threads()
+    window = int(args.gram_frame_window)
+    windows = video_windows(init, styles, window)
+    if net is None or losses is None:
+        set_model_args(args, max(*init.shape))
+        net, losses = models.load_model(args)
+    if not args.verbose:
+        PBAR.reset()
+        PBAR.total = len(windows[0]) * num_iters
+        PBAR.refresh()
+    set_content_targets(net, content, args)
+    if args.avg_frame_window == -1:  # one set of targets from the whole style videos
+        set_style_video_targets(net, styles, args)
+        for mod in losses:
+            mod.mode = "loss"
+
+    output = init.clone()
+    for w, window_start in enumerate(windows[0]):
+        front_overlap = windows[0][w - 1] + window - window_start
+        end_overlap = (window_start + window) % output.shape[0] if window_start + window >= output.shape[0] else 0
+        index = wrapping_slice(output, window_start, window, return_indices=True)
+        if args.avg_frame_window != -1:  # targets from the stretch of every style video that accompanies this window
+            current_styles = [wrapping_slice(style, windows[k + 1][w], args.avg_frame_window) for k, style in enumerate(styles)]
+            set_style_video_targets(net, current_styles, args)
+            for mod in losses:
+                mod.mode = "loss"
+        if w == 0 and args.normalize_weights:  # once, strengths are not reset (optim.py:176-178)
+            for mod in net.content_losses + net.style_losses + net.temporal_losses:
+                mod.strength = mod.strength / max(mod.target.size())
+
+        def mask_overlap(grad, w=w, front=front_overlap, end=end_overlap):
+            if w != 0:  # same slices as the reference (optim.py:218-221), Python semantics included
+                grad[:front] = 0
+                if end > 0:
+                    grad[-end:] = 0
+
+        opt = PixelOptimizer(net, losses, output[index], args, planned_iters=num_iters, grad_hook=mask_overlap)
+        _run_iterations(opt, num_iters, args, save_offset=w * num_iters, save_total=len(windows[0]) * num_iters)
+        output[index] = opt.x.detach().cpu().to(output.dtype)
+        del opt
+    for mod in losses:
+        mod.loss = 0
+    return output
+
+
 def optimize(content, styles, init, num_iters, args, net=None, losses=None):
     """Optimise `init` towards `content` / `styles`; returns a CPU fp32 tensor shaped like `init`."""
     if "_vid" in args.transfer_type:
-        raise NotImplementedError("img_vid (sliding style-video windows) is outside this build's scope")
+        return _optimize_video(content, styles, init, num_iters, args, net, losses)
     limit_host_threads()
     if init.shape[0] != 1:
         raise NotImplementedError("one frame per call (the reference's img_img / vid_img call pattern)")
@@ -260,24 +368,7 @@ def optimize(content, styles, init, num_iters, args, net=None, losses=None):
             mod.strength = mod.strength / max(mod.target.size())
 
     opt = PixelOptimizer(net, losses, init, args, planned_iters=num_iters)
-    if args.optimizer == "lbfgs":
-        _describe("Running optimization with L-BFGS", args)
-        steps = lbfgs_moves(num_iters)
-    else:
-        _describe("Running optimization with ADAM", args)
-        steps = num_iters + 1  # `while i[0] <= iters` with i starting at 0 (optim.py:240)
-
-    for i in range(1, steps + 1):
-        slots, total = opt.step()
-        if not args.verbose and not (args.optimizer == "adam" and i == 1):
-            PBAR.update(1)
-        if args.print_iter > 0 and i % args.print_iter == 0 and args.verbose:
-            print(f"Iteration {i} / {args.num_iters}, Loss: {float(total)}")
-        if args.save_iter > 0 and (i % args.save_iter == 0 or i == num_iters):
-            import load
-            load.save_tensor_to_file(opt.x.detach().cpu(), args, i if i != num_iters else None, opt.x.size(3))
-        if args.optimizer == "lbfgs" and i % 25 == 0 and opt.state.status()["stopped"]:
-            break  # g.d > -tolerance_change: the reference breaks out of LBFGS.step here
+    _run_iterations(opt, num_iters, args)
 
     for mod in losses:
         mod.loss = 0

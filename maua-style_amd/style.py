@@ -11,7 +11,9 @@ are block-partitioned over the ranks of a torchrun job (dist.py) - one RCCL broa
 no per-iteration collective, every rank writes its own frames.  With a precomputed flow cache (`.flo` fields and
 reliability PNGs under <output_dir>/flow, as the reference's flow networks leave them) the temporally consistent
 loop runs: warped previous result as initialisation and as pixel-level temporal target (sequential, one rank).
-`img_vid` (README of the reference: "not sure if this is actually working") is not provided.
+`img_vid` (README of the reference: "not sure if this is actually working"; its driver fails in its own loader) follows the
+reference's intended flow with clips as directories of frames: optim.optimize's '_vid' branch - sliding windows of B
+frames with the cross-frame dynamic Gram term - is the part with reference parity (tests/golden/imgvid_S64.npz).
 """
 import concurrent.futures
 import glob
@@ -75,7 +77,60 @@ def img_img(args):
 
 
 def img_vid(args):
-    raise NotImplementedError("img_vid (style videos with sliding Gram windows) is outside this build's scope")
+    """One content image animated by style clips (reference style.py:76-142): the pastiche is a clip of `num_frames`
+    frames (or as long as the longest style clip), optimised coarse-to-fine by optim.optimize's sliding windows of
+    `gram_frame_window` frames (one value per scale).  As shipped the reference's own driver stops in
+    load.process_style_videos (`args.style.split` on a list), so this follows its intended flow; clips are directories
+    of frame images on both sides (no codecs in this build): style clips are read with load.preprocess_video, each
+    scale's result goes to <output>_<size>/frame_#####.png and the final clip to <output>/."""
+    import scipy.ndimage as ndi
+    limit_host_threads()
+    style_videos_big = load.process_style_videos(args)
+    content_image_big = match_histogram(load.preprocess(args.content), style_videos_big, mode=args.match_histograms)
+    video_length = max(v.shape[0] for v in style_videos_big) if args.num_frames == -1 else args.num_frames
+    delta_ts = str(args.gram_frame_window).split(",")
+    content_size = np.array(content_image_big.size()[-2:])
+    H, W = (int(v) for v in content_size)
+
+    if args.init == "random":
+        pastiche = th.randn((video_length, 3, H, W)) * 255
+        pastiche = th.from_numpy(ndi.gaussian_filter(pastiche.numpy(), [video_length, 0, H / 32, W / 32], mode="wrap"))
+    elif args.init == "content":
+        pastiche = F.interpolate(content_image_big.clone(), (H, W), mode="bilinear", align_corners=False)
+        pastiche = pastiche.repeat([video_length, 1, 1, 1])
+        pastiche += th.randn((video_length, 3, H, W)) * 255
+        pastiche = th.from_numpy(ndi.gaussian_filter(pastiche.numpy(), [video_length, 0, 4, 4], mode="wrap"))
+    else:
+        pastiche = load.preprocess_video(args.init, args.fps).repeat([video_length, 1, 1, 1])
+    pastiche = match_histogram(pastiche, style_videos_big, mode=args.match_histograms)
+
+    for i, (current_size, num_iters) in enumerate(zip(args.image_sizes, args.num_iters)):
+        done = f"{args.output}_{current_size}"
+        if os.path.isdir(done) and os.listdir(done):  # resume: a finished scale is reloaded
+            pastiche = load.preprocess_video(done, args.fps)
+            continue
+        print("\nCurrent size {}px".format(current_size))
+        args.gram_frame_window = int(delta_ts[min(i, len(delta_ts) - 1)])
+        content_image = F.interpolate(content_image_big, scale_factor=current_size / max(*content_size), mode="bilinear",
+                                      align_corners=False)
+        style_videos = _scaled_styles(style_videos_big, content_image.shape[2] * content_image.shape[3], args)
+        pastiche = F.interpolate(pastiche.clone(), tuple(int(v) for v in content_image.shape[2:]), mode="bilinear",
+                                 align_corners=False)
+
+        pastiche = optim.optimize(content_image, style_videos, pastiche, num_iters, args).detach().cpu()
+
+        # the reference rolls the clip and the style clips by 7 frames between scales (style.py:134-135), so that the
+        # window seams fall elsewhere at the next scale
+        pastiche = th.cat((pastiche[7:], pastiche[:7]))
+        style_videos_big = [th.cat((svb[7:], svb[:7])) for svb in style_videos_big]
+        if args.temporal_blend > 0:
+            pastiche = th.from_numpy(ndi.gaussian_filter(pastiche.numpy(), [args.temporal_blend, 0, 0, 0], mode="wrap"))
+        pastiche = match_histogram(pastiche, style_videos_big, mode=args.match_histograms)
+        load.save_tensor_to_file(pastiche, args, filename=done)
+
+    pastiche = match_histogram(pastiche, style_videos_big, mode=args.match_histograms)
+    load.save_tensor_to_file(pastiche, args)
+    return pastiche
 
 
 def _vid_img_flow(args, output_dir, frames, style_images_big, content_size):

@@ -187,6 +187,41 @@ def test_vid_img_calls_against_fp64_arbiter(weight_files, tmp_path):
         assert err <= max(1e-3, 2 * floor), (fname, err, floor)
 
 
+def test_img_vid_frame_directories_end_to_end(tmp_path, weight_files):
+    """SURVEY 8(f)-4 through the command line: one content image, one style clip (directory of frames), a 6-frame
+    pastiche optimised in windows of 3 frames at two scales; per-scale and final clips come out as directories of PNGs,
+    and a finished scale is reloaded on a second run."""
+    clip = tmp_path / "clip"
+    clip.mkdir()
+    g = torch.Generator().manual_seed(8)
+    for t in range(4):
+        Image.fromarray((torch.rand(40, 44, 3, generator=g) * 255).byte().numpy()).save(clip / f"s_{t:03d}.png")
+    content = tmp_path / "content.png"
+    Image.fromarray((torch.rand(64, 64, 3, generator=g) * 255).byte().numpy()).save(content)
+    scaling = tmp_path / "scaling.json"
+    scaling.write_text(json.dumps({"100000": {"gpu": "0", "multidevice": False}}))
+    out = tmp_path / "out"
+    out.mkdir()
+    argv = ["--transfer_type", "img_vid", "--content", str(content), "--style", str(clip), "--image_sizes", "32,48",
+            "--num_iters", "3,2", "--gram_frame_window", "3,3", "--num_frames", "6", "--init", "content", "--seed", "0",
+            "--style_layers", "relu1_1,relu2_1", "--content_layers", "relu2_2", "--model_file", weight_files["vgg19"],
+            "--disable_check", "--scaling_args", str(scaling), "--output_dir", str(out)]
+    r = run_style(argv, cwd=PKG)
+    assert r.returncode == 0, r.stderr[-2000:]
+    base = out / "content_clip"
+    for d, side in ((out / "content_clip_32", 32), (out / "content_clip_48", 48), (base, 48)):
+        frames = sorted(os.listdir(d))
+        assert frames == [f"frame_{t:05d}.png" for t in range(6)], (d, frames)
+        img = Image.open(d / frames[0])
+        assert img.size == (side, side)
+    clip0 = np.stack([np.asarray(Image.open(base / f"frame_{t:05d}.png"), dtype=np.int32) for t in range(6)])
+    assert clip0.std() > 1 and np.abs(clip0[0] - clip0[3]).max() > 0  # frames differ: they were optimised, not copied
+    mtime = (out / "content_clip_32" / "frame_00000.png").stat().st_mtime_ns
+    r = run_style(argv, cwd=PKG)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert (out / "content_clip_32" / "frame_00000.png").stat().st_mtime_ns == mtime
+
+
 def test_bench_prints_one_contract_line(tmp_path):
     """bench.py's output contract (one JSON line with metric / value / roofline / cpu_baseline ...) on a small size."""
     env = dict(os.environ)

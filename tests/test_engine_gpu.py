@@ -386,6 +386,102 @@ def test_more_trajectories_vs_fp64_arbiter(weight_files, case, model, opt, S, fl
     assert err <= max(1e-3, 2 * floor), (case, err, floor)
 
 
+def imgvid_inputs(S=64, T=5, TS=7):
+    """Same construction as tools/make_golden.py::imgvid_inputs."""
+    g = torch.Generator().manual_seed(77)
+    content = torch.rand(1, 3, S, S, generator=g) * 255 - 120
+    style_video = torch.rand(TS, 3, S, S, generator=g) * 255 - 120
+    init = torch.rand(T, 3, S, S, generator=g) * 255 - 120
+    return content, style_video, init
+
+
+IMGVID_FLAGS = ["--transfer_type", "img_vid", "--style_layers", "relu1_1,relu2_1", "--content_layers", "relu2_2"]
+
+
+def test_set_style_video_targets_matches_reference(weight_files):
+    """window-averaged per-frame and cross-frame (3C x 3C) Gram targets of a 7-frame style video
+    (optim.py:69-90 + loss.py:141-175), against the reference's fp64 values."""
+    import models
+    import optim
+    g = gold("imgvid_S64")
+    args = product_args(weight_files, IMGVID_FLAGS + ["--avg_frame_window", "-1"], optimizer="adam", S=64, N=4)
+    args.gram_frame_window = 3
+    _, style_video, _ = imgvid_inputs()
+    optim.set_model_args(args, 64)
+    net, losses = models.load_model(args)
+    optim.set_style_video_targets(net, [style_video], args)
+    assert all(m.mode == "none" for m in net.style_losses)
+    for k, m in enumerate(net.style_losses):
+        assert rel_l2(m.target.cpu(), g[f"target_{k}"]) <= 1e-5
+        vt = m.video_target.cpu().double()
+        rows, norm, trace, total = g[f"video_target_{k}_stats"]
+        assert vt.shape == (int(rows), int(rows)) and int(rows) == 3 * m.target.shape[0]
+        assert rel_l2(vt[:48, -48:], g[f"video_target_{k}_block"]) <= 1e-5
+        assert abs(float(vt.norm()) - norm) <= 1e-5 * norm and abs(float(vt.trace()) - trace) <= 1e-5 * abs(trace)
+        assert abs(float(vt.sum()) - total) <= 1e-4 * norm
+
+
+@pytest.mark.parametrize("opt,extra", [("lbfgs", []), ("adam", ["--avg_frame_window", "-1"])])
+def test_img_vid_optimize_vs_fp64_arbiter(weight_files, opt, extra):
+    """optim.optimize with transfer_type img_vid: 5-frame pastiche in windows of B = 3 frames (3 windows, wrap-around
+    write-back, overlap gradients zeroed), per-window style-video targets (L-BFGS case) or one capture (Adam case);
+    4 iterations per window; trajectory rule against the reference's fp64 run."""
+    import optim
+    g = gold("imgvid_S64")
+    args = product_args(weight_files, IMGVID_FLAGS + extra, optimizer=opt, S=64, N=4)
+    args.gram_frame_window = 3
+    content, style_video, init = imgvid_inputs()
+    out = optim.optimize(content, [style_video], init.clone(), 4, args)
+    assert out.shape == init.shape and out.dtype == torch.float32 and out.device.type == "cpu"
+    floor = rel_l2(g[f"out_{opt}_f32"], g[f"out_{opt}_f64"])
+    err = rel_l2(out, g[f"out_{opt}_f64"])
+    moved = rel_l2(init, g[f"out_{opt}_f64"])
+    assert moved > 1e-2  # the fixture really moves the clip
+    assert err <= max(1e-3, 2 * floor), (opt, err, floor)
+    # every frame was written by some window
+    assert all(float((out[t] - init[t]).abs().max()) > 0 for t in range(init.shape[0]))
+
+
+@pytest.mark.parametrize("variant", ["default", "no_grad_norm", "covariance", "no_tv_no_vsf", "normalize_weights"])
+def test_engine_on_a_window_of_frames_matches_the_module_path(weight_files, variant):
+    """The fused plan with B = 3 frames (per-frame static Gram terms, one 3C x 3C dynamic Gram term, a single-frame content
+    target broadcast over the window, TV over all frames) against the same loss modules run one by one under autograd
+    (which the B = 2 golden tests pin to the reference): losses, total and the gradient of every frame."""
+    import engine
+    import models
+    import optim
+    args = product_args(weight_files, IMGVID_FLAGS + ["--avg_frame_window", "-1"] + VARIANT_FLAGS[variant], optimizer="adam",
+                        S=64, N=4)
+    args.gram_frame_window = 3
+    content, style_video, init = imgvid_inputs()
+    optim.set_model_args(args, 64)
+    net, losses = models.load_model(args)
+    optim.set_content_targets(net, content, args)
+    optim.set_style_video_targets(net, [style_video], args)
+    for m in losses:
+        m.mode = "loss"
+    if args.normalize_weights:
+        for m in net.content_losses + net.style_losses + net.temporal_losses:
+            m.strength = m.strength / max(m.target.size())
+    x = init[1:4].cuda()
+    po = optim.PixelOptimizer(net, losses, init[1:4], args)
+    slots_m, total_m, grad_m = po._feval_modules()
+    slots_m, total_m, grad_m = slots_m.clone(), total_m.clone(), grad_m.clone()
+    eng = engine.StyleEngine(net, losses)
+    slots_e, total_e, grad_e = eng.feval(x)
+    torch.cuda.synchronize()
+    assert grad_e.shape == x.shape
+    for name, a_, b_ in zip([m.name for m in losses], slots_e.cpu().tolist(), slots_m.cpu().tolist()):
+        assert abs(a_ - b_) <= 1e-5 * max(abs(b_), 1e-12), (name, a_, b_)
+    assert abs(float(total_e) - float(total_m)) <= 1e-5 * abs(float(total_m))
+    for b in range(3):
+        assert rel_l2(grad_e[b].cpu(), grad_m[b].cpu().double()) <= 2e-5, b
+    # and it is the path optimize() takes: no fallback happened
+    assert po.engine is not None
+    po.feval()
+    assert po.engine is not None
+
+
 def test_pixel_gradient_is_as_close_to_fp64_as_the_reference_fp32(weight_files):
     """The split-precision convolutions claim fp32-level accuracy: the whole-network pixel gradient must sit as close to the
     fp64 reference as the reference's own fp32 arithmetic does (fixtures hold both), not merely inside a loose tolerance."""

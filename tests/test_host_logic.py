@@ -212,3 +212,16 @@ def test_match_histogram_against_reference_fixture():
     torch.manual_seed(0)
     out = utils.match_histogram(target.clone(), [src1], mode=True)
     assert torch.allclose(out.mean((0, 2, 3)), src1.mean((0, 2, 3)), atol=0.05)
+
+
+def test_video_windows_schedule_matches_reference_formula():
+    """optim.py:113-123: ceil(T / window) + 1 window starts per sequence, spaced over (frames - window / 2); single images
+    always start at 0.  Values below were produced by the reference's expression for the same shapes."""
+    import torch
+
+    import optim
+    init, video, image = torch.zeros(5, 1), torch.zeros(7, 1), torch.zeros(1, 1)
+    assert optim.video_windows(init, [video, image], 3) == [[0, 2, 4], [0, 3, 6], [0, 0, 0]]
+    init, video = torch.zeros(40, 1), torch.zeros(25, 1)
+    w = optim.video_windows(init, [video], 18)
+    assert w == [[0, 11, 21, 31], [0, 6, 11, 16]]

@@ -753,7 +753,53 @@ def gen_traj_extra():
     save("traj_extra", **res)
 
 
-GROUPS = {"traj_extra": gen_traj_extra, "batch": gen_batch, "vid": gen_vid, "temporal": gen_temporal, "cli": gen_cli, "traj64v": gen_traj_variants64, "feval": gen_feval, "traj": gen_traj, "nin": gen_nin, "hist": gen_hist, "host": gen_host}
+def imgvid_inputs(S=64, T=5, TS=7):
+    """Seeded stand-ins for img_vid's tensors: one content image, one style video of TS frames, a pastiche of T frames
+    (uniform noise in the preprocessed range, like synth.images)."""
+    g = torch.Generator().manual_seed(77)
+    content = torch.rand(1, 3, S, S, generator=g) * 255 - 120
+    style_video = torch.rand(TS, 3, S, S, generator=g) * 255 - 120
+    init = torch.rand(T, 3, S, S, generator=g) * 255 - 120
+    return content, style_video, init
+
+
+def gen_imgvid():
+    """SURVEY 8(f)-4 at workflow level: optim.optimize with transfer_type img_vid (optim.py:111-255 with the '_vid'
+    branches: window schedule, per-window style-video targets, overlap-gradient masking, wrapped write-back) and
+    optim.set_style_video_targets (optim.py:69-90), on B = gram_frame_window = 3 frames."""
+    print("[imgvid] sliding-window video optimisation, B = 3")
+    S, N = 64, 4
+    layers = ["--style_layers", "relu1_1,relu2_1", "--content_layers", "relu2_2"]
+    res = {}
+    for opt, extra in (("lbfgs", []), ("adam", ["--avg_frame_window", "-1"])):
+        for double in (False, True):
+            args = get_args(["--transfer_type", "img_vid"] + layers + extra, optimizer=opt, S=S, N=N)
+            args.gram_frame_window = 3  # style.img_vid sets the integer per scale (style.py:111)
+            content, style_video, init = imgvid_inputs(S)
+            ref_optim.set_model_args(args, S)
+            with quiet():
+                net, losses = ref_models.load_model(args)
+            if double:
+                net.double()
+                args.dtype = torch.DoubleTensor
+            with quiet():
+                out = ref_optim.optimize(content, [style_video], init.double() if double else init.clone(), N, args, net, losses).detach()
+            tag = f"{opt}_{'f64' if double else 'f32'}"
+            res[f"out_{tag}"] = out.numpy()
+            print(f"    {tag}: moved {float((out.double() - init.double()).norm() / init.double().norm()):.4e}")
+            if opt == "adam" and double:  # targets as set_style_video_targets leaves them (captured once: avg window -1)
+                for k, m in enumerate(net.style_losses):
+                    res[f"target_{k}"] = m.target.numpy().copy()
+                    vt = m.video_target
+                    res[f"video_target_{k}_block"] = vt[:48, -48:].numpy().copy()  # a corner across two frames' channels
+                    res[f"video_target_{k}_stats"] = np.array([vt.shape[0], float(vt.norm()), float(vt.trace()), float(vt.sum())])
+    for opt in ("lbfgs", "adam"):
+        a, b = torch.from_numpy(res[f"out_{opt}_f32"]).double(), torch.from_numpy(res[f"out_{opt}_f64"])
+        print(f"    {opt}: f32 vs f64 {float((a - b).norm() / b.norm()):.3e}")
+    save("imgvid_S64", **res)
+
+
+GROUPS = {"imgvid": gen_imgvid, "traj_extra": gen_traj_extra, "batch": gen_batch, "vid": gen_vid, "temporal": gen_temporal, "cli": gen_cli, "traj64v": gen_traj_variants64, "feval": gen_feval, "traj": gen_traj, "nin": gen_nin, "hist": gen_hist, "host": gen_host}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
