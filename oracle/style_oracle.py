@@ -169,7 +169,8 @@ def _scale_grad_coeff(incoming, strength):
 
 
 class OracleNet:
-    """Explicit forward/backward of the assembled loss network for B = 1 (img_img / vid_img paths)."""
+    """Explicit forward/backward of the assembled loss network: B = 1 (img_img / vid_img paths) and windows of B > 1
+    frames (img_vid: per-frame static style terms plus the cross-frame dynamic Gram term)."""
 
     def __init__(self, spec, state_dict, dtype=torch.float32):
         self.spec = spec
@@ -186,6 +187,7 @@ class OracleNet:
                 # refuses the backward pass (version-counter error), so this layout never trains there.
                 raise NotImplementedError("loss modules on conv-named layers are unusable in the reference")
         self.targets = {}  # layer index -> target tensor (content: feature map, style: CxC)
+        self.video_targets = {}  # style layer index -> (B*C) x (B*C) target of StyleLoss.dynamic_loss
         self.strength = {i: l.strength for i, l in enumerate(spec) if l.kind in ("content", "style", "tv", "temporal")}
 
     # -- forward ---------------------------------------------------------------------------
@@ -239,6 +241,36 @@ class OracleNet:
                     g = bw * self._gram_normed(acts[i], l) / img.shape[0]
                     self.targets[i] = g if i not in self.targets else self.targets[i] + g
 
+    def capture_style_videos(self, videos, blend_weights, window):
+        """optim.set_style_video_targets (optim.py:69-90): every window of `window` consecutive frames of every style clip
+        goes through the net in 'capture' mode with blend weight / number of windows.  StyleLoss.static_loss adds
+        blend * Gram(frame) / (C*H*W) / B for every frame of the window (loss.py:141-151), StyleLoss.dynamic_loss adds
+        blend * Gram(window as (B*C) rows) / (B*C*H*W) to the video target when video_style_factor > 0 - unless a video
+        target of another size already exists (loss.py:164-175)."""
+        for i, l in enumerate(self.spec):
+            if l.kind == "style":
+                self.targets.pop(i, None)
+                self.video_targets.pop(i, None)
+        for video, bw in zip(videos, blend_weights):
+            n_windows = max(len(video) - window + 1, 1)
+            w_blend = bw / n_windows
+            for start in range(n_windows):
+                frames = video[start:start + window].to(self.dtype)
+                acts, _ = self._forward(frames)
+                for i, l in enumerate(self.spec):
+                    if l.kind != "style":
+                        continue
+                    f = acts[i]
+                    for b in range(f.shape[0]):
+                        g = w_blend * self._gram_normed(f[b:b + 1], l) / f.shape[0]
+                        self.targets[i] = g if i not in self.targets else self.targets[i] + g
+                    if l.video_style_factor > 0:
+                        rows = f.shape[0] * f.shape[1]
+                        if i in self.video_targets and self.video_targets[i].shape[0] != rows:
+                            continue
+                        gd = w_blend * gram_matrix(f, l.use_covariance) / f.nelement()
+                        self.video_targets[i] = gd if i not in self.video_targets else self.video_targets[i] + gd
+
     def normalize_weights(self):
         """optim.py:176-178: strength /= max(target.size()); raises like the reference when a
         temporal module with an empty target is present (ZeroDivisionError)."""
@@ -254,7 +286,8 @@ class OracleNet:
         Closed form (SURVEY §8 a-spec).  Reported loss weights vs gradient weights differ when
         normalize_gradients is on because ScaleGradients is applied to the scalar MSE."""
         x = x.to(self.dtype)
-        assert x.shape[0] == 1, "oracle covers the B=1 hot path"
+        if x.shape[0] > 1:
+            return self._feval_window(x)
         acts, aux = self._forward(x)
         losses, inject = {}, {}
         for i, l in enumerate(self.spec):
@@ -316,7 +349,12 @@ class OracleNet:
                 if l.use_covariance:
                     gf = gf - gf.mean(1).unsqueeze(1)  # backward of the row-mean subtraction
                 inject[i] = gf.reshape(f.shape)
-        # backward to the pixels
+        g = self._backward(x, acts, aux, inject)
+        total = sum(losses.values())
+        return total, losses, g
+
+    def _backward(self, x, acts, aux, inject):
+        """Backward to the pixels: the injected loss gradients flow down through relu / conv / pool."""
         g = None
         for i in range(len(self.spec) - 1, -1, -1):
             l = self.spec[i]
@@ -336,6 +374,79 @@ class OracleNet:
                     g = gi.reshape(inp.shape)
                 else:
                     g = _avg_pool_backward(g, inp.shape, l.k, l.stride, l.ceil)
+        return g
+
+    def _feval_window(self, x):
+        """feval for a window of B > 1 frames (img_vid).  TV over the whole batch (loss.py:224-233); ContentLoss loops over the
+        frames against the single-frame target, each entering with strength / B (loss.py:48-58); StyleLoss: static term
+        per frame against the C x C target with strength / B (loss.py:141-158), dynamic term on the (B*C) x (B*C) Gram of
+        the window against the video target with video_style_factor * strength / B, skipped when the sizes differ
+        (loss.py:164-181).  With normalize_gradients every scalar MSE passes ScaleGradients: its gradient weight becomes
+        sign(incoming) * strength^2, whatever the 1 / B."""
+        B = x.shape[0]
+        acts, aux = self._forward(x)
+        losses, inject = {}, {}
+        for i, l in enumerate(self.spec):
+            s = self.strength.get(i, 0.0)
+            if l.kind == "tv":
+                dv = x[:, :, 1:, :] - x[:, :, :-1, :]
+                dh = x[:, :, :, 1:] - x[:, :, :, :-1]
+                losses[i] = s * (dv.abs().sum() + dh.abs().sum())
+                g = torch.zeros_like(x)
+                sv, sh = torch.sign(dv), torch.sign(dh)
+                g[:, :, 1:, :] += sv
+                g[:, :, :-1, :] -= sv
+                g[:, :, :, 1:] += sh
+                g[:, :, :, :-1] -= sh
+                inject[i] = s * g
+            elif l.kind == "temporal":
+                if i in self.targets:
+                    raise NotImplementedError("temporal targets on a window of frames are not part of img_vid")
+            elif l.kind == "content":
+                f, t = acts[i], self.targets[i]
+                if f.shape[1:] != t.shape[1:]:
+                    continue
+                assert t.shape[0] == 1
+                coeff = _scale_grad_coeff(s / B, s) if l.normalize else s / B
+                diff = f - t  # every frame against the same target
+                n = f[0].nelement()
+                losses[i] = sum(((diff[b] * diff[b]).mean() * s / B for b in range(B)))
+                inject[i] = diff * (coeff * 2.0 / n)
+            elif l.kind == "style":
+                f, t = acts[i], self.targets[i]
+                C, n = f.shape[1], f[0].nelement()
+                coeff = _scale_grad_coeff(s / B, s) if l.normalize else s / B
+                loss = 0.0
+                gf_all = torch.zeros_like(f)
+                for b in range(B):
+                    fb = f[b:b + 1]
+                    d = self._gram_normed(fb, l) - t
+                    loss = loss + (d * d).mean() * s / B
+                    ff = fb.reshape(C, -1)
+                    if l.use_covariance:
+                        ff = ff - ff.mean(1).unsqueeze(1)
+                    gfb = (coeff * 2.0 / (C * C) / n) * ((d + d.t()) @ ff)
+                    if l.use_covariance:
+                        gfb = gfb - gfb.mean(1).unsqueeze(1)
+                    gf_all[b] = gfb.reshape(f.shape[1:])
+                vsf = l.video_style_factor
+                if vsf > 0:
+                    vt = self.video_targets[i]
+                    if vt.shape[0] == B * C:
+                        nall = f.nelement()
+                        d = gram_matrix(f, l.use_covariance) / nall - vt
+                        loss = loss + vsf * (d * d).mean() * s / B
+                        cd = _scale_grad_coeff(vsf * s / B, s) if l.normalize else vsf * s / B
+                        ff = f.reshape(B * C, -1)
+                        if l.use_covariance:
+                            ff = ff - ff.mean(1).unsqueeze(1)
+                        gd = (cd * 2.0 / (B * C) ** 2 / nall) * ((d + d.t()) @ ff)
+                        if l.use_covariance:
+                            gd = gd - gd.mean(1).unsqueeze(1)
+                        gf_all = gf_all + gd.reshape(f.shape)
+                losses[i] = loss
+                inject[i] = gf_all
+        g = self._backward(x, acts, aux, inject)
         total = sum(losses.values())
         return total, losses, g
 
@@ -502,3 +613,69 @@ def optimize(content, styles, init, num_iters, cfg, state_dict, dtype=torch.floa
     else:
         raise ValueError(cfg.optimizer)
     return out
+
+
+# ----------------------------------------------------------------------------------------
+# img_vid: sliding windows of frames (optim.py:111-255, the '_vid' branches)
+# ----------------------------------------------------------------------------------------
+def wrapping_indices(n_frames, start, length):
+    """utils.wrapping_slice(..., return_indices=True) (utils.py:76-85)."""
+    if n_frames == 1:
+        return torch.zeros(1, dtype=torch.int64)
+    if start + length <= n_frames:
+        return torch.arange(start, start + length)
+    return torch.cat((torch.arange(start, n_frames), torch.arange(0, (start + length) % n_frames)))
+
+
+def video_windows(lengths, window):
+    """optim.py:113-123: window starts over the pastiche (lengths[0]) and over every style clip."""
+    num_windows = math.ceil(lengths[0] / window)
+    step = [(n - window / 2) / num_windows for n in lengths]
+    return [[math.ceil(step[k] * j) for j in range(num_windows + 1)] if n != 1 else [0] * (num_windows + 1)
+            for k, n in enumerate(lengths)]
+
+
+def optimize_video(content, styles, init, num_iters, cfg, state_dict, window, avg_frame_window=18, dtype=torch.float32):
+    """optim.optimize for transfer types with '_vid': the clip `init` (T frames) is optimised `window` frames at a time; the
+    style-video targets come from the whole clips once (avg_frame_window == -1, optim.py:140-144) or, per window, from the
+    `avg_frame_window` frames of every clip that start at that clip's own window start (optim.py:158-165); frames already
+    styled by the previous window (front overlap) and, past the wrap-around, by the first (end overlap) get a zero
+    gradient (optim.py:217-221); the window is written back through the wrapping index (optim.py:243-245)."""
+    spec = build_spec(cfg)
+    net = OracleNet(spec, state_dict, dtype)
+    net.capture_content(content)
+    windows = video_windows([init.shape[0]] + [v.shape[0] for v in styles], window)
+    if avg_frame_window == -1:
+        net.capture_style_videos(styles, cfg.style_blend_weights, window)
+    output = init.clone().to(dtype)
+    T = output.shape[0]
+    for w, start in enumerate(windows[0]):
+        front = windows[0][w - 1] + window - start
+        end = (start + window) % T if start + window >= T else 0
+        idx = wrapping_indices(T, start, window)
+        if avg_frame_window != -1:
+            current = [v[wrapping_indices(v.shape[0], windows[k + 1][w], avg_frame_window)] for k, v in enumerate(styles)]
+            net.capture_style_videos(current, cfg.style_blend_weights, window)
+        if w == 0 and getattr(cfg, "normalize_weights", False):
+            net.normalize_weights()
+        x0 = output[idx]
+        shape = x0.shape
+
+        def fg(xf, w=w, front=front, end=end):
+            total, _, g = net.feval(xf.reshape(shape))
+            g = g.clone()
+            if w != 0:
+                g[:front] = 0
+                if end > 0:
+                    g[-end:] = 0
+            return float(total), g.flatten()
+
+        if cfg.optimizer == "lbfgs":
+            out, _ = lbfgs_run(fg, x0, num_iters, history=cfg.lbfgs_num_correction, tol_grad=float(cfg.lbfgs_tolerance_grad),
+                               tol_change=float(cfg.lbfgs_tolerance_change))
+        elif cfg.optimizer == "adam":
+            out, _ = adam_run(fg, x0, num_iters, lr=cfg.learning_rate)
+        else:
+            raise ValueError(cfg.optimizer)
+        output[idx] = out.reshape(shape).to(output.dtype)
+    return output

@@ -482,6 +482,36 @@ def test_engine_on_a_window_of_frames_matches_the_module_path(weight_files, vari
     assert po.engine is not None
 
 
+@pytest.mark.parametrize("variant", ["default", "covariance", "no_grad_norm"])
+def test_engine_on_a_window_of_frames_vs_fp64_oracle(weight_files, variant):
+    """B = 3 frames through the fused plan against the CPU oracle in fp64 (which reproduces the reference's fp64 img_vid
+    run to 1e-7, tests/test_oracle_golden.py): total loss and pixel gradient."""
+    import engine
+    import models
+    import optim
+    from oracle.style_oracle import OracleNet, build_spec
+    over = dict(FEVAL_VARIANTS[variant], style_layers="relu1_1,relu2_1", content_layers="relu2_2")
+    cfg = make_cfg(optimizer="adam", **over)
+    content, style_video, init = imgvid_inputs()
+    onet = OracleNet(build_spec(cfg), synth.vgg19_state_dict(), torch.float64)
+    onet.capture_content(content)
+    onet.capture_style_videos([style_video], cfg.style_blend_weights, 3)
+    total_o, _, grad_o = onet.feval(init[1:4])
+    args = product_args(weight_files, IMGVID_FLAGS + ["--avg_frame_window", "-1"] + VARIANT_FLAGS[variant], optimizer="adam",
+                        S=64, N=4)
+    args.gram_frame_window = 3
+    optim.set_model_args(args, 64)
+    net, losses = models.load_model(args)
+    optim.set_content_targets(net, content, args)
+    optim.set_style_video_targets(net, [style_video], args)
+    for m in losses:
+        m.mode = "loss"
+    _, total, grad = engine.StyleEngine(net, losses).feval(init[1:4].cuda())
+    torch.cuda.synchronize()
+    assert abs(float(total) - float(total_o)) <= 1e-5 * abs(float(total_o))
+    assert rel_l2(grad.cpu(), grad_o) <= 1e-5
+
+
 def test_pixel_gradient_is_as_close_to_fp64_as_the_reference_fp32(weight_files):
     """The split-precision convolutions claim fp32-level accuracy: the whole-network pixel gradient must sit as close to the
     fp64 reference as the reference's own fp32 arithmetic does (fixtures hold both), not merely inside a loose tolerance."""

@@ -238,3 +238,55 @@ def test_oracle_temporal_trajectory_fp64(opt):
     out = optimize(content, [style], init, N, cfg, synth.vgg19_state_dict(), dtype=torch.float64,
                           temporal=temporal_inputs(S))
     assert rel_l2(out, torch.from_numpy(g[f"{opt}_N{N}_f64"])) <= 1e-7
+
+
+# ---------------------------------------------------------------------------------------------------------
+# windows of B > 1 frames (img_vid) - static + dynamic style terms, '_vid' branches of optim.optimize
+# ---------------------------------------------------------------------------------------------------------
+def imgvid_inputs(S=64, T=5, TS=7):
+    """Same construction as tools/make_golden.py::imgvid_inputs."""
+    g = torch.Generator().manual_seed(77)
+    content = torch.rand(1, 3, S, S, generator=g) * 255 - 120
+    style_video = torch.rand(TS, 3, S, S, generator=g) * 255 - 120
+    init = torch.rand(T, 3, S, S, generator=g) * 255 - 120
+    return content, style_video, init
+
+
+IMGVID_CFG = dict(style_layers="relu1_1,relu2_1", content_layers="relu2_2")
+
+
+def test_oracle_style_video_targets_fp64():
+    """optim.set_style_video_targets on a 7-frame clip, windows of 3: C x C and 3C x 3C targets of both style layers."""
+    from oracle.style_oracle import OracleNet as Net
+    g = gold("imgvid_S64")
+    cfg = make_cfg(optimizer="adam", **IMGVID_CFG)
+    _, style_video, _ = imgvid_inputs()
+    net = Net(build_spec(cfg), synth.vgg19_state_dict(), torch.float64)
+    net.capture_style_videos([style_video], cfg.style_blend_weights, 3)
+    layers = [i for i, l in enumerate(net.spec) if l.kind == "style"]
+    assert len(layers) == 2
+    for k, i in enumerate(layers):
+        assert rel_l2(net.targets[i], g[f"target_{k}"]) <= 1e-10
+        vt = net.video_targets[i]
+        rows, norm, trace, total = g[f"video_target_{k}_stats"]
+        assert vt.shape == (int(rows), int(rows))
+        assert rel_l2(vt[:48, -48:], g[f"video_target_{k}_block"]) <= 1e-10
+        assert abs(float(vt.norm()) - norm) <= 1e-10 * norm and abs(float(vt.trace()) - trace) <= 1e-10 * abs(trace)
+        assert abs(float(vt.sum()) - total) <= 1e-9 * norm
+
+
+@pytest.mark.parametrize("opt,avg", [("lbfgs", 18), ("adam", -1)])
+def test_oracle_img_vid_trajectory(opt, avg):
+    """The '_vid' optimize loop (3 windows of B = 3 frames over a 5-frame clip, 4 iterations each): the fp64 oracle
+    reproduces the reference's fp64 run, the fp32 oracle meets the trajectory rule."""
+    from oracle.style_oracle import optimize_video
+    g = gold("imgvid_S64")
+    cfg = make_cfg(optimizer=opt, **IMGVID_CFG)
+    content, style_video, init = imgvid_inputs()
+    sd = synth.vgg19_state_dict()
+    ref32, ref64 = g[f"out_{opt}_f32"], g[f"out_{opt}_f64"]
+    out64 = optimize_video(content, [style_video], init, 4, cfg, sd, 3, avg_frame_window=avg, dtype=torch.float64)
+    assert rel_l2(out64, ref64) <= 1e-7
+    out32 = optimize_video(content, [style_video], init, 4, cfg, sd, 3, avg_frame_window=avg, dtype=torch.float32)
+    floor = rel_l2(ref32, ref64)
+    assert rel_l2(out32, ref64) <= max(1e-3, 2 * floor), (rel_l2(out32, ref64), floor)
