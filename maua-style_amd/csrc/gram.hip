@@ -170,8 +170,9 @@ gram_finish_kernel(const float* __restrict__ partial, float* __restrict__ gram, 
     const float* base = partial + (int64_t)blockIdx.x * ksplit * (GT * GT);
     const int e = blockIdx.y * 256 + threadIdx.x;
     int er = e / GT, ec = e % GT;
-    // diagonal tiles: block (1,0) was not computed, read its mirror image from block (0,1)
-    const int src = (ti == tj && er >= 32 && ec < 32) ? ec * GT + er : e;
+    // diagonal tiles: the lower triangle is read from the upper one - block (1,0) was not computed at all, and G comes out
+    // exactly symmetric whatever arithmetic produced the slabs
+    const int src = (ti == tj && er > ec) ? ec * GT + er : e;
     double sd = 0.0;  // fp64 keeps the split-K sum exact to fp32 rounding; slabs k = 0, kstride, 2 kstride, ...
     for (int k = 0; k < ksplit; k += kstride) sd += (double)base[(int64_t)k * (GT * GT) + src];
     const float s = (float)(sd * (double)scale);

@@ -196,6 +196,40 @@ def test_gram_fwd_bwd(hip, C, HW, center):
     assert rel_l2(gf.cpu(), refb + base.double()) <= TOL
 
 
+@pytest.mark.parametrize("kind", ["wide_range", "tiny", "huge", "zeros", "one_hot", "big_mean"])
+def test_gram_survives_extreme_inputs(hip, kind):
+    """Rows spanning many decades, values near the fp32 extremes (squares stay finite), all-zero maps, one non-zero element,
+    and (covariance form) a mean far above the spread; the result is exactly symmetric."""
+    C, HW = 128, 4096
+    g = torch.Generator().manual_seed(21)
+    f = torch.randn(1, C, HW, 1, generator=g)
+    center = False
+    if kind == "wide_range":
+        f = f * torch.exp(torch.randn(1, C, 1, 1, generator=g) * 4.0)
+    elif kind == "tiny":
+        f = f * 1e-15
+    elif kind == "huge":
+        f = f * 1e15
+    elif kind == "zeros":
+        f = torch.zeros_like(f)
+    elif kind == "one_hot":
+        f = torch.zeros_like(f)
+        f[0, 5, 77, 0] = 3.0e-6
+    elif kind == "big_mean":
+        f, center = f + 50.0, True
+    ff = f.reshape(C, HW).double()
+    fc = ff - ff.mean(1, keepdim=True) if center else ff
+    ref = fc @ fc.t() / (C * HW)
+    gram, _ = hip.gram_fwd(dev(f), 1.0 / (C * HW), center)
+    torch.cuda.synchronize()
+    assert torch.isfinite(gram).all()
+    if kind == "zeros":
+        assert float(gram.abs().max()) == 0.0
+    else:
+        assert rel_l2(gram.cpu(), ref) <= (2e-5 if kind == "big_mean" else 2e-6)
+    assert torch.equal(gram.cpu(), gram.cpu().t())
+
+
 def test_gram_deterministic(hip):
     f = dev(torch.relu(rnd(1, 128, 64, 64, seed=14)))
     a, _ = hip.gram_fwd(f, 1e-3)

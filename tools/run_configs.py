@@ -155,6 +155,31 @@ def config5(p, tmp):
             "finite": bool(torch.isfinite(out).all()), **summarise(t.calls, wall)}
 
 
+def config6(p, tmp, B=6, T=12, S=512, N=100):
+    """SURVEY 8(f)-4 as a job: a T-frame pastiche at S x S optimised in sliding windows of B frames (optim.optimize with
+    transfer_type img_vid): per-frame static Gram terms plus the (B C) x (B C) dynamic Gram term on the fused engine."""
+    args = config.get_args(["--transfer_type", "img_vid", "--content", "c.png", "--style", "clip", "--model_file", p["vgg19"],
+                            "--disable_check", "--scaling_args", p["scaling"], "--image_sizes", str(S), "--num_iters", str(N),
+                            "--seed", "0", "--no_hist_match", "--output_dir", tmp])
+    args.gram_frame_window = B
+    g = torch.Generator().manual_seed(11)
+    content = torch.rand(1, 3, S, S, generator=g) * 255 - 120
+    clip = torch.rand(T, 3, S, S, generator=g) * 255 - 120
+    init = torch.rand(T, 3, S, S, generator=g) * 255 - 120
+    n_windows = len(optim.video_windows(init, [clip], B)[0])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = optim.optimize(content, [clip], init, N, args)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    fevals = n_windows * optim.lbfgs_moves(N)
+    return {"config": 6, "workload": f"img_vid: {T}-frame pastiche at {S}x{S}, windows of B = {B} frames ({n_windows} windows), "
+                                    f"{T}-frame style clip, avg_frame_window {args.avg_frame_window}, L-BFGS {N} iters per window",
+            "finite": bool(torch.isfinite(out).all()), "wall_seconds": round(wall, 3), "window_fevals": fevals,
+            "window_iterations_per_second_incl_setup": round(fevals / wall, 2),
+            "frame_iterations_per_second_incl_setup": round(fevals * B / wall, 2)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default="2,3,4,5")
@@ -176,6 +201,8 @@ def main():
             results.append(config4(p, tmp, a.frames))
         if 5 in want:
             results.append(config5(p, tmp))
+        if 6 in want:
+            results.append(config6(p, tmp))
     for r in results:
         print(json.dumps(r), flush=True)
     if a.out:
