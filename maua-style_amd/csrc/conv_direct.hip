@@ -181,15 +181,38 @@ conv3x3_few_out_kernel(ConvArgs p, const float* __restrict__ wbank) {
 }
 
 // out = act(bias + sum_split ws[split]) (+ out) masked: the fixed-order second stage of the split-K convolution
-__global__ void conv_splitk_finish_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
-                                        const float* __restrict__ omask, float* __restrict__ y, int ksplit, int Cout,
-                                        int64_t out_plane, int64_t total, int relu, int accumulate) {
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t per_n = (int64_t)Cout * out_plane;
-        const int64_t n = e / per_n, r = e - n * per_n;
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+conv_splitk_finish_kernel(const float* __restrict__ ws, const float* __restrict__ bias, const float* __restrict__ omask,
+                          float* __restrict__ y, int ksplit, int Cout, int64_t out_plane, int relu, int accumulate) {
+    // grid = (pixel quads of a plane / 256, Cout, n): no index divisions, the channel's bias is wave-uniform, 16-byte
+    // accesses when planes are quad-aligned; the ksplit partials are added in index order (deterministic)
+    const int co = blockIdx.y, n = blockIdx.z;
+    const int64_t per_n = (int64_t)Cout * out_plane;
+    const int64_t p = ((int64_t)blockIdx.x * 256 + threadIdx.x) * (VEC ? 4 : 1);
+    if (p >= out_plane) return;
+    const int64_t r = (int64_t)co * out_plane + p, e = (int64_t)n * per_n + r;
+    const float* src = ws + (int64_t)n * ksplit * per_n + r;
+    const float b = bias ? bias[co] : 0.f;
+    if constexpr (VEC) {
+        typedef float v4 __attribute__((ext_vector_type(4)));
+        v4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < ksplit; ++k) v += *reinterpret_cast<const v4*>(src + (int64_t)k * per_n);
+        v += b;
+        if (accumulate) v += *reinterpret_cast<const v4*>(y + e);
+        v4 m = {1.f, 1.f, 1.f, 1.f};
+        if (omask) m = *reinterpret_cast<const v4*>(omask + e);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float t = v[i];
+            if (relu) t = t > 0.f ? t : 0.f;
+            v[i] = m[i] > 0.f ? t : 0.f;
+        }
+        *reinterpret_cast<v4*>(y + e) = v;
+    } else {
         float v = 0.f;
-        for (int k = 0; k < ksplit; ++k) v += ws[(n * ksplit + k) * per_n + r];
-        if (bias) v += bias[r / out_plane];
+        for (int k = 0; k < ksplit; ++k) v += src[(int64_t)k * per_n];
+        v += b;
         if (accumulate) v += y[e];
         if (relu) v = v > 0.f ? v : 0.f;
         if (omask) v = omask[e] > 0.f ? v : 0.f;
@@ -198,11 +221,16 @@ __global__ void conv_splitk_finish_kernel(const float* __restrict__ ws, const fl
 }
 
 int conv_splitk_finish(const ConvArgs& a, int n, int ksplit, hipStream_t stream) {
-    const int64_t out_plane = (int64_t)a.OH * a.OW, total = (int64_t)n * a.Cout * out_plane;
-    int fb = (int)((total + 255) / 256);
-    if (fb > 4096) fb = 4096;
-    hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(fb), dim3(256), 0, stream, a.ws, a.bias, a.omask, a.y, ksplit, a.Cout,
-                       out_plane, total, a.relu, a.accumulate);
+    const int64_t out_plane = (int64_t)a.OH * a.OW;
+    const bool vec = out_plane % 4 == 0 && ((uintptr_t)a.ws | (uintptr_t)a.y | (uintptr_t)a.omask) % 16 == 0;
+    const int64_t items = vec ? out_plane / 4 : out_plane;
+    dim3 grid((unsigned)((items + 255) / 256), (unsigned)a.Cout, (unsigned)n);
+    if (vec)
+        hipLaunchKernelGGL(conv_splitk_finish_kernel<true>, grid, dim3(256), 0, stream, a.ws, a.bias, a.omask, a.y, ksplit, a.Cout,
+                           out_plane, a.relu, a.accumulate);
+    else
+        hipLaunchKernelGGL(conv_splitk_finish_kernel<false>, grid, dim3(256), 0, stream, a.ws, a.bias, a.omask, a.y, ksplit, a.Cout,
+                           out_plane, a.relu, a.accumulate);
     return check_launch("conv_splitk_finish_kernel");
 }
 
