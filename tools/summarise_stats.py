@@ -7,12 +7,12 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 iters = int(sys.argv[2])
 print("# rocprofv3 --kernel-trace --stats, round 1 (final state of the round)\n")
 print("Command (on the MI355X box, from /tmp with TMPDIR=/tmp):")
-print("`rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_final -o fin -- python3 bench.py --steps 20 --warmup 2 "
+print("`rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_fin2 -o fin -- python3 bench.py --steps 20 --warmup 2 "
       "--no_cpu_baseline --no_hip_graph`")
 print(f"({iters} iterations in total: 100 history-filling + 2 warm-up + 20 timed; 1024x1024, L-BFGS, eager launches so that every kernel "
       "appears under its own name; the JSON line of this run is `bench_r01_under_rocprof.json`, the unprofiled runs "
       "`bench_r01_final_1024_lbfgs.json` (hipGraph replay, the product default) and `bench_r01_final_1024_lbfgs_eager.json`).  "
-      "The conv_x6_kernel averages here are the figures `bench.py`'s `roofline.avg_launch_ms` must agree with.\n")
+      "The conv_x3_kernel averages here are the figures `bench.py`'s `roofline.avg_launch_ms` must agree with.\n")
 print("| kernel | calls | total ms | avg us | % | ms / iteration |")
 print("|---|---|---|---|---|---|")
 for r in rows[:28]:
