@@ -42,6 +42,23 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // Sum over a workgroup of up to 1024 threads; result valid in thread 0.  `scratch` holds >= 16 doubles.
+// Maximum of a NON-NEGATIVE float over the wave with DPP row shifts / row broadcasts (no LDS-pipe shuffles: lanes without
+// a source receive 0, the identity for non-negative maxima); the result is wave-uniform.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_max_nonneg(float v) {
+    const int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+    return fmaxf(v, __builtin_bit_cast(float, o));
+}
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+    v = dpp_max_nonneg<0x111, 0xf>(v);  // row_shr:1   (inclusive scan inside each row of 16 lanes)
+    v = dpp_max_nonneg<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_max_nonneg<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_max_nonneg<0x118, 0xf>(v);  // row_shr:8
+    v = dpp_max_nonneg<0x142, 0xa>(v);  // row_bcast:15 -> rows 1, 3
+    v = dpp_max_nonneg<0x143, 0xc>(v);  // row_bcast:31 -> rows 2, 3 ; lane 63 holds the maximum
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 __device__ __forceinline__ double block_sum(double v, double* scratch) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     v = wave_sum(v);

@@ -124,11 +124,8 @@ __global__ void __launch_bounds__(256, 4) conv1x1_x3_kernel(ConvArgs p, const fl
             for (int q = 0; q < 4; ++q) mx = fmaxf(fmaxf(mx, fabsf(rx[s][q][0])), fabsf(rx[s][q][1]));
 #pragma unroll
         for (int q = 0; q < 4; ++q) mw = fmaxf(fmaxf(mw, fabsf(rw[q][0])), fabsf(rw[q][1]));
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-            mw = fmaxf(mw, __shfl_xor(mw, off, 64));
-        }
+        mx = wave_max_nonneg(mx);
+        mw = wave_max_nonneg(mw);
         if (lane == 0) {
             Ml[wave] = mx;
             Ml[4 + wave] = mw;

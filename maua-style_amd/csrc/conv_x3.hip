@@ -134,8 +134,7 @@ __global__ void __launch_bounds__(256, 4) conv_x3_kernel(ConvArgs p, float w_inv
             const bool ok = pos_ok && (C8 || rp_c0 + c < p.Cin);
             m = fmaxf(m, ok ? fabsf(rp[c]) : 0.f);
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        m = wave_max_nonneg(m);
         if (lane == 0) Ml[wave] = m;
     };
     // scale of the staged chunk: max in [2^11, 2^12) after scaling.  Returns the INVERSE scale, sets `sx`.
