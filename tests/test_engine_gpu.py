@@ -512,6 +512,21 @@ def test_engine_on_a_window_of_frames_vs_fp64_oracle(weight_files, variant):
     assert rel_l2(grad.cpu(), grad_o) <= 1e-5
 
 
+def test_img_vid_graph_replay_equals_eager_launches(weight_files, monkeypatch):
+    """Runs of >= 128 iterations replay each window's iteration (fused plan on B frames, overlap-gradient masking, L-BFGS
+    update) from a captured hipGraph; the result must be the eager one bit for bit."""
+    import optim
+    content, style_video, init = imgvid_inputs()
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MAUA_HIP_GRAPH", flag)
+        args = product_args(weight_files, IMGVID_FLAGS, optimizer="lbfgs", S=64, N=130)
+        args.gram_frame_window = 3
+        outs.append(optim.optimize(content, [style_video], init.clone(), 130, args))
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_pixel_gradient_is_as_close_to_fp64_as_the_reference_fp32(weight_files):
     """The split-precision convolutions claim fp32-level accuracy: the whole-network pixel gradient must sit as close to the
     fp64 reference as the reference's own fp32 arithmetic does (fixtures hold both), not merely inside a loose tolerance."""
