@@ -10,9 +10,11 @@ one RCCL broadcast of the conv weights and style targets; there is no per-iterat
 Before the timed region the L-BFGS history (100 pairs) is filled by running `history` real iterations, so the
 timed steps are steady-state iterations (the two-loop cost grows until the history is full).
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the MFMA implicit-GEMM convolution):
-algorithmic FLOPs per launch / average launch duration measured with HIP events on the launch stream, against
-the fp32 MFMA peak (157.3 TFLOP/s).  `cpu_baseline` times the CPU oracle on this host's cores on a bounded sample.
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the split-precision 3x3 convolution, conv_x3.hip
+by default): algorithmic fp32-equivalent FLOPs per launch / average launch duration measured with HIP events on the launch
+stream, against the dense 16-bit MFMA peak divided by the MFMAs one product block costs (2500 / 3 for fp16x3, 2500 / 6 for
+bf16x6; 157.3 TFLOP/s when the fp32 matrix cores are selected with MAUA_CONV_X6=0); `traffic` comes from the committed
+PMC passes.  `cpu_baseline` times the CPU oracle on this host's cores on a bounded sample.
 """
 import argparse
 import json
@@ -224,7 +226,7 @@ def main():
     ms = elapsed / a.steps * 1e3
     # dominant kernel: the MFMA convolution (forward + backward-data launches)
     x6 = opt.engine is not None and opt.engine.x6_fwd and opt.engine.x6_bwd
-    dominant = "conv_x6" if x6 else "conv"  # with bf16x6 on, conv1_1 (3 channels) runs other kernels: not counted here
+    dominant = "conv3x3_split" if x6 else "conv"  # with bf16x6 on, conv1_1 (3 channels) runs other kernels: not counted here
     conv = [(fl, e0.elapsed_time(e1)) for tag, fl, nb, e0, e1 in timer if tag.startswith(dominant)]
     roofline = None
     pmc = pmc_traffic(("maua::conv_x3_kernel<" if models._x3_enabled() else "maua::conv_x6_kernel<") if x6

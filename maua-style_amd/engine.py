@@ -264,7 +264,7 @@ class StyleEngine:
             if s.kind == "conv":
                 fl, nb = self._conv_work(s, a[s.src].shape, a[s.dst].shape, False)
                 if self.x6_fwd and self._x6_ok(s, s.mod.out_channels):
-                    self._timed("conv_x6_fwd", fl, nb, lambda: models_mod.conv3x3_mfma(
+                    self._timed("conv3x3_split_fwd", fl, nb, lambda: models_mod.conv3x3_mfma(
                         a[s.src], s.mod, False, out=a[s.dst], relu=s.relu, workspace=self.ws))
                 elif self.x6_fwd and models_mod.conv1x1_is_mfma(s.mod, False):
                     self._timed("conv_1x1_fwd", fl, nb, lambda: models_mod.conv1x1_mfma(
@@ -384,7 +384,7 @@ class StyleEngine:
                 fl, nb = self._conv_work(s, a[s.src].shape, a[s.dst].shape, True)
                 im = a[s.src] if premask(s) else None
                 if self.x6_bwd and self._x6_ok(s, s.mod.in_channels):
-                    self._timed("conv_x6_bwd", fl, nb, lambda: models_mod.conv3x3_mfma(
+                    self._timed("conv3x3_split_bwd", fl, nb, lambda: models_mod.conv3x3_mfma(
                         g[s.dst], s.mod, True, out=g[s.src], out_relu_mask=im, workspace=self.ws))
                 elif self.x6_bwd and models_mod.conv1x1_is_mfma(s.mod, True):
                     self._timed("conv_1x1_bwd", fl, nb, lambda: models_mod.conv1x1_mfma(
