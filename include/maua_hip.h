@@ -104,6 +104,17 @@ int maua_conv3x3_x3(const float* x, const void* bank, float w_scale, const float
                     int n, int cin, int h, int w, int cout, int pad, int relu, int accumulate, void* workspace,
                     size_t workspace_bytes, maua_stream_t stream);
 
+/* ---- KS x KS stride-1 convolution in the same fp16x3 arithmetic (conv_kxk_x3.hip; KS = 5: NIN's conv2, models.py:86).
+ *      Banks as for maua_conv_pack_filters_x3 with KS*KS taps; backward-data of a pad-p conv: bank_bwd, cin/cout exchanged,
+ *      pad KS-1-p.  workspace (nullable) as for maua_conv3x3_x6: lets small output grids split the channel loop. ---- */
+size_t maua_conv_kxk_x3_bank_bytes(int cout_produced, int cin_consumed, int ks);
+int maua_conv_pack_filters_kxk_x3(const float* w_oihw, void* bank_fwd, void* bank_bwd, int cout, int cin, int ks, float w_scale,
+                                  maua_stream_t stream);
+size_t maua_conv_kxk_x3_workspace_bytes(int n, int cin, int h, int w, int cout, int ks, int pad);
+int maua_conv_kxk_x3(const float* x, const void* bank, float w_scale, const float* bias, const float* out_relu_mask, float* y,
+                     int n, int cin, int h, int w, int cout, int ks, int pad, int relu, int accumulate, void* workspace,
+                     size_t workspace_bytes, maua_stream_t stream);
+
 /* ---- 1x1 convolution / channel-mixing product y[co][p] (+)= sum_ci w[co][ci] x[ci][p] in the same fp16x3 arithmetic
  *      (conv1x1_x3.hip): NIN's 1x1 layers (models.py:84-110; backward-data passes the transposed weights) and the Gram
  *      backward D x (F - mean) of loss.py:91.  Both operands are plain fp32; the kernel scales and splits them per

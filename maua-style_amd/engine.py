@@ -162,6 +162,9 @@ class StyleEngine:
                 _, cout, oh, ow = shapes[s.dst]
                 ws = max(ws, hip.conv_workspace_bytes(n, cin, h, w, cout, s.k, 1, s.pad),
                          hip.conv_workspace_bytes(n, cout, oh, ow, cin, s.k, 1, s.k - 1 - s.pad))
+                if s.k == 5:
+                    ws = max(ws, hip.conv_kxk_x3_workspace_bytes(n, cin, h, w, cout, 5, s.pad),
+                             hip.conv_kxk_x3_workspace_bytes(n, cout, oh, ow, cin, 5, 4 - s.pad))
                 if s.k == 1 and s.pad == 0:
                     ws = max(ws, hip.conv1x1_x3_workspace_bytes(n, cin, h * w, cout), hip.conv1x1_x3_workspace_bytes(n, cout, h * w, cin))
                 if s.k == 3:
@@ -268,6 +271,9 @@ class StyleEngine:
                         a[s.src], s.mod, False, out=a[s.dst], relu=s.relu, workspace=self.ws))
                 elif self.x6_fwd and models_mod.conv1x1_is_mfma(s.mod, False):
                     self._timed("conv_1x1_fwd", fl, nb, lambda: models_mod.conv1x1_mfma(
+                        a[s.src], s.mod, False, out=a[s.dst], relu=s.relu, workspace=self.ws))
+                elif self.x6_fwd and models_mod.conv5x5_is_mfma(s.mod, False):
+                    self._timed("conv_5x5_fwd", fl, nb, lambda: models_mod.conv5x5_mfma(
                         a[s.src], s.mod, False, out=a[s.dst], relu=s.relu, workspace=self.ws))
                 else:
                     wf, _ = s.mod.banks()
@@ -389,6 +395,9 @@ class StyleEngine:
                 elif self.x6_bwd and models_mod.conv1x1_is_mfma(s.mod, True):
                     self._timed("conv_1x1_bwd", fl, nb, lambda: models_mod.conv1x1_mfma(
                         g[s.dst], s.mod, True, out=g[s.src], out_relu_mask=im, workspace=self.ws))
+                elif self.x6_bwd and models_mod.conv5x5_is_mfma(s.mod, True):
+                    self._timed("conv_5x5_bwd", fl, nb, lambda: models_mod.conv5x5_mfma(
+                        g[s.dst], s.mod, True, out=g[s.src], out_relu_mask=im, workspace=self.ws))
                 else:
                     _, wb = s.mod.banks()
                     self._timed("conv_other_bwd", fl, nb, lambda: hip.conv2d_bwd_data(
@@ -425,6 +434,8 @@ class StyleEngine:
                     models_mod.conv3x3_mfma(a[s.src], s.mod, False, out=a[s.dst], relu=s.relu, workspace=self.ws)
                 elif self.x6_fwd and models_mod.conv1x1_is_mfma(s.mod, False):
                     models_mod.conv1x1_mfma(a[s.src], s.mod, False, out=a[s.dst], relu=s.relu, workspace=self.ws)
+                elif self.x6_fwd and models_mod.conv5x5_is_mfma(s.mod, False):
+                    models_mod.conv5x5_mfma(a[s.src], s.mod, False, out=a[s.dst], relu=s.relu, workspace=self.ws)
                 else:
                     wf, _ = s.mod.banks()
                     hip.conv2d_fwd(a[s.src], wf, s.mod.bias_device(), s.k, s.stride, s.pad, s.relu, out=a[s.dst],

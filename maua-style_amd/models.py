@@ -39,7 +39,7 @@ def _x6_mode():
 
 def _x3_enabled():
     """MAUA_CONV_X3: "1" (default) = the fp32-accurate 3x3 convolution runs as fp16x3 (two-part fp16 split, three MFMAs per
-    product block, conv_x3.hip; the 3-channel image layer keeps the exact bf16x6 products); "0" = bf16x6 everywhere
+    product block, conv_x3.hip; the 3-channel image layer keeps the exact bf16x6 products); "0" = bf16x6 everywhere (and NIN's 1x1 / 5x5 layers on the fp32 matrix cores)
     (three-part bf16 split, six MFMAs, conv_x6.hip).  Measured pixel-gradient error against the fp64 reference:
     2.8e-7 / 2.6e-7; the reference's own fp32 arithmetic: 4.5e-7 (4.6e-7 if the image layer ran on fp16x3 too)."""
     import os
@@ -82,6 +82,24 @@ def conv1x1_mfma(x, mod, backward, out=None, out_relu_mask=None, relu=False, wor
     return hip.conv1x1_x3(x, w2d, mod.bias_device(), relu, out=out, out_relu_mask=out_relu_mask, workspace=workspace)
 
 
+def conv5x5_is_mfma(mod, backward):
+    """Whether a layer's pass runs on the fp16x3 k x k kernel (conv_kxk_x3.hip): 5x5, stride 1 (NIN's conv2, reference
+    models.py:86), the split-precision path enabled for that pass and fp16x3 selected."""
+    k, stride, pad = mod.kernel_size[0], mod.stride[0], mod.padding[0]
+    produced = mod.in_channels if backward else mod.out_channels
+    return _x6_mode()[1 if backward else 0] and _x3_enabled() and k == 5 and stride == 1 and pad <= 4 and produced > 32
+
+
+def conv5x5_mfma(x, mod, backward, out=None, out_relu_mask=None, relu=False, workspace=None):
+    bf, bb, wsc = mod.banks_kxk()
+    k, pad = mod.kernel_size[0], mod.padding[0]
+    if backward:
+        return hip.conv_kxk_x3(x, bb, wsc, None, mod.in_channels, k, k - 1 - pad, False, out=out, out_relu_mask=out_relu_mask,
+                               workspace=workspace)
+    return hip.conv_kxk_x3(x, bf, wsc, mod.bias_device(), mod.out_channels, k, pad, relu, out=out, out_relu_mask=out_relu_mask,
+                           workspace=workspace)
+
+
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mod):
@@ -91,6 +109,8 @@ class _ConvFn(torch.autograd.Function):
             return conv3x3_mfma(x.contiguous(), mod, False)
         if conv1x1_is_mfma(mod, False):
             return conv1x1_mfma(x.contiguous(), mod, False)
+        if conv5x5_is_mfma(mod, False):
+            return conv5x5_mfma(x.contiguous(), mod, False)
         return hip.conv2d_fwd(x.contiguous(), mod.banks()[0], mod.bias_device(), k, stride, pad, False)
 
     @staticmethod
@@ -101,6 +121,8 @@ class _ConvFn(torch.autograd.Function):
             return conv3x3_mfma(gy.contiguous(), mod, True), None
         if conv1x1_is_mfma(mod, True):
             return conv1x1_mfma(gy.contiguous(), mod, True), None
+        if conv5x5_is_mfma(mod, True):
+            return conv5x5_mfma(gy.contiguous(), mod, True), None
         gx = hip.conv2d_bwd_data(gy.contiguous(), None, mod.banks()[1], mod.weight.detach(), ctx.in_shape, k, stride, pad)
         return gx, None
 
@@ -134,6 +156,14 @@ class Conv2d(nn.Conv2d):
             self._banks3 = hip.conv_pack_filters_x3(self.weight.detach().contiguous())
             self._bank3_key = key
         return self._banks3
+
+    def banks_kxk(self):
+        """fp16x2 pre-split, pre-scaled banks (forward, backward-data, filter scale) of the k x k fp16x3 kernel."""
+        key = (self.weight.data_ptr(), self.weight._version, self.weight.device)
+        if getattr(self, "_bankk_key", None) != key:
+            self._banksk = hip.conv_pack_filters_kxk_x3(self.weight.detach().contiguous())
+            self._bankk_key = key
+        return self._banksk
 
     def mats(self):
         """1x1 layers: the weights as plain matrices ([cout][cin], [cin][cout]) for the fp16x3 1x1 kernel."""

@@ -27,7 +27,7 @@ def test_header_symbols_exported(libpath):
     out = subprocess.check_output(["nm", "-D", "--defined-only", libpath], text=True)
     exported = set(re.findall(r" T (maua_[a-z0-9_]+)", out))
     want = declared_symbols()
-    assert len(want) >= 36
+    assert len(want) >= 40
     missing = [s for s in want if s not in exported]
     assert not missing, f"declared in maua_hip.h but not exported: {missing}"
     extra = sorted(exported - set(want))

@@ -614,6 +614,64 @@ def test_conv1x1_x3_scaling_survives_extreme_inputs(hip, kind):
         assert rel_l2(y.cpu(), ref) <= 2e-6
 
 
+# ---------------------------------------------------------------------------------------------------------
+# fp16x3 k x k convolution (5x5: NIN's conv2), forward and backward-data
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cin,cout,H,W,pad", [(96, 256, 31, 29, 2), (40, 70, 9, 37, 2), (256, 96, 20, 33, 2), (16, 64, 12, 12, 0),
+                                              (8, 40, 5, 70, 4)])
+def test_conv5x5_x3_forward_and_backward(hip, cin, cout, H, W, pad):
+    x = rnd(2, cin, H, W, seed=1)
+    w = rnd(cout, cin, 5, 5, seed=2, scale=math.sqrt(2.0 / (25 * cin)))
+    b = rnd(cout, seed=3, scale=0.1)
+    ref = torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=pad))
+    bank_f, bank_b, wsc = hip.conv_pack_filters_kxk_x3(dev(w))
+    assert 32 <= float(w.abs().max()) * wsc < 64
+    y = hip.conv_kxk_x3(dev(x), bank_f, wsc, dev(b), cout, 5, pad, True)
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape
+    assert rel_l2(y.cpu(), ref) <= 2e-6
+    gy = rnd(*ref.shape, seed=4)
+    refb = torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), padding=pad)
+    mask, base = rnd(*x.shape, seed=6), rnd(*x.shape, seed=5)
+    gx = hip.conv_kxk_x3(dev(gy), bank_b, wsc, None, cin, 5, 4 - pad, False, out_relu_mask=dev(mask))
+    torch.cuda.synchronize()
+    assert gx.shape == x.shape
+    assert rel_l2(gx.cpu(), refb * (mask > 0)) <= 2e-6
+    gx2 = hip.conv_kxk_x3(dev(gy), bank_b, wsc, None, cin, 5, 4 - pad, False, out=dev(base.clone()), accumulate=True)
+    gx3 = hip.conv_kxk_x3(dev(gy), bank_b, wsc, None, cin, 5, 4 - pad, False, out=dev(base.clone()), accumulate=True)
+    torch.cuda.synchronize()
+    assert rel_l2(gx2.cpu(), refb + base.double()) <= 2e-6
+    assert torch.equal(gx2, gx3)
+
+
+def test_conv5x5_x3_split_k_matches_single_pass(hip):
+    """Backward geometry of NIN's conv2 scaled down: few output tiles -> the channel loop is split and finished in order."""
+    cin, cout, H, W = 256, 96, 24, 30
+    assert hip.conv_kxk_x3_workspace_bytes(1, cin, H, W, cout, 5, 2) > 0
+    assert hip.conv_kxk_x3_workspace_bytes(1, 96, 126, 126, 256, 5, 2) == 0
+    x = rnd(1, cin, H, W, seed=1)
+    w = rnd(cout, cin, 5, 5, seed=2, scale=math.sqrt(2.0 / (25 * cin)))
+    b = rnd(cout, seed=3, scale=0.1)
+    base, mask = rnd(1, cout, H, W, seed=5), rnd(1, cout, H, W, seed=6)
+    ref = (torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=2) + base.double())) * (mask > 0)
+    bank_f, _, wsc = hip.conv_pack_filters_kxk_x3(dev(w))
+    none = torch.empty(0, dtype=torch.uint8, device="cuda")
+    one = hip.conv_kxk_x3(dev(x), bank_f, wsc, dev(b), cout, 5, 2, True, out=dev(base.clone()), accumulate=True,
+                          out_relu_mask=dev(mask), workspace=none)
+    split = hip.conv_kxk_x3(dev(x), bank_f, wsc, dev(b), cout, 5, 2, True, out=dev(base.clone()), accumulate=True,
+                            out_relu_mask=dev(mask))
+    torch.cuda.synchronize()
+    assert rel_l2(one.cpu(), ref) <= 2e-6 and rel_l2(split.cpu(), ref) <= 2e-6
+    assert rel_l2(split.cpu(), one.cpu().double()) <= 5e-7
+
+
+def test_conv5x5_x3_rejects_other_filter_sizes(hip):
+    x = dev(rnd(1, 8, 16, 16))
+    bank = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    with pytest.raises(hip.HipError):
+        hip.conv_kxk_x3(x, bank, 1.0, None, 64, 7, 3, False)
+
+
 def test_conv3x3_x6_persistent_workgroups_subprocess():
     """MAUA_X6_PERSIST=1 (read once per process): several tiles per workgroup with cross-tile prefetch, in-loop epilogue
     and accumulator re-initialisation must give the same bits as one workgroup per tile."""
