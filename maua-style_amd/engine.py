@@ -289,20 +289,31 @@ class StyleEngine:
                 (lw, gw), dynamic = self._style_terms(s, B)
                 slots = self.terms[id(s)]
                 cov = s.mod.use_covariance
-                for b in range(B):  # static terms: one C x C Gram per frame against the shared target
-                    mean_b = self.mean[id(s)][b] if cov else None
-                    self._timed("gram_fwd", 2 * c * c * (n // c), n * 4 + c * c * 4, lambda: hip.gram_fwd(
-                        f[b:b + 1], 1.0 / n, cov, out=self.gram[id(s)][b], mean_out=mean_b, workspace=self.ws))
-                    hip.mse_fwd_bwd(self.gram[id(s)][b], s.mod.target, self.dmat[id(s)][b], lw / (c * c), gw * 4.0 / (c * c) / n,
-                                    False, self.slots_all[slots[b]:slots[b] + 1], workspace=self.ws)
-                if dynamic is not None:  # one (B C) x (B C) Gram over the window: rows are (frame, channel) pairs
+                if dynamic is not None:
+                    # One (B C) x (B C) Gram over the window (rows = (frame, channel) pairs of the contiguous activation): its
+                    # diagonal C x C blocks are the per-frame Grams (up to the normalisation, 1 / (B n) instead of 1 / n), so the
+                    # static terms cost no extra pass over the feature maps - forward or backward.
                     lwd, gwd = dynamic
                     bc, nall = B * c, B * n
+                    gd, dd = self.gram_d[id(s)], self.dmat_d[id(s)]
                     self._timed("gram_fwd", 2 * bc * bc * (n // c), nall * 4 + bc * bc * 4, lambda: hip.gram_fwd(
-                        f.view(1, bc, f.shape[2], f.shape[3]), 1.0 / nall, cov, out=self.gram_d[id(s)],
-                        mean_out=self.mean_d[id(s)], workspace=self.ws))
-                    hip.mse_fwd_bwd(self.gram_d[id(s)], s.mod.video_target, self.dmat_d[id(s)], lwd / (bc * bc),
-                                    gwd * 4.0 / (bc * bc) / nall, False, self.slots_all[slots[B]:slots[B] + 1], workspace=self.ws)
+                        f.view(1, bc, f.shape[2], f.shape[3]), 1.0 / nall, cov, out=gd, mean_out=self.mean_d[id(s)],
+                        workspace=self.ws))
+                    hip.mse_fwd_bwd(gd, s.mod.video_target, dd, lwd / (bc * bc), gwd * 4.0 / (bc * bc) / nall, False,
+                                    self.slots_all[slots[B]:slots[B] + 1], workspace=self.ws)
+                    for b in range(B):
+                        blk = slice(b * c, (b + 1) * c)
+                        torch.mul(gd[blk, blk], float(B), out=self.gram[id(s)][b])
+                        hip.mse_fwd_bwd(self.gram[id(s)][b], s.mod.target, self.dmat[id(s)][b], lw / (c * c), gw * 4.0 / (c * c) / n,
+                                        False, self.slots_all[slots[b]:slots[b] + 1], workspace=self.ws)
+                        dd[blk, blk] += self.dmat[id(s)][b]  # the frame's static gradient matrix joins the diagonal block
+                else:
+                    for b in range(B):  # static terms only: one C x C Gram per frame against the shared target
+                        mean_b = self.mean[id(s)][b] if cov else None
+                        self._timed("gram_fwd", 2 * c * c * (n // c), n * 4 + c * c * 4, lambda: hip.gram_fwd(
+                            f[b:b + 1], 1.0 / n, cov, out=self.gram[id(s)][b], mean_out=mean_b, workspace=self.ws))
+                        hip.mse_fwd_bwd(self.gram[id(s)][b], s.mod.target, self.dmat[id(s)][b], lw / (c * c),
+                                        gw * 4.0 / (c * c) / n, False, self.slots_all[slots[b]:slots[b] + 1], workspace=self.ws)
             elif s.kind == "style" and self._active(s, a[s.src].shape):
                 f = a[s.src]
                 c, n = f.shape[1], f[0].nelement()
@@ -334,17 +345,16 @@ class StyleEngine:
                     _, dynamic = self._style_terms(s, B)
                     acc = cur == s.src
                     cov = s.mod.use_covariance
-                    last_is_static = dynamic is None  # the last writer of a slice applies the producer's ReLU mask
-                    for b in range(B):
-                        rm = f[b] if (premask(s) and last_is_static) else None
-                        self._timed("gram_bwd", 2 * c * c * (n // c), n * 4 * 3 + c * c * 4, lambda: hip.gram_bwd(
-                            self.dmat[id(s)][b], f[b], self.mean[id(s)][b] if cov else None, g[s.src][b], acc, workspace=self.ws,
-                            relu_mask=rm))
-                    if dynamic is not None:
+                    if dynamic is not None:  # one pass: D = dynamic matrix + per-frame static matrices on its diagonal blocks
                         bc = B * c
                         self._timed("gram_bwd", 2 * bc * bc * (n // c), B * n * 4 * 3 + bc * bc * 4, lambda: hip.gram_bwd(
-                            self.dmat_d[id(s)], f, self.mean_d[id(s)], g[s.src], True, workspace=self.ws,
+                            self.dmat_d[id(s)], f, self.mean_d[id(s)], g[s.src], acc, workspace=self.ws,
                             relu_mask=f if premask(s) else None))
+                    else:
+                        for b in range(B):
+                            self._timed("gram_bwd", 2 * c * c * (n // c), n * 4 * 3 + c * c * 4, lambda: hip.gram_bwd(
+                                self.dmat[id(s)][b], f[b], self.mean[id(s)][b] if cov else None, g[s.src][b], acc,
+                                workspace=self.ws, relu_mask=f[b] if premask(s) else None))
                     cur = s.src
             elif s.kind == "content" and a[s.src].shape[0] > 1:
                 if self._active(s, a[s.src].shape):
