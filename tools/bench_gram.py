@@ -21,4 +21,4 @@ for name, c, hw in shapes:
     out = torch.empty(c, c, device="cuda")
     t = timeit(lambda: hip.gram_fwd(f, 1.0 / (c * hw), False, out=out, workspace=ws))
     gf = 2.0 * c * c * hw / 1e9
-    print(f"{name:18s} C={c:5d} HW={hw:8d}  {t:8.1f} us  {gf / t:7.1f} TFLOP/s  HBM floor {c * hw * 4 / 6.3e6:6.1f} us", flush=True)
+    print(f"{name:18s} C={c:5d} HW={hw:8d}  {t:8.1f} us  {gf / t * 1e3:7.1f} TFLOP/s  HBM floor {c * hw * 4 / 6.3e6:6.1f} us", flush=True)
