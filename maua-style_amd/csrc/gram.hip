@@ -19,6 +19,7 @@ constexpr int GK = 64;       // pixels per stage
 constexpr int GRS = GK + 4;  // LDS row stride (floats): 16-byte aligned rows, 4*row mod 64 banks -> conflict-free b128
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
 // Row means in two fixed-order stages: grid (C, RM_SPLIT) partial sums in fp64, then one small kernel adds each row's
 // partials in index order (one workgroup per row could not fill the chip: 96 rows of 64516 values took 64 us).
@@ -46,7 +47,6 @@ __global__ void row_mean_finish_kernel(const double* __restrict__ partial, float
 // consecutive pixels with one ds_read_b128 and uses them as the k-values of 4 MFMAs: half h of the wave takes pixels
 // 8q+4h..8q+4h+3 of every 8-pixel group, the same pixels for the A and the B operand, so the pairing is consistent.
 // On diagonal tiles the (1,0) block is the transpose of (0,1) and is not computed (gram_finish mirrors it).
-template <bool VEC>
 __global__ void __launch_bounds__(256)
 gram_partial_kernel(const float* __restrict__ f, const float* __restrict__ mean, float* __restrict__ partial, int C,
                     int64_t HW, int ksplit, int64_t chunk) {
@@ -77,16 +77,16 @@ gram_partial_kernel(const float* __restrict__ f, const float* __restrict__ mean,
             const int64_t pp = p0 + c4;
             const int rowa = ti * GT + r, rowb = tj * GT + r;
             f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (VEC) {
-                if (pp < p_end) {
-                    if (rowa < C) {
-                        va = *reinterpret_cast<const f32x4*>(f + (int64_t)rowa * HW + pp);
-                        if (mean) va -= mean[rowa];
-                    }
-                    if (!diag && rowb < C) {
-                        vb = *reinterpret_cast<const f32x4*>(f + (int64_t)rowb * HW + pp);
-                        if (mean) vb -= mean[rowb];
-                    }
+            // 16-byte loads need only dword alignment in global memory, so rows of odd length (NIN's 253^2, 63^2, 31^2 planes;
+            // the deep layers at 724^2) are read the same way; a row's last, partial quad goes element by element
+            if (pp + 4 <= p_end) {
+                if (rowa < C) {
+                    va = *reinterpret_cast<const f32x4u*>(f + (int64_t)rowa * HW + pp);
+                    if (mean) va -= mean[rowa];
+                }
+                if (!diag && rowb < C) {
+                    vb = *reinterpret_cast<const f32x4u*>(f + (int64_t)rowb * HW + pp);
+                    if (mean) vb -= mean[rowb];
                 }
             } else {
 #pragma unroll
@@ -360,13 +360,8 @@ int maua_gram_fwd(const float* f, float* gram, float* row_mean_out, int c, int64
         rc = check_launch("row_mean_finish_kernel");
         if (rc) return rc;
     }
-    const bool vec = (hw % 4 == 0) && ((uintptr_t)f % 16 == 0);
-    if (vec)
-        hipLaunchKernelGGL(gram_partial_kernel<true>, dim3(npairs, ksplit), dim3(256), 0, s, f,
-                           center ? row_mean_out : nullptr, (float*)workspace, c, hw, ksplit, chunk);
-    else
-        hipLaunchKernelGGL(gram_partial_kernel<false>, dim3(npairs, ksplit), dim3(256), 0, s, f,
-                           center ? row_mean_out : nullptr, (float*)workspace, c, hw, ksplit, chunk);
+    hipLaunchKernelGGL(gram_partial_kernel, dim3(npairs, ksplit), dim3(256), 0, s, f, center ? row_mean_out : nullptr,
+                       (float*)workspace, c, hw, ksplit, chunk);
     int rc = check_launch("gram_partial_kernel");
     if (rc) return rc;
     int kstride = 1;
