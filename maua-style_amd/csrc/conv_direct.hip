@@ -181,21 +181,21 @@ conv3x3_few_out_kernel(ConvArgs p, const float* __restrict__ wbank) {
 }
 
 // out = act(bias + sum_split ws[split]) (+ out) masked: the fixed-order second stage of the split-K convolution
-template <bool VEC>
 __global__ void __launch_bounds__(256)
 conv_splitk_finish_kernel(const float* __restrict__ ws, const float* __restrict__ bias, const float* __restrict__ omask,
                           float* __restrict__ y, int ksplit, int Cout, int64_t out_plane, int relu, int accumulate) {
     // grid = (pixel quads of a plane / 256, Cout, n): no index divisions, the channel's bias is wave-uniform, 16-byte
-    // accesses when planes are quad-aligned; the ksplit partials are added in index order (deterministic)
+    // accesses (dword alignment is enough in global memory, so odd-sized planes take them too; a plane's last, partial
+    // quad goes element by element); the ksplit partials are added in index order (deterministic)
+    typedef float v4 __attribute__((ext_vector_type(4), aligned(4)));
     const int co = blockIdx.y, n = blockIdx.z;
     const int64_t per_n = (int64_t)Cout * out_plane;
-    const int64_t p = ((int64_t)blockIdx.x * 256 + threadIdx.x) * (VEC ? 4 : 1);
+    const int64_t p = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (p >= out_plane) return;
     const int64_t r = (int64_t)co * out_plane + p, e = (int64_t)n * per_n + r;
     const float* src = ws + (int64_t)n * ksplit * per_n + r;
     const float b = bias ? bias[co] : 0.f;
-    if constexpr (VEC) {
-        typedef float v4 __attribute__((ext_vector_type(4)));
+    if (p + 4 <= out_plane) {
         v4 v = {0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < ksplit; ++k) v += *reinterpret_cast<const v4*>(src + (int64_t)k * per_n);
         v += b;
@@ -210,27 +210,23 @@ conv_splitk_finish_kernel(const float* __restrict__ ws, const float* __restrict_
         }
         *reinterpret_cast<v4*>(y + e) = v;
     } else {
-        float v = 0.f;
-        for (int k = 0; k < ksplit; ++k) v += src[(int64_t)k * per_n];
-        v += b;
-        if (accumulate) v += y[e];
-        if (relu) v = v > 0.f ? v : 0.f;
-        if (omask) v = omask[e] > 0.f ? v : 0.f;
-        y[e] = v;
+        for (int i = 0; p + i < out_plane; ++i) {
+            float v = 0.f;
+            for (int k = 0; k < ksplit; ++k) v += src[(int64_t)k * per_n + i];
+            v += b;
+            if (accumulate) v += y[e + i];
+            if (relu) v = v > 0.f ? v : 0.f;
+            if (omask) v = omask[e + i] > 0.f ? v : 0.f;
+            y[e + i] = v;
+        }
     }
 }
 
 int conv_splitk_finish(const ConvArgs& a, int n, int ksplit, hipStream_t stream) {
     const int64_t out_plane = (int64_t)a.OH * a.OW;
-    const bool vec = out_plane % 4 == 0 && ((uintptr_t)a.ws | (uintptr_t)a.y | (uintptr_t)a.omask) % 16 == 0;
-    const int64_t items = vec ? out_plane / 4 : out_plane;
-    dim3 grid((unsigned)((items + 255) / 256), (unsigned)a.Cout, (unsigned)n);
-    if (vec)
-        hipLaunchKernelGGL(conv_splitk_finish_kernel<true>, grid, dim3(256), 0, stream, a.ws, a.bias, a.omask, a.y, ksplit, a.Cout,
-                           out_plane, a.relu, a.accumulate);
-    else
-        hipLaunchKernelGGL(conv_splitk_finish_kernel<false>, grid, dim3(256), 0, stream, a.ws, a.bias, a.omask, a.y, ksplit, a.Cout,
-                           out_plane, a.relu, a.accumulate);
+    dim3 grid((unsigned)(((out_plane + 3) / 4 + 255) / 256), (unsigned)a.Cout, (unsigned)n);
+    hipLaunchKernelGGL(conv_splitk_finish_kernel, grid, dim3(256), 0, stream, a.ws, a.bias, a.omask, a.y, ksplit, a.Cout, out_plane,
+                       a.relu, a.accumulate);
     return check_launch("conv_splitk_finish_kernel");
 }
 
