@@ -11,7 +11,6 @@
 // h takes group 2s+h).  LDS: activations [part][group][pixel][8ch] 16 KB + weights [group][part][co][8ch] 8 KB, both
 // conflict-free for b128.  Without the tap reuse of a 3x3 filter this is a bandwidth / staging-bound kernel (2 MFMA
 // steps per 16 staged values per thread); what it buys is the fp32 matrix cores' 16x lower rate out of the way.
-#include <stdlib.h>
 
 #include "common.hpp"
 

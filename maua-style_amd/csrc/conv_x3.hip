@@ -20,7 +20,6 @@
 // [tap][part][co][8ch] 18 KB), filter halves streamed by LDS-DMA behind the k-steps, counted vmcnt, XCD-aware tile
 // order, deterministic split-K.  The fp32 master accumulator is always present here (it is where the per-chunk scales
 // meet), so one variant serves every channel count (conv1_1's three channels are a single, partly empty chunk).
-#include <stdlib.h>
 
 #include "common.hpp"
 
