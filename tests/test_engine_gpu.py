@@ -527,6 +527,40 @@ def test_img_vid_graph_replay_equals_eager_launches(weight_files, monkeypatch):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("model,B,S,flags", [
+    ("nin", 2, 128, NIN_FLAGS + ["--use_covariance"]),
+    ("vgg19", 4, 48, ["--style_layers", "relu1_1,relu2_1,relu3_1", "--content_layers", "relu2_2"]),
+    ("vgg19", 2, 64, ["--style_layers", "relu1_1,relu2_1", "--content_layers", "relu2_2", "--video_style_factor", "0", "--pooling", "avg"]),
+])
+def test_engine_windows_other_networks_and_sizes(weight_files, model, B, S, flags):
+    """B = 2 / 4 frames through NIN (1x1, 5x5, strided stem, 3x3/2 ceil pools; covariance form) and VGG-19 variants: the fused
+    plan against the module-by-module autograd path on the same kernels."""
+    import engine
+    import models
+    import optim
+    args = product_args(weight_files, ["--transfer_type", "img_vid", "--avg_frame_window", "-1"] + flags, model=model,
+                        optimizer="adam", S=S, N=4)
+    args.gram_frame_window = B
+    g = torch.Generator().manual_seed(5)
+    content = torch.rand(1, 3, S, S, generator=g) * 255 - 120
+    clip = torch.rand(B + 2, 3, S, S, generator=g) * 255 - 120
+    x = torch.rand(B, 3, S, S, generator=g) * 255 - 120
+    optim.set_model_args(args, S)
+    net, losses = models.load_model(args)
+    optim.set_content_targets(net, content, args)
+    optim.set_style_video_targets(net, [clip], args)
+    for m in losses:
+        m.mode = "loss"
+    po = optim.PixelOptimizer(net, losses, x, args)
+    slots_m, total_m, grad_m = [t.clone() for t in po._feval_modules()]
+    slots_e, total_e, grad_e = engine.StyleEngine(net, losses).feval(x.cuda())
+    torch.cuda.synchronize()
+    assert abs(float(total_e) - float(total_m)) <= 1e-5 * abs(float(total_m))
+    for a_, b_ in zip(slots_e.cpu().tolist(), slots_m.cpu().tolist()):
+        assert abs(a_ - b_) <= 1e-5 * max(abs(b_), 1e-12)
+    assert rel_l2(grad_e.cpu(), grad_m.cpu().double()) <= 2e-5
+
+
 def test_pixel_gradient_is_as_close_to_fp64_as_the_reference_fp32(weight_files):
     """The split-precision convolutions claim fp32-level accuracy: the whole-network pixel gradient must sit as close to the
     fp64 reference as the reference's own fp32 arithmetic does (fixtures hold both), not merely inside a loose tolerance."""
