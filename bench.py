@@ -67,15 +67,32 @@ def algorithmic_work(S, history=100):
     return dict(flops=4 * macs + gram, bytes_feval=bf + bb, bytes_lbfgs=(4 * history + 10) * npx * 4)
 
 
-def cpu_baseline(S_full, optimizer):
-    """The CPU oracle (oracle/, a restatement of the reference's arithmetic on torch CPU ops) timed on this host:
-    a bounded sample at reduced size, scaled to S_full by the pixel ratio (the path is O(pixels))."""
+def _host_description():
+    """(nproc, CPU model string) of this host: os.cpu_count() and the 'model name' line of /proc/cpuinfo (what lscpu prints)."""
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return os.cpu_count() or 1, model
+
+
+def cpu_baseline(S, optimizer, iters=5, repeats=3):
+    """The CPU oracle (oracle/, a restatement of the reference's arithmetic on torch CPU ops) timed on this host's cores AT
+    THE BENCHMARKED SIZE, no extrapolation: `repeats` runs of `iters` L-BFGS iterations (evaluate + two-loop update) from
+    the same start, median.  The intra-op thread count is the fastest of a sweep of single evaluations up to nproc
+    (MKL-DNN oversubscribes badly on many-core hosts, SURVEY.md section 8c: more threads is not faster)."""
+    import argparse as ap
+    import statistics
+
     import synth
     from oracle import OracleNet, build_spec
     from oracle.style_oracle import _LbfgsState, _lbfgs_step
-    import argparse as ap
-    cores = os.cpu_count() or 1
-    S = 512 if S_full >= 512 else S_full
+    nproc, model = _host_description()
     cfg = ap.Namespace(model_file="vgg19", pooling="max", content_layers="relu4_2",
                        style_layers="relu1_1,relu2_1,relu3_1,relu4_1,relu5_1", tv_weight=1e-3, temporal_weight=50.0,
                        content_weight=5.0, style_weight=100.0, use_covariance=False, normalize_gradients=True,
@@ -85,28 +102,34 @@ def cpu_baseline(S_full, optimizer):
     net.capture_content(content)
     net.capture_style([style], [1.0])
     shape = init.shape
-    # thread count: MKL-DNN oversubscribes badly on many-core hosts; pick the fastest of a short sweep
+    sweep = {}
     best = (float("inf"), 1)
-    for k in sorted({min(cores, c) for c in (8, 16, 32, 64)}):
+    for k in sorted({min(nproc, c) for c in (4, 8, 16, 32, 64, 128, nproc)}):
         torch.set_num_threads(k)
         t0 = time.perf_counter()
         net.feval(init)
-        best = min(best, (time.perf_counter() - t0, k))
+        dt = time.perf_counter() - t0
+        sweep[k] = round(dt, 3)
+        best = min(best, (dt, k))
+        if dt > 2.0 * best[0]:
+            break  # well past the optimum: larger counts only oversubscribe further
     torch.set_num_threads(best[1])
 
     def closure(x):
         total, _, g = net.feval(x.reshape(shape))
         return float(total), g.flatten()
 
-    iters = 40  # ~10-30 s of CPU work on the hosts seen so far
-    st = _LbfgsState()
-    t0 = time.perf_counter()
-    _lbfgs_step(init.flatten().clone(), closure, st, iters, 100)
-    dt = time.perf_counter() - t0
-    scale = (S * S) / float(S_full * S_full)
-    return {"value": round(iters / dt * scale, 5), "unit": "iterations/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{iters} L-BFGS iterations of the CPU oracle at {S}x{S} in {dt:.1f} s, scaled by the pixel ratio "
-                      f"({S}^2/{S_full}^2) to {S_full}x{S_full}"}
+    times = []
+    for _ in range(repeats):
+        st = _LbfgsState()
+        t0 = time.perf_counter()
+        _lbfgs_step(init.flatten().clone(), closure, st, iters, 100)
+        times.append(time.perf_counter() - t0)
+    dt = statistics.median(times)
+    return {"value": round(iters / dt, 5), "unit": "iterations/s", "cores": best[1], "threads_used": best[1], "nproc": nproc,
+            "cpu_model": model, "kind": "port", "thread_sweep_s_per_feval": sweep,
+            "sample": f"{iters} L-BFGS iterations of the CPU oracle at {S}x{S} (the benchmarked size, no scaling), median of "
+                      f"{repeats} runs: {dt:.2f} s on {best[1]} threads ({nproc} logical CPUs)"}
 
 
 def pmc_traffic(prefix):
@@ -132,10 +155,88 @@ def pmc_traffic(prefix):
                     "2 x TCC_EA0_RDREQ x 64 B (gfx950 correction, upper bound for 4 B/lane loads) + write requests"}
 
 
+def _visible_gpus():
+    """Device count WITHOUT initialising the GPU in this process (torch.cuda.device_count() does not, on this image)."""
+    try:
+        return int(torch.cuda.device_count())
+    except Exception:
+        return 0
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` outside torchrun: start N fresh rank processes (one per GPU) with torchrun's environment
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) and wait for them.  This parent never touches the GPU and
+    never re-execs itself; rank 0's JSON line is relayed on stdout.  Fewer than N visible devices is an error unless
+    MAUA_DIST_BACKEND=gloo asks for several ranks per GPU (the 1-GPU test box)."""
+    import socket
+    import subprocess
+    have = _visible_gpus()
+    if have < n and os.environ.get("MAUA_DIST_BACKEND") != "gloo":
+        sys.stderr.write(f"bench.py: --gpus {n} but only {have} device(s) visible (set MAUA_DIST_BACKEND=gloo to share GPUs)\n")
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
+                       "HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write(f"bench.py: ranks failed (rank, exit code): {bad}\n")
+        return 1
+    return 0
+
+
+def steady_rate(size, steps, optimizer="lbfgs", history=100, warmup=5):
+    """iterations/s of one more single-image job at another size on this rank's GPU (the 512x512 figure north_star asks for
+    next to the 1024x1024 headline): same construction as the main workload, history prefilled, graph replay."""
+    import config
+    import models
+    import optim
+    import synth
+    tmp = tempfile.mkdtemp(prefix="maua_bench_")
+    wfile = os.path.join(tmp, "vgg19_synth.pth")
+    torch.save(synth.vgg19_state_dict(), wfile)
+    scaling = os.path.join(tmp, "scaling.json")
+    with open(scaling, "w") as f:
+        json.dump({"100000": {"gpu": "0", "multidevice": False}}, f)
+    args = config.get_args(["--content", "c.png", "--style", "s.png", "--model_file", wfile, "--disable_check",
+                            "--scaling_args", scaling, "--optimizer", optimizer, "--image_sizes", str(size),
+                            "--num_iters", str(steps), "--seed", "0", "--no_hist_match", "--lbfgs_num_correction", str(history)])
+    args.hip_graph = True
+    optim.set_model_args(args, size)
+    net, losses = models.load_model(args)
+    content, style, init = synth.images(size)
+    optim.set_content_targets(net, content, args)
+    optim.set_style_targets(net, [style], args)
+    for m in losses:
+        m.mode = "loss"
+    opt = optim.PixelOptimizer(net, losses, init, args)
+    for _ in range((history if optimizer == "lbfgs" else 0) + warmup):
+        opt.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        opt.step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    work = algorithmic_work(size, history)
+    return {"image_size": size, "optimizer": optimizer, "steps": steps, "iterations_per_s": round(steps / dt, 2),
+            "ms_per_step": round(dt / steps * 1e3, 4), "model_tflops": round(work["flops"] / (dt / steps) / 1e12, 2)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--optimizer", default="lbfgs", choices=["lbfgs", "adam"])
@@ -144,7 +245,10 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--hip_graph", action="store_true", help="(default) replay each iteration from a captured hipGraph")
     ap.add_argument("--no_hip_graph", action="store_true", help="launch every kernel eagerly in the timed region too")
+    ap.add_argument("--no_extra_sizes", action="store_true", help="skip the 512x512 figure in `extra`")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))  # before anything in this process touches the GPU
 
     import config
     import dist
@@ -154,6 +258,8 @@ def main():
     import synth
 
     rank, local_rank, world = dist.init()
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the process group has WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU implementation")
     hip.lib()
@@ -206,7 +312,9 @@ def main():
         opt.step()
     torch.cuda.synchronize()
     dist.barrier()
-    elapsed = dist.max_over_ranks(time.perf_counter() - t0)
+    mine = time.perf_counter() - t0
+    elapsed = dist.max_over_ranks(mine)
+    per_rank = dist.gather_floats(a.steps / mine)  # iterations/s of every rank (rank order)
     eager_ms = None
     if opt.engine is not None and a.hip_graph and rank == 0:
         opt.engine.timer = timer
@@ -286,6 +394,8 @@ def main():
                    "image_size": S, "optimizer": a.optimizer, "lbfgs_history_len": status.get("history_len"),
                    "parallelism": f"frames x{world} (replicas, one broadcast, no per-iteration collective)",
                    "hip_graph": bool(a.hip_graph)},
+        "rccl_ranks": dist.group_size(), "dist_backend": dist.backend_name(),
+        "per_rank_iterations_per_s": [round(v, 3) for v in per_rank],
         "model_flops_per_step": work["flops"],
         "whole_step": {"tflops": round(work["flops"] / (ms * 1e-3) / 1e12, 2),
                        "frac_fp32_mfma_peak": round(work["flops"] / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
@@ -293,6 +403,9 @@ def main():
                        "frac_hbm_peak": round((work["bytes_feval"] + (work["bytes_lbfgs"] if a.optimizer == "lbfgs" else 0)) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         "roofline": roofline,
     }
+    if world == 1 and not a.no_extra_sizes and S == 1024:
+        del opt  # frees the 2.5 GB history slab before the next job allocates its own
+        out["extra"] = {"other_sizes": [steady_rate(512, max(a.steps, 100), a.optimizer, a.history)]}
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(S, a.optimizer)
     print(json.dumps(out), flush=True)

@@ -193,15 +193,17 @@ int maua_adam_step(float* x, const float* grad, float* exp_avg, float* exp_avg_s
 /* Device-resident state: `state` is an opaque caller-allocated buffer of maua_lbfgs_state_bytes(count, history)
  * bytes holding the (s, y) history slab [2*history][count], the previous gradient, the direction, the Gram matrix of
  * the history and all scalars.  maua_lbfgs_init zeroes the bookkeeping (not the slab).
- * maua_lbfgs_iterate consumes the gradient of the current x and moves x, replicating one trip of the loop in
- * LBFGS.step without line search: first call d = -g, t = min(1, 1/|g|_1) * lr; later calls push the curvature pair when
- * y.s > 1e-10, run the two-loop recursion (evaluated in the coefficient space of the stored vectors), t = lr; stop
- * (x left untouched, status flag raised) when g.d > -tolerance_change.  No host synchronisation.
+ * maua_lbfgs_iterate consumes the gradient (and, optionally, the loss value: a device scalar, NULL to skip the loss test)
+ * of the current x and moves x, replicating one trip of the loop in LBFGS.step without line search: first call d = -g,
+ * t = min(1, 1/|g|_1) * lr; later calls push the curvature pair when y.s > 1e-10, run the two-loop recursion (evaluated
+ * in the coefficient space of the stored vectors), t = lr.  The stop tests of lbfgs.py are all evaluated on the device
+ * (x left untouched, status flag raised): max|g| <= tolerance_grad, g.d > -tolerance_change, max|t d| <= tolerance_change
+ * of the previous move, |loss - previous loss| < tolerance_change.  history <= 254.  No host synchronisation.
  * maua_lbfgs_status copies {n_iter, history_len, stopped, last g.d, last t} (5 floats) to a device buffer. */
 size_t maua_lbfgs_state_bytes(int64_t count, int history);
 int maua_lbfgs_init(void* state, size_t state_bytes, int64_t count, int history, maua_stream_t stream);
-int maua_lbfgs_iterate(void* state, float* x, const float* grad, int64_t count, int history, float lr,
-                       float tolerance_change, maua_stream_t stream);
+int maua_lbfgs_iterate(void* state, float* x, const float* grad, const float* loss, int64_t count, int history, float lr,
+                       float tolerance_change, float tolerance_grad, maua_stream_t stream);
 int maua_lbfgs_status(const void* state, int64_t count, int history, float* out5, maua_stream_t stream);
 
 #ifdef __cplusplus

@@ -26,7 +26,11 @@ struct LbfgsHeader {
     float t;        // step length of the LAST move (s = t*d)
     float gtd;
     double h_diag;
-    double reserved[4];
+    float prev_loss;      // loss handed to the previous call (lbfgs.py: prev_loss)
+    unsigned gmax_bits;   // max |g| of the gradient handed to this call (bit pattern of a non-negative float: orders like an integer)
+    unsigned dmax_bits;   // max |t d| of the last move
+    int pad1;
+    double reserved[2];
 };
 
 constexpr int LB_EPT = 16;            // elements per thread in the sweeps
@@ -80,6 +84,9 @@ __global__ void lbfgs_init_kernel(LbfgsHeader* h, double* M, int nb_ids, float* 
             h->t = 0.f;
             h->gtd = 0.f;
             h->h_diag = 1.0;
+            h->prev_loss = 0.f;
+            h->gmax_bits = 0u;
+            h->dmax_bits = 0u;
         }
     }
 }
@@ -118,7 +125,7 @@ lbfgs_pair_kernel(const LbfgsHeader* __restrict__ hdr, const float* __restrict__
 // with (s_new, y_new, g) and, for id == g only, sum|g| in the 4th slot.  The candidate pair is read back like any
 // stored pair, so the loop body is uniform: 2*LB_EPT coalesced loads, 6*LB_EPT FMAs, six 64-lane reductions.
 __global__ void __launch_bounds__(256)
-lbfgs_pair_dots_kernel(const LbfgsHeader* __restrict__ hdr, const float* __restrict__ g, const float* __restrict__ S,
+lbfgs_pair_dots_kernel(LbfgsHeader* __restrict__ hdr, const float* __restrict__ g, const float* __restrict__ S,
                        const float* __restrict__ Y, float* __restrict__ partial, int64_t n, int m1) {
     extern __shared__ float lds[];  // [4 waves][nb_ids][4]
     const int nb_ids = 2 * m1 + 1;
@@ -171,17 +178,22 @@ lbfgs_pair_dots_kernel(const LbfgsHeader* __restrict__ hdr, const float* __restr
         wave_reduce3_store(b0, b1, b2, mine + 4 * (m1 + p), lane);
     }
     {
-        float sg = 0.f, yg = 0.f, gg = 0.f, g1 = 0.f;
+        float sg = 0.f, yg = 0.f, gg = 0.f, g1 = 0.f, gm = 0.f;
 #pragma unroll
         for (int k = 0; k < LB_EPT; ++k) {
             sg = fmaf(sv[k], gv[k], sg);
             yg = fmaf(yv[k], gv[k], yg);
             gg = fmaf(gv[k], gv[k], gg);
             g1 += fabsf(gv[k]);
+            gm = fmaxf(gm, fabsf(gv[k]));
         }
         wave_reduce3_store(sg, yg, gg, mine + 4 * (2 * m1), lane);
         g1 = wave_sum(g1);
-        if (lane == 0) mine[4 * (2 * m1) + 3] = g1;
+        gm = wave_max_nonneg(gm);
+        if (lane == 0) {
+            mine[4 * (2 * m1) + 3] = g1;
+            atomicMax(&hdr->gmax_bits, __float_as_uint(gm));  // a maximum does not depend on the order: deterministic
+        }
     }
     __syncthreads();
     float* out = partial + (size_t)blockIdx.x * nb_ids * 4;
@@ -232,7 +244,8 @@ __device__ inline double wave_total_f64(double v) {
 template <int NQ>
 __global__ void __launch_bounds__(64)
 lbfgs_coeffs_kernel(LbfgsHeader* __restrict__ hdr, const double* __restrict__ dots, double* __restrict__ M,
-                    float* __restrict__ coef, int m1, int history, float lr, float tol_change) {
+                    float* __restrict__ coef, int m1, int history, float lr, float tol_change, float tol_grad,
+                    const float* __restrict__ loss) {
     extern __shared__ double sh[];  // alpha[m1 + 1], rinv[m1 + 1]  (slot m1: sink / zero for the padding steps)
     const int nb_ids = 2 * m1 + 1, gid = 2 * m1;
     double* alpha = sh;
@@ -242,6 +255,26 @@ lbfgs_coeffs_kernel(LbfgsHeader* __restrict__ hdr, const double* __restrict__ do
     const bool first = hdr->n_iter == 0;
     double h_diag = hdr->h_diag;
     if (hdr->stopped) return;
+    {
+        // Stop tests of LBFGS.step that look at the new evaluation (lbfgs.py: `opt_cond` before the first direction and after
+        // every re-evaluation, `d.mul(t).abs().max() <= tolerance_change`, `abs(loss - prev_loss) < tolerance_change`).
+        // All of them end the step() call, i.e. x stays where the last move left it.
+        const float gmax = __uint_as_float(hdr->gmax_bits), dmax = __uint_as_float(hdr->dmax_bits);
+        const float cur = loss ? loss[0] : 0.f;
+        bool stop = gmax <= tol_grad;
+        if (!first) {
+            stop = stop || dmax <= tol_change;
+            if (loss) stop = stop || fabs((double)cur - (double)hdr->prev_loss) < (double)tol_change;
+        }
+        __syncthreads();  // every lane has read the header before lane 0 rewrites it
+        if (lane == 0) {
+            hdr->gmax_bits = 0u;
+            hdr->dmax_bits = 0u;
+            hdr->prev_loss = cur;
+            if (stop) hdr->stopped = 1;
+        }
+        if (stop) return;
+    }
 
     // 1. curvature test and ring update (lbfgs.py: `if ys > 1e-10`)
     const double ys = dots[(m1 + cand) * 4 + 0];  // y_new . s_new
@@ -350,7 +383,7 @@ lbfgs_coeffs_kernel(LbfgsHeader* __restrict__ hdr, const double* __restrict__ do
 __global__ void __launch_bounds__(256)
 lbfgs_combine_kernel(const LbfgsHeader* __restrict__ hdr, const float* __restrict__ coef, const float* __restrict__ g,
                      const float* __restrict__ S, const float* __restrict__ Y, float* __restrict__ d, float* __restrict__ x,
-                     int64_t n, int m1) {
+                     int64_t n, int m1, unsigned* __restrict__ dmax_bits) {
     const int len = hdr->len, head = hdr->head, stopped = hdr->stopped;
     const float t = hdr->t;
     const int64_t blk = (int64_t)blockIdx.x * LB_WG;
@@ -379,14 +412,18 @@ lbfgs_combine_kernel(const LbfgsHeader* __restrict__ hdr, const float* __restric
     }
     float* dB = d + blk;
     float* xB = x + blk;
+    float dm = 0.f;
 #pragma unroll
     for (int k = 0; k < LB_EPT; ++k) {
         const int e = tid + 256 * k;
         if (e < rem) {
             dB[e] = acc[k];
+            dm = fmaxf(dm, fabsf(acc[k] * t));             // d.mul(t).abs().max()
             if (!stopped) xB[e] = fmaf(t, acc[k], xB[e]);  // p.add_(d, alpha=t)
         }
     }
+    dm = wave_max_nonneg(dm);
+    if ((tid & 63) == 0 && !stopped) atomicMax(dmax_bits, __float_as_uint(dm));
 }
 
 __global__ void lbfgs_status_kernel(const LbfgsHeader* __restrict__ hdr, float* __restrict__ out) {
@@ -412,6 +449,7 @@ size_t maua_lbfgs_state_bytes(int64_t count, int history) {
 
 int maua_lbfgs_init(void* state, size_t state_bytes, int64_t count, int history, maua_stream_t stream) {
     MAUA_REQUIRE(state && count > 0 && history > 0, MAUA_E_INVAL, "lbfgs_init: bad args");
+    MAUA_REQUIRE(2 * (history + 1) + 1 <= 512, MAUA_E_UNSUPPORTED, "lbfgs_init: history %d too large (at most 254)", history);
     const LbfgsLayout L = lbfgs_layout(count, history);
     MAUA_REQUIRE(state_bytes >= L.total, MAUA_E_WORKSPACE, "lbfgs_init: state %zu < %zu bytes", state_bytes, L.total);
     char* b = (char*)state;
@@ -420,8 +458,8 @@ int maua_lbfgs_init(void* state, size_t state_bytes, int64_t count, int history,
     return check_launch("lbfgs_init_kernel");
 }
 
-int maua_lbfgs_iterate(void* state, float* x, const float* grad, int64_t count, int history, float lr,
-                       float tolerance_change, maua_stream_t stream) {
+int maua_lbfgs_iterate(void* state, float* x, const float* grad, const float* loss, int64_t count, int history, float lr,
+                       float tolerance_change, float tolerance_grad, maua_stream_t stream) {
     MAUA_REQUIRE(state && x && grad && count > 0 && history > 0, MAUA_E_INVAL, "lbfgs_iterate: bad args");
     const LbfgsLayout L = lbfgs_layout(count, history);
     char* b = (char*)state;
@@ -436,7 +474,8 @@ int maua_lbfgs_iterate(void* state, float* x, const float* grad, int64_t count, 
     float* Y = (float*)(b + L.off_Y);
     hipStream_t s = (hipStream_t)stream;
     const size_t lds1 = sizeof(float) * 4 * L.nb_ids * 4;
-    MAUA_REQUIRE(lds1 <= 64 * 1024, MAUA_E_UNSUPPORTED, "lbfgs_iterate: history %d too large", history);
+    // lbfgs_coeffs_kernel<8> keeps the 2*history+3 coefficients in 8 registers x 64 lanes
+    MAUA_REQUIRE(lds1 <= 64 * 1024 && L.nb_ids <= 512, MAUA_E_UNSUPPORTED, "lbfgs_iterate: history %d too large (at most 254)", history);
     int pg = (int)((count + 1023) / 1024);
     if (pg > 2048) pg = 2048;
     hipLaunchKernelGGL(lbfgs_pair_kernel, dim3(pg), dim3(256), 0, s, hdr, grad, g_prev, d, S, Y, count);
@@ -451,13 +490,14 @@ int maua_lbfgs_iterate(void* state, float* x, const float* grad, int64_t count, 
     const size_t lds3 = sizeof(double) * 2 * (L.m1 + 1);
     if (L.nb_ids <= 256)
         hipLaunchKernelGGL(lbfgs_coeffs_kernel<4>, dim3(1), dim3(64), lds3, s, hdr, dots, M, coef, L.m1, history, lr,
-                           tolerance_change);
+                           tolerance_change, tolerance_grad, loss);
     else
         hipLaunchKernelGGL(lbfgs_coeffs_kernel<8>, dim3(1), dim3(64), lds3, s, hdr, dots, M, coef, L.m1, history, lr,
-                           tolerance_change);
+                           tolerance_change, tolerance_grad, loss);
     rc = check_launch("lbfgs_coeffs_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(lbfgs_combine_kernel, dim3(L.nwg), dim3(256), 0, s, hdr, coef, grad, S, Y, d, x, count, L.m1);
+    hipLaunchKernelGGL(lbfgs_combine_kernel, dim3(L.nwg), dim3(256), 0, s, hdr, coef, grad, S, Y, d, x, count, L.m1,
+                       &hdr->dmax_bits);
     return check_launch("lbfgs_combine_kernel");
 }
 

@@ -340,7 +340,7 @@ using namespace maua;
 
 extern "C" {
 
-int maua_abi_version(void) { return 1; }
+int maua_abi_version(void) { return 2; }
 const char* maua_last_error(void) { return maua::g_err; }
 
 int maua_conv_pack_filters(const float* w, float* wf, float* wb, int cout, int cin, int kh, int kw, maua_stream_t stream) {

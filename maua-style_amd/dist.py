@@ -30,7 +30,11 @@ def init(backend=None):
         elif torch.cuda.is_available():
             torch.cuda.set_device(local_rank % torch.cuda.device_count())
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group(backend=backend, rank=rank, world_size=world)
+        # Ranks meet only at start-up (one broadcast) and at the very end of a job that can run for hours with uneven
+        # shards: the default 10-minute collective timeout would abort the waiting ranks.  MAUA_DIST_TIMEOUT_S overrides.
+        import datetime
+        timeout = datetime.timedelta(seconds=float(os.environ.get("MAUA_DIST_TIMEOUT_S", 7 * 24 * 3600)))
+        td.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank if local_rank < torch.cuda.device_count() else 0)
     return rank, local_rank, world
@@ -112,6 +116,26 @@ def max_over_ranks(value):
     t = torch.tensor([value], dtype=torch.float64, device=_coll_device())
     td.all_reduce(t, op=td.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_floats(value):
+    """python float of every rank, in rank order, on every rank."""
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=_coll_device())
+    out = [torch.zeros_like(t) for _ in range(td.get_world_size())]
+    td.all_gather(out, t)
+    return [float(v.item()) for v in out]
+
+
+def group_size():
+    """Number of ranks the communicator itself reports (1 outside a process group)."""
+    return td.get_world_size() if (td.is_available() and td.is_initialized()) else 1
+
+
+def backend_name():
+    """"nccl" (= RCCL on ROCm), "gloo", or "none" for a single process."""
+    return str(td.get_backend()) if (td.is_available() and td.is_initialized()) else "none"
 
 
 def gather_frames(local, n_items):

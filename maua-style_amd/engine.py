@@ -51,7 +51,7 @@ class StyleEngine:
         self.slot_of = {id(m): i for i, m in enumerate(self.losses)}
         self.steps = self._plan(list(net))
         self.shape = None
-        self.graph = None
+        self.graph, self.graph_key = None, None
         # 3x3 stride-1 convs run on the bf16 matrix cores with a 3-way operand split (fp32 accuracy, conv_x6.hip) unless
         # MAUA_CONV_X6=0 asks for the fp32-MFMA kernels (A/B comparisons)
         mode = os.environ.get("MAUA_CONV_X6", "1")  # "1" both passes, "fwd" / "bwd" one of them, "0" off
@@ -457,6 +457,24 @@ class StyleEngine:
         for s in want:
             s.mod.target = a[s.src].detach().clone()
 
+    def _graph_key(self):
+        """Everything a captured evaluation bakes in besides the image: the addresses and shapes of every target / weight
+        tensor, the Python-side decisions of `_active` and the loss coefficients.  A graph is replayed only while this is
+        unchanged (the same network is reused by vid_img per frame and by img_vid per window, each call installing new
+        targets); a tensor rewritten IN PLACE keeps its address, so the graph stays valid and reads the new values."""
+        def sig(t):
+            return None if t is None or not torch.is_tensor(t) else (t.data_ptr(), tuple(t.shape))
+        key = []
+        for s in self.steps:
+            m = s.mod
+            if s.kind in ("tv", "content", "style"):
+                key.append((s.kind, id(m), getattr(m, "mode", None), float(m.strength), bool(getattr(m, "normalize", False)),
+                            sig(getattr(m, "target", None)), sig(getattr(m, "video_target", None)), sig(getattr(m, "weights", None)),
+                            float(getattr(m, "video_style_factor", 0.0)), bool(getattr(m, "use_covariance", False))))
+            elif s.kind == "conv":
+                key.append((id(m), m.weight.data_ptr(), m.weight._version))
+        return tuple(key)
+
     def feval(self, x, capture=False):
         """Evaluate at `x` (B,3,H,W fp32 on the GPU; B > 1 = a window of frames with per-frame and cross-frame style terms).  Returns (per-module loss slots in `losses` order, total
         loss, gradient) - device tensors owned by the engine, overwritten by the next call; no host sync."""
@@ -464,7 +482,9 @@ class StyleEngine:
         if not capture:
             self._run(x)
             return self.slots, self.total, self.gbuf[0]
-        if self.graph is None:
+        key = self._graph_key()
+        if self.graph is None or self.graph_key != key:
+            self.graph, self.graph_key = None, key
             self.x_static.copy_(x)
             self._run(self.x_static)  # warm-up outside capture (filter banks, lazy init)
             torch.cuda.synchronize()

@@ -59,7 +59,7 @@ SIGNATURES = {
     "maua_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_f, c_f, c_f, c_f, c_p]),
     "maua_lbfgs_state_bytes": (c_sz, [c_i64, c_i]),
     "maua_lbfgs_init": (c_i, [c_p, c_sz, c_i64, c_i, c_p]),
-    "maua_lbfgs_iterate": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_f, c_f, c_p]),
+    "maua_lbfgs_iterate": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_f, c_f, c_f, c_p]),
     "maua_lbfgs_status": (c_i, [c_p, c_i64, c_i, c_p, c_p]),
 }
 
@@ -428,14 +428,18 @@ class LbfgsState:
 
     def __init__(self, count, history, device):
         self.count, self.history = int(count), int(history)
+        if not 0 < self.history <= 254:
+            raise HipError(f"--lbfgs_num_correction {history}: the device-side recursion holds at most 254 pairs")
         nbytes = lib().maua_lbfgs_state_bytes(self.count, self.history)
         self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
         self._status = torch.zeros(5, dtype=torch.float32, device=device)
         _check(lib().maua_lbfgs_init(self.buf.data_ptr(), nbytes, self.count, self.history, _stream()), "maua_lbfgs_init")
 
-    def iterate(self, x, grad, lr=1.0, tolerance_change=-1.0):
-        _check(lib().maua_lbfgs_iterate(self.buf.data_ptr(), _ptr(x), _ptr(grad), self.count, self.history, float(lr),
-                                        float(tolerance_change), _stream()), "maua_lbfgs_iterate")
+    def iterate(self, x, grad, lr=1.0, tolerance_change=-1.0, tolerance_grad=-1.0, loss=None):
+        """One trip of LBFGS.step's loop; `loss` (device scalar of the evaluation that produced `grad`) feeds the
+        |loss - prev_loss| < tolerance_change test and may be None."""
+        _check(lib().maua_lbfgs_iterate(self.buf.data_ptr(), _ptr(x), _ptr(grad), _ptr(loss), self.count, self.history, float(lr),
+                                        float(tolerance_change), float(tolerance_grad), _stream()), "maua_lbfgs_iterate")
 
     def status(self):
         """Host copy of {n_iter, history_len, stopped, g.d, t} - this one synchronises."""

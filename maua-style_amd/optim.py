@@ -40,10 +40,13 @@ def _engine_of(net):
     """The fused engine of a loss network (built once per network; None when its module layout is not covered)."""
     eng = getattr(net, "_maua_engine", None)
     if eng is None and not getattr(net, "_maua_engine_refused", False):
+        if not all(hasattr(net, a) for a in ("content_losses", "style_losses", "tv_losses", "temporal_losses")):
+            net._maua_engine_refused = True  # not assembled by models.load_model: module path
+            return None
         try:
             eng = engine_mod.StyleEngine(net, net.content_losses + net.style_losses + net.tv_losses + net.temporal_losses)
             net._maua_engine = eng
-        except (engine_mod.UnsupportedNet, AttributeError):
+        except engine_mod.UnsupportedNet:  # nothing else: a bug inside the engine must not silently demote the run
             net._maua_engine_refused = True
     return eng
 
@@ -219,7 +222,7 @@ class PixelOptimizer:
         slots, total, grad = self.engine.feval(self.x)
         if self.grad_hook is not None:
             self.grad_hook(grad)
-        self.state.iterate(self.x, grad, 1.0, float(a.lbfgs_tolerance_change))
+        self.state.iterate(self.x, grad, 1.0, float(a.lbfgs_tolerance_change), float(a.lbfgs_tolerance_grad), total)
         self.step_count += 1
         th.cuda.synchronize()
         graph = th.cuda.CUDAGraph()
@@ -227,7 +230,8 @@ class PixelOptimizer:
             self.engine._run(self.x)
             if self.grad_hook is not None:
                 self.grad_hook(self.engine.gbuf[0])
-            self.state.iterate(self.x, self.engine.gbuf[0], 1.0, float(a.lbfgs_tolerance_change))
+            self.state.iterate(self.x, self.engine.gbuf[0], 1.0, float(a.lbfgs_tolerance_change), float(a.lbfgs_tolerance_grad),
+                               self.engine.total)
         self._graph = graph
         return slots, total
 
@@ -244,7 +248,8 @@ class PixelOptimizer:
         self.step_count += 1
         a = self.args
         if self.kind == "lbfgs":
-            self.state.iterate(self.x, grad, 1.0, float(a.lbfgs_tolerance_change))
+            self.state.iterate(self.x, grad, 1.0, float(a.lbfgs_tolerance_change), float(a.lbfgs_tolerance_grad),
+                               total if th.is_tensor(total) and total.is_cuda else None)
         else:
             hip.adam_step(self.x, grad, self.m, self.v, self.step_count, float(a.learning_rate))
         return slots, total
@@ -259,15 +264,16 @@ def _run_iterations(opt, num_iters, args, save_offset=0, save_total=None):
         _describe("Running optimization with ADAM", args)
         steps = num_iters + 1  # `while i[0] <= iters` with i starting at 0 (optim.py:240)
     for i in range(1, steps + 1):
+        if args.save_iter > 0 and (i % args.save_iter == 0 or i == num_iters):
+            # the reference saves inside evaluation i (optim.py:230-236): the image BEFORE the move of iteration i
+            import load
+            last = save_offset + i == (save_total if save_total is not None else num_iters)
+            load.save_tensor_to_file(opt.x.detach().cpu(), args, None if last else save_offset + i, opt.x.size(3))
         slots, total = opt.step()
         if not args.verbose and not (args.optimizer == "adam" and i == 1):
             PBAR.update(1)
         if args.print_iter > 0 and i % args.print_iter == 0 and args.verbose:
             print(f"Iteration {i} / {args.num_iters}, Loss: {float(total)}")
-        if args.save_iter > 0 and (i % args.save_iter == 0 or i == num_iters):
-            import load
-            last = save_offset + i == (save_total if save_total is not None else num_iters)
-            load.save_tensor_to_file(opt.x.detach().cpu(), args, None if last else save_offset + i, opt.x.size(3))
         if args.optimizer == "lbfgs" and i % 25 == 0 and opt.state.status()["stopped"]:
             break  # g.d > -tolerance_change: the reference breaks out of LBFGS.step here
 

@@ -42,7 +42,19 @@ def _scaled_styles(style_images_big, content_area, args):
     return out
 
 
+def _single_rank_only(what):
+    """img_img / img_vid optimise ONE image / clip (replicas only): under a multi-rank launch rank 0
+    does the job and the others leave, instead of every rank redoing it on GPU 0 and racing on the output files."""
+    rank, _, world = dist.env_rank()
+    if world > 1 and rank != 0:
+        print(f"{what}: one job, rank {rank} of {world} has nothing to do")
+        return False
+    return True
+
+
 def img_img(args):
+    if not _single_rank_only("img_img"):
+        return None
     limit_host_threads()
     style_images_big = load.process_style_images(args)
     content_image_big = match_histogram(load.preprocess(args.content), style_images_big, mode=args.match_histograms)
@@ -84,6 +96,8 @@ def img_vid(args):
     of frame images on both sides (no codecs in this build): style clips are read with load.preprocess_video, each
     scale's result goes to <output>_<size>/frame_#####.png and the final clip to <output>/."""
     import scipy.ndimage as ndi
+    if not _single_rank_only("img_vid"):
+        return None
     limit_host_threads()
     style_videos_big = load.process_style_videos(args)
     content_image_big = match_histogram(load.preprocess(args.content), style_videos_big, mode=args.match_histograms)
@@ -234,10 +248,11 @@ def vid_img(args):
     output_dir = args.output_dir + "/" + name(args.content) + "_" + "_".join([name(s) for s in args.style])
     frames = load.process_content_frames(args.content)
     if args.temporal_weight > 0 and glob.glob(output_dir + "/flow/*.flo"):
+        # sequential job (every frame starts from its predecessor): rank 0 runs it, the other ranks of a torchrun launch
+        # leave at once - no collective here, a barrier would time out (and hold the GPUs) while rank 0 works for hours
         if rank == 0:
             _vid_img_flow(args, output_dir, frames, load.process_style_images(args),
                           np.array(load.preprocess(frames[0]).size()[-2:]))
-        dist.barrier()
         return
     lo, hi = dist.shard_range(len(frames), rank, world)
     mine = frames[lo:hi]

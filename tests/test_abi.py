@@ -38,7 +38,7 @@ def test_binding_table_matches_header(libpath):
     import hip
     assert sorted(hip.SIGNATURES) == declared_symbols()
     L = hip.lib()  # dlopen + argtypes for every symbol; no compute call
-    assert L.maua_abi_version() == 1
+    assert L.maua_abi_version() == 2
 
 
 def test_host_only_entry_points(libpath):

@@ -265,6 +265,29 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     assert "x2" in d["config"]["parallelism"]
 
 
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` WITHOUT torchrun (the form the driver's scaling run uses): the parent starts two rank
+    processes itself, never touches the GPU, and relays rank 0's line; the communicator's own size is reported."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["MAUA_DIST_BACKEND"] = "gloo"  # two ranks on this box's single GPU
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--size", "128", "--steps", "4",
+                          "--warmup", "1", "--history", "5"], capture_output=True, text=True, env=env, timeout=900,
+                         cwd=str(tmp_path))
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["dist_backend"] == "gloo"
+    assert len(d["per_rank_iterations_per_s"]) == 2 and all(v > 0 for v in d["per_rank_iterations_per_s"])
+    assert d["value"] <= sum(d["per_rank_iterations_per_s"]) * 1.001  # whole job = 2 K / slowest rank's time
+    # without the gloo override a 1-GPU box cannot host two RCCL ranks: refused, non-zero
+    env.pop("MAUA_DIST_BACKEND")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--size", "128", "--steps", "2"],
+                         capture_output=True, text=True, env=env, timeout=300, cwd=str(tmp_path))
+    if torch.cuda.device_count() < 2:
+        assert out.returncode != 0 and "device(s) visible" in out.stderr
+
+
 def test_vid_img_sharded_over_two_ranks_matches_one_rank(tmp_path, weight_files):
     """Frame sharding of the flow-less vid_img over two ranks (sharing this box's GPU over gloo): the same files, bit for
     bit, as the single-process run - frames are independent problems and rank 0's weights are broadcast."""

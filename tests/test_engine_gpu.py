@@ -165,11 +165,32 @@ def test_whole_iteration_graph_equals_eager(weight_files, opt, monkeypatch):
     import optim
     content, style, init = synth.images(64)
     outs = []
-    for flag in ("1", "0"):
-        monkeypatch.setenv("MAUA_HIP_GRAPH", flag)
+    for flag in (True, False):
         args = product_args(weight_files, optimizer=opt, S=64, N=12)
+        args.hip_graph = flag  # runs this short would launch eagerly by default (optim.GRAPH_MIN_ITERS)
         outs.append(optim.optimize(content, [style], init.clone(), 12, args))
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("opt", ["lbfgs", "adam"])
+def test_graph_is_recaptured_when_a_reused_network_gets_new_targets(weight_files, opt):
+    """vid_img calls optimize once per frame with the SAME prebuilt network: every call installs new content targets (and the
+    temporal path new weights / active modules).  A captured graph bakes in the old tensors' addresses, so each call must
+    replay a graph of ITS OWN targets: frame 2 through the graph path equals frame 2 launched eagerly, bit for bit."""
+    import models
+    import optim
+    frames = [synth.images(64, seed=30 + k)[0] for k in range(3)]
+    style = synth.images(64)[1]
+    outs = {}
+    for flag in (True, False):
+        args = product_args(weight_files, optimizer=opt, S=64, N=6)
+        args.hip_graph = flag
+        optim.set_model_args(args, 64)
+        net, losses = models.load_model(args)
+        outs[flag] = [optim.optimize(f, [style], f.clone(), 6, args, net, losses) for f in frames]
+    for a, b in zip(outs[True], outs[False]):
+        assert torch.equal(a, b)
+    assert not torch.equal(outs[True][1], outs[True][2])
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -127,3 +127,205 @@ def test_full_size_lbfgs_descends(setup):
     st = opt.state.status()
     assert math.isfinite(after) and after < 0.99 * before, (before, after)  # no line search, first step 1/|g|_1: slow start
     assert st["n_iter"] == 15 and st["history_len"] >= 10 and not st["stopped"]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# fp16x3 against fp64 at the benchmarked size: real activations / gradients of the 1024x1024 network, output crops
+# ---------------------------------------------------------------------------------------------------------
+def _crop_reference(x_gpu, w, bias, y0, x0, size, pad, dtype):
+    """Output crop [y0:y0+size, x0:x0+size] (all channels) of conv3x3(x, w, pad) computed on the CPU in `dtype` from the
+    input window it depends on (zero padding where the window leaves the image)."""
+    import torch.nn.functional as F
+    _, c, h, w_in = x_gpu.shape
+    ys, xs = y0 - pad, x0 - pad
+    win = torch.zeros(1, c, size + 2, size + 2, dtype=dtype)
+    sy0, sx0 = max(ys, 0), max(xs, 0)
+    sy1, sx1 = min(ys + size + 2, h), min(xs + size + 2, w_in)
+    win[:, :, sy0 - ys:sy1 - ys, sx0 - xs:sx1 - xs] = x_gpu[:, :, sy0:sy1, sx0:sx1].cpu().to(dtype)
+    return F.conv2d(win, w.cpu().to(dtype), None if bias is None else bias.cpu().to(dtype))
+
+
+@pytest.mark.parametrize("layer", ["conv1_2", "conv3_2", "conv4_2"])
+@pytest.mark.parametrize("direction", ["fwd", "bwd"])
+def test_full_size_fp16x3_conv_is_as_close_to_fp64_as_fp32_cpu(setup, layer, direction):
+    """The split-precision claim at the size that is benchmarked: conv_x3 on the REAL inputs of three layers of the
+    1024x1024 network (post-ReLU activations after 1 / 6 / 10 layers with their true dynamic range; for backward-data the
+    real incoming gradients), K up to 4608, compared on 64x64 output crops (image corner incl. padding, and interior) with
+    F.conv2d in fp64.  Bar: not worse than 1.5x the error of the reference's own arithmetic (fp32 conv on the CPU)."""
+    import hip
+    _, _, _, eng, x = setup
+    eng.feval(x)
+    torch.cuda.synchronize()
+    want = {"conv1_2": (64, 64, 1024), "conv3_2": (256, 256, 256), "conv4_2": (512, 512, 128)}[layer]
+    step = next(s for s in eng.steps if s.kind == "conv" and (s.mod.in_channels, s.mod.out_channels) == want[:2]
+                and eng.act[s.src].shape[2] == want[2])
+    mod = step.mod
+    bf, bb, wsc = mod.banks3()
+    if direction == "fwd":
+        inp = eng.act[step.src].clone()
+        got = hip.conv3x3_x3(inp, bf, wsc, mod.bias_device(), mod.out_channels, 1, False)
+        w_eff, bias = mod.weight.detach(), mod.bias_device()
+    else:
+        inp = eng.gbuf[step.dst].clone()  # d loss / d (conv output), already ReLU-masked by its producer
+        got = hip.conv3x3_x3(inp, bb, wsc, None, mod.in_channels, 1, False)
+        w_eff, bias = mod.weight.detach().flip(2, 3).transpose(0, 1).contiguous(), None  # backward-data as a correlation
+    torch.cuda.synchronize()
+    assert float(inp.abs().max()) > 0
+    side = inp.shape[2]
+    for y0, x0 in ((0, 0), (side // 2 - 32, side // 2 - 16), (side - 64, side - 64)):
+        r64 = _crop_reference(inp, w_eff, bias, y0, x0, 64, 1, torch.float64)
+        r32 = _crop_reference(inp, w_eff, bias, y0, x0, 64, 1, torch.float32)
+        mine = got[:, :, y0:y0 + 64, x0:x0 + 64].cpu()
+        floor = rel_l2(r32, r64)
+        err = rel_l2(mine, r64)
+        assert err <= max(1.5 * floor, 1e-7), (layer, direction, (y0, x0), err, floor)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BASELINE config 2 (512x512 L-BFGS), config 3 (stock scaling table up to 2048x2048 Adam), config 5 (NIN + covariance 1024)
+# ---------------------------------------------------------------------------------------------------------
+def _engine_for(weight_files, S, extra=(), model="vgg19", optimizer="lbfgs"):
+    import engine
+    import models
+    import optim
+    args = product_args(weight_files, list(extra), model=model, optimizer=optimizer, S=S, N=10)
+    content, style, init = synth.images(S)
+    optim.set_model_args(args, S)
+    net, losses = models.load_model(args)
+    optim.set_content_targets(net, content, args)
+    optim.set_style_targets(net, [style], args)
+    for m in losses:
+        m.mode = "loss"
+    return args, net, losses, engine.StyleEngine(net, losses), init.cuda()
+
+
+def _check_determinism_and_slope(eng, x, eps, tol):
+    s0, t0, g0 = eng.feval(x)
+    s0, t0, g0 = s0.clone(), t0.clone(), g0.clone()
+    s1, t1, g1 = eng.feval(x)
+    torch.cuda.synchronize()
+    assert torch.equal(g0, g1) and torch.equal(s0, s1) and torch.equal(t0, t1)
+    assert torch.isfinite(g0).all() and float(t0) > 0 and float(g0.abs().max()) > 0
+    v = g0 / g0.norm()
+    slope = float((g0.double() * v.double()).sum())
+    lp = float(eng.feval(x + eps * v)[1])
+    lm = float(eng.feval(x - eps * v)[1])
+    fd = (lp - lm) / (2 * eps)
+    assert abs(fd - slope) <= tol * abs(slope), (fd, slope)
+
+
+def test_config2_512_lbfgs_graph_equals_eager_and_descends(weight_files):
+    """512x512 VGG-19 L-BFGS (BASELINE config 2's shape): deterministic evaluation, gradient = directional derivative, the
+    graph-replayed iteration loop equals the eagerly launched one bit for bit, and 40 iterations descend."""
+    import optim
+    args, net, losses, eng, x = _engine_for(weight_files, 512, ["--no_grad_norm"])
+    _check_determinism_and_slope(eng, x, 0.5, 2e-2)
+    before = float(eng.feval(x)[1])
+    outs = []
+    for flag in (True, False):
+        args.hip_graph = flag
+        opt = optim.PixelOptimizer(net, losses, x.cpu(), args)
+        for _ in range(40):
+            opt.step()
+        torch.cuda.synchronize()
+        outs.append(opt.x.clone())
+    assert torch.equal(outs[0], outs[1])
+    after = float(eng.feval(outs[0])[1])
+    assert math.isfinite(after) and after < 0.9 * before, (before, after)
+
+
+def test_config5_nin_covariance_1024(weight_files):
+    """NIN + --use_covariance at 1024x1024 (BASELINE config 5): the odd-sized maps (254 / 127 / 63 / 31), the strided stem,
+    the 5x5 and split 1x1 kernels and the ceil-mode pools at their real grids - determinism, directional derivative,
+    L-BFGS descent and graph == eager."""
+    import optim
+    from conftest import NIN_FLAGS
+    args, net, losses, eng, x = _engine_for(weight_files, 1024, NIN_FLAGS + ["--use_covariance", "--no_grad_norm"], model="nin")
+    _check_determinism_and_slope(eng, x, 0.5, 3e-2)
+    assert [tuple(eng.act[s.dst].shape[1:]) for s in eng.steps if s.kind == "conv"][:1] == [(96, 254, 254)]
+    before = float(eng.feval(x)[1])
+    outs = []
+    for flag in (True, False):
+        args.hip_graph = flag
+        opt = optim.PixelOptimizer(net, losses, x.cpu(), args)
+        for _ in range(25):
+            opt.step()
+        torch.cuda.synchronize()
+        outs.append(opt.x.clone())
+        st = opt.state.status()
+        assert st["n_iter"] == 25 and not st["stopped"]
+    assert torch.equal(outs[0], outs[1])
+    after = float(eng.feval(outs[0])[1])
+    assert math.isfinite(after) and after < 0.99 * before, (before, after)
+
+
+def test_config3_stock_scaling_table_256_to_2048(tmp_path, weight_files):
+    """BASELINE config 3 through style.img_img with the STOCK config/scaling-img.json (only its model_file entries point at
+    the synthetic checkpoint: no real weights exist offline): 256 -> 512 -> 1024 -> 2048 with histogram matching; the
+    table must pick L-BFGS up to 1456 px and Adam above (reference optim.py:93-108), whatever --optimizer says; every
+    scale writes its PNG; the 2048x2048 Adam stage descends."""
+    import json
+    import os
+    import numpy as np
+    from PIL import Image
+    import config
+    import optim
+    import style
+    from conftest import PKG, REPO
+    with open(os.path.join(PKG, "config", "scaling-img.json")) as f:
+        table = json.load(f)
+    assert [int(k) for k in table] == sorted(int(k) for k in table)
+    for entry in table.values():
+        entry["model_file"] = weight_files["vgg19"]
+    scaling = tmp_path / "scaling-img.json"
+    scaling.write_text(json.dumps(table))
+    out = tmp_path / "out"
+    out.mkdir()
+    args = config.get_args(["--content", os.path.join(REPO, "tests", "synth_content_256.png"), "--style",
+                            os.path.join(REPO, "tests", "synth_style_256.png"), "--model_file", weight_files["vgg19"],
+                            "--disable_check", "--scaling_args", str(scaling), "--image_sizes", "256,512,1024,2048",
+                            "--num_iters", "12,10,8,8", "--seed", "0", "--init", "content", "--optimizer", "lbfgs",
+                            "--output_dir", str(out)])
+    calls = []
+    orig = optim.optimize
+
+    def spy(content, styles, init, num_iters, a, *rest, **kw):
+        res = orig(content, styles, init, num_iters, a, *rest, **kw)
+        calls.append((int(init.shape[-1]), a.optimizer, num_iters))
+        return res
+
+    optim.optimize = spy
+    try:
+        torch.manual_seed(0)
+        result = style.img_img(args)
+    finally:
+        optim.optimize = orig
+    assert calls == [(256, "lbfgs", 12), (512, "lbfgs", 10), (1024, "lbfgs", 8), (2048, "adam", 8)], calls
+    assert tuple(result.shape) == (1, 3, 2048, 2048) and torch.isfinite(result).all()
+    for size in (256, 512, 1024, 2048):
+        png = out / f"synth_content_256_synth_style_256_{size}.png"
+        assert png.exists() and np.asarray(Image.open(png)).shape == (size, size, 3)
+    # the schedule itself, straight from the table
+    for size, want in ((256, "lbfgs"), (1024, "lbfgs"), (1456, "lbfgs"), (1457, "adam"), (2048, "adam"), (2448, "adam")):
+        a2 = config.get_args(["--content", "c.png", "--style", "s.png", "--scaling_args", str(scaling), "--optimizer",
+                              "adam" if want == "lbfgs" else "lbfgs"])
+        optim.set_model_args(a2, size)
+        assert a2.optimizer == want, (size, a2.optimizer)
+
+
+def test_config3_adam_2048_evaluation_and_descent(weight_files):
+    """2048x2048 VGG-19 with Adam (the top scale of config 3; 4.9 GB of activations): deterministic evaluation, gradient =
+    directional derivative, N + 1 Adam steps (the reference's `while i <= N`) through the graph path equal the eager ones
+    and descend."""
+    import optim
+    args, net, losses, eng, x = _engine_for(weight_files, 2048, ["--no_grad_norm"], optimizer="adam")
+    _check_determinism_and_slope(eng, x, 1.0, 2e-2)
+    before = float(eng.feval(x)[1])
+    content, style, init = synth.images(2048)
+    outs = []
+    for flag in (True, False):
+        args.hip_graph = flag
+        outs.append(optim.optimize(content, [style], init.clone(), 6, args, net, losses))
+    assert torch.equal(outs[0], outs[1])
+    after = float(eng.feval(outs[0].cuda())[1])
+    assert math.isfinite(after) and after < before, (before, after)

@@ -225,3 +225,16 @@ def test_video_windows_schedule_matches_reference_formula():
     init, video = torch.zeros(40, 1), torch.zeros(25, 1)
     w = optim.video_windows(init, [video], 18)
     assert w == [[0, 11, 21, 31], [0, 6, 11, 16]]
+
+
+def test_bench_refuses_more_ranks_than_devices(tmp_path):
+    """`bench.py --gpus N` starts N ranks itself; with fewer than N devices visible (none here) and no gloo override it
+    must fail loudly instead of silently measuring one GPU."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MAUA_DIST_BACKEND")}
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True,
+                         text=True, env=env, timeout=300, cwd=str(tmp_path))
+    if torch.cuda.device_count() < 2:
+        assert out.returncode == 2 and "device(s) visible" in out.stderr and not out.stdout.strip()

@@ -367,6 +367,48 @@ def test_lbfgs_stop_flag_and_first_step(hip):
     assert st.status()["stopped"] and torch.equal(x, before)
 
 
+@pytest.mark.parametrize("which", ["grad", "step", "loss"])
+def test_lbfgs_tolerances_stop_where_the_oracle_stops(hip, which):
+    """--lbfgs_tolerance_grad / --lbfgs_tolerance_change (reference optim.py:183-188 hands them to torch.optim.LBFGS): the
+    max|g|, max|t d| and |loss - prev_loss| tests run on the device and end the run at the oracle's move count."""
+    from oracle import lbfgs_run
+    n, iters = 2000, 60
+    fg = _toy_problem(n, seed=9)
+    x0 = (torch.randn(n, generator=torch.Generator().manual_seed(10), dtype=torch.float64) * (1.25 / n)).float().double()
+    # thresholds met part of the way through the unconstrained 60-iteration run of this problem
+    trace = []
+    lbfgs_run(fg, x0, iters, trace=trace)
+    xs = [x0] + trace
+    k = 12
+    if which == "grad":
+        tg, tc = float(fg(xs[k])[1].abs().max()) * 1.0001, -1.0
+    elif which == "step":
+        tg, tc = -1.0, float((xs[k] - xs[k - 1]).abs().max()) * 1.0001
+    else:
+        tg, tc = -1.0, abs(fg(xs[k])[0] - fg(xs[k - 1])[0]) * 1.0001
+    trace2, stats = [], {}
+    ref, _ = lbfgs_run(fg, x0, iters, tol_grad=tg, tol_change=tc, trace=trace2, stats=stats)
+    assert 3 <= len(trace2) < iters  # the oracle really stopped early
+    x = dev(x0.float())
+    st = hip.LbfgsState(n, 100, x.device)
+    moves = 0
+    for it in range(iters):
+        loss, g = fg(x)
+        st.iterate(x, g.contiguous(), 1.0, tc, tg, loss=torch.tensor([loss], dtype=torch.float32, device=x.device))
+        if st.status()["stopped"]:
+            break
+        moves += 1
+    assert abs(moves - len(trace2)) <= 1, (moves, len(trace2))  # a threshold 1e-4 off the boundary: fp32 may land either side
+    if moves == len(trace2):
+        assert float((x.cpu().double() - ref).norm() / x0.norm()) <= 1e-4
+
+
+def test_lbfgs_history_limit_is_refused(hip):
+    with pytest.raises(hip.HipError):
+        hip.LbfgsState(1000, 255, torch.device("cuda"))
+    hip.LbfgsState(1000, 254, torch.device("cuda"))
+
+
 # ---------------------------------------------------------------------------------------------------------
 # bf16x6 convolution (fp32 accuracy on the bf16 matrix cores) and producer-side ReLU masks
 # ---------------------------------------------------------------------------------------------------------
