@@ -67,7 +67,7 @@ def test_invalid_arguments_are_rejected_without_touching_the_gpu(libpath):
     assert L.maua_conv2d_fwd(None, None, None, None, None, 1, 3, 8, 8, 4, 3, 3, 1, 1, 0, 0, None, 0, None) == -1
     assert b"null" in L.maua_last_error()
     assert L.maua_fill(None, 10, 0.0, None) == -1
-    assert L.maua_lbfgs_iterate(None, None, None, 10, 5, 1.0, -1.0, None) == -1
+    assert L.maua_lbfgs_iterate(None, None, None, None, 10, 5, 1.0, -1.0, -1.0, None) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch):
