@@ -57,6 +57,12 @@ SIGNATURES = {
     "maua_axpy": (c_i, [c_p, c_p, c_f, c_i64, c_p]),
     "maua_sum_small": (c_i, [c_p, c_i, c_p, c_p]),
     "maua_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_f, c_f, c_f, c_f, c_p]),
+    "maua_channel_stats_workspace_bytes": (c_sz, [c_i, c_i]),
+    "maua_channel_stats": (c_i, [c_p, c_p, c_f, c_i, c_i, c_p, c_p, c_sz, c_p]),
+    "maua_color_match_solve": (c_i, [c_p, c_i64, c_p, c_i64, c_f, c_p, c_p]),
+    "maua_color_match_apply": (c_i, [c_p, c_p, c_f, c_p, c_p, c_i, c_f, c_i, c_i, c_i, c_p, c_p]),
+    "maua_resize_bilinear": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
+    "maua_deprocess_u8": (c_i, [c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_p]),
     "maua_lbfgs_state_bytes": (c_sz, [c_i64, c_i]),
     "maua_lbfgs_init": (c_i, [c_p, c_sz, c_i64, c_i, c_p]),
     "maua_lbfgs_iterate": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_f, c_f, c_f, c_p]),
@@ -421,6 +427,71 @@ def sum_small(slots, out):
 def adam_step(x, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
     _check(lib().maua_adam_step(_ptr(x), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), x.numel(), int(step), float(lr),
                                 beta1, beta2, eps, _stream()), "maua_adam_step")
+
+
+# ------------------------------------------------------------------------------------------
+# image-space steps between two optimisation runs (csrc/image.hip)
+# ------------------------------------------------------------------------------------------
+def channel_stats(x, noise_whc=None, noise_amp=1e-3, out=None, workspace=None):
+    """Raw colour statistics of one 3-channel frame x (3,H,W), optionally jittered by noise_amp * noise (laid out [W][H][3],
+    the order the reference draws it in): 9 doubles = channel sums (3) and the upper triangle of sum x x^T (6)."""
+    c, h, w = x.shape
+    if c != 3:
+        raise HipError("channel_stats: 3-channel images")
+    if out is None:
+        out = torch.empty(9, dtype=torch.float64, device=x.device)
+    workspace = _ws(workspace, lib().maua_channel_stats_workspace_bytes(h, w), x.device)
+    if noise_whc is not None and noise_whc.numel() != x.numel():
+        raise HipError("channel_stats: noise must have the frame's element count")
+    _check(lib().maua_channel_stats(_ptr(_f32(x, "x")), _ptr(noise_whc), float(noise_amp), h, w, _ptr(out), workspace.data_ptr(),
+                                    workspace.numel() * workspace.element_size(), _stream()), "maua_channel_stats")
+    return out
+
+
+def color_match_solve(stats_t, count_t, stats_s, count_s, eps, coef_out):
+    """coef_out (16 floats) = [M = cov_s^(1/2) cov_t^(-1/2) (9), mean_t (3), mean_s (3), ok]; no host sync."""
+    _check(lib().maua_color_match_solve(_ptr(stats_t), int(count_t), _ptr(stats_s), int(count_s), float(eps), _ptr(coef_out),
+                                        _stream()), "maua_color_match_solve")
+    return coef_out
+
+
+def color_match_apply(x, noise_whc, noise_amp, coef, all_coef, weight, accumulate, out):
+    c, h, w = x.shape
+    _check(lib().maua_color_match_apply(_ptr(_f32(x, "x")), _ptr(noise_whc), float(noise_amp), _ptr(coef), _ptr(all_coef),
+                                        all_coef.numel() // 16, float(weight), int(accumulate), h, w, _ptr(out), _stream()),
+           "maua_color_match_apply")
+    return out
+
+
+def resize_bilinear(x, size=None, scale_factor=None):
+    """F.interpolate(x, size | scale_factor=..., mode="bilinear", align_corners=False) for (N,C,H,W) device tensors, with
+    ATen's conventions: scale_factor form -> output floor(in * s), source step float(1 / s); size form -> in / out."""
+    import math
+    import numpy as np
+    n, c, h, w = x.shape
+    if (size is None) == (scale_factor is None):
+        raise HipError("resize_bilinear: give exactly one of size / scale_factor")
+    if scale_factor is not None:
+        oh, ow = int(math.floor(float(h) * scale_factor)), int(math.floor(float(w) * scale_factor))
+        sh = sw = float(np.float32(1.0 / scale_factor))
+    else:
+        oh, ow = (int(size), int(size)) if isinstance(size, int) else (int(size[0]), int(size[1]))
+        sh, sw = float(np.float32(h) / np.float32(oh)), float(np.float32(w) / np.float32(ow))
+    if oh <= 0 or ow <= 0:
+        raise HipError(f"resize_bilinear: output {oh}x{ow}")
+    out = torch.empty(n, c, oh, ow, device=x.device, dtype=torch.float32)
+    _check(lib().maua_resize_bilinear(_ptr(_f32(x, "x")), _ptr(out), n * c, h, w, oh, ow, sh, sw, _stream()), "maua_resize_bilinear")
+    return out
+
+
+def deprocess_u8(x, mean_bgr):
+    """(1,3,H,W) or (3,H,W) network-space BGR image -> (H,W,3) uint8 RGB device tensor (load.deprocess's arithmetic)."""
+    x3 = x.reshape(3, x.shape[-2], x.shape[-1])
+    _, h, w = x3.shape
+    out = torch.empty(h, w, 3, dtype=torch.uint8, device=x.device)
+    _check(lib().maua_deprocess_u8(_ptr(_f32(x3, "x")), out.data_ptr(), h, w, float(mean_bgr[0]), float(mean_bgr[1]),
+                                   float(mean_bgr[2]), _stream()), "maua_deprocess_u8")
+    return out
 
 
 class LbfgsState:

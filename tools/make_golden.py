@@ -282,7 +282,33 @@ def gen_hist():
         out = ref_utils.match_histogram(target.clone(), srcs, mode="avg")
         res[f"out_avg_{tag}"] = out.numpy()
     res["out_off"] = ref_utils.match_histogram(target.clone(), [src1], mode=False).numpy()
+    # clips: a 3-frame target against a 4-frame and a 1-frame source ("avg": per target frame against the source's mean
+    # frame; otherwise the whole clip at once against one random source frame - np.random, seeded here)
+    clip = torch.rand(3, 3, 20, 24, generator=g) * 255 - 120
+    vsrc = torch.rand(4, 3, 16, 16, generator=g) * 180 - 70
+    res["clip"], res["vsrc"] = clip.numpy(), vsrc.numpy()
+    for tag, mode in (("avg", "avg"), ("rand", True)):
+        torch.manual_seed(77)
+        np.random.seed(5)
+        res[f"out_clip_{tag}"] = ref_utils.match_histogram(clip.clone(), [vsrc, src2], mode=mode).numpy()
+    # a larger, strongly correlated case (natural-image-like colour statistics: cond(cov) ~ 1e3)
+    base = torch.rand(1, 1, 96, 80, generator=g)
+    big = torch.cat([base * 200 + torch.rand(1, 1, 96, 80, generator=g) * 8 * (k + 1) for k in range(3)], 1) - 100
+    res["big"] = big.numpy()
+    torch.manual_seed(99)
+    res["out_big"] = ref_utils.match_histogram(big.clone(), [src1], mode=True).numpy()
     save("match_histogram", **res)
+    # bilinear resizing exactly as style.img_img calls it (style.py:38-66): scale_factor form and size form
+    import torch.nn.functional as F
+    img = torch.rand(1, 3, 37, 53, generator=g) * 255 - 120
+    rs = {"img": img.numpy()}
+    for k, sf in enumerate((0.5, 0.73, 1.9, 2.0)):
+        rs[f"sf_{k}"] = np.float64(sf)
+        rs[f"out_sf_{k}"] = F.interpolate(img, scale_factor=sf, mode="bilinear", align_corners=False).numpy()
+    for k, hw in enumerate(((74, 106), (20, 31), (37, 53), (111, 60))):
+        rs[f"hw_{k}"] = np.array(hw)
+        rs[f"out_hw_{k}"] = F.interpolate(img, hw, mode="bilinear", align_corners=False).numpy()
+    save("resize_bilinear", **rs)
 
 
 def gen_host():
