@@ -191,25 +191,29 @@ int maua_adam_step(float* x, const float* grad, float* exp_avg, float* exp_avg_s
 
 /* ---- image-space steps between two optimisation runs ------------------ */
 /* utils.match_histogram (reference utils.py:88-151, called at style.py:24,67,71,292): PCA colour transfer.
- * maua_channel_stats: replaces get_histogram's `tensor.mean(...)` and `th.mm(h, h.T)` (utils.py:88-93) for ONE 3-channel
- *   frame x [3][h][w], jittered as the reference does (`frame + 1e-3 * th.randn(size=frame.shape)`, utils.py:123-124):
- *   noise_whc is that draw in ITS layout [w][h][3] (the frame is viewed as b,w,h,c there), NULL = no jitter.
- *   stats9 (device, doubles) = sum x_c (3), then sum x_a x_b for (0,0) (0,1) (0,2) (1,1) (1,2) (2,2); fp64 partials per tile
- *   in `workspace`, summed in tile order (deterministic).
+ * Layout: the reference views the (B,3,H,W) batch as (B,W,H,3) and reshapes the centred tensor with
+ * `h.permute(0, 3, 1, 2).reshape(C, -1)` (utils.py:91): the 3 B planes (p = 3 b + c) become 3 rows of B whole planes, so
+ * component k of pseudo-pixel (slot j, h, w) is plane k * frames + j (for one image: channel k).  That is reproduced as is.
+ * maua_channel_stats: replaces get_histogram's `tensor.mean(...)` and `th.mm(h, h.T)` (utils.py:88-93) for plane slot `slot`
+ *   of x [frames][3][h][w], jittered as the reference does (`frame + 1e-3 * th.randn(size=frame.shape)`, utils.py:123-124):
+ *   noise_bwhc is that draw in ITS layout [frames][w][h][3], NULL = no jitter.  stats9 (device, doubles) = sum of component
+ *   k (3), then sum of products of components (0,0) (0,1) (0,2) (1,1) (1,2) (2,2); fp64 partials per tile in `workspace`,
+ *   summed in tile order (deterministic).  One call per slot; the caller lays the results out as [frames][9].
  * maua_color_match_solve: replaces symeig + sqrt + th.inverse + the two th.mm of utils.py:127-139 on the device (one thread,
- *   fp64): covariance = second moments / count - mean mean^T + eps I, Q = V sqrt(max(L, 0)) V^T for target and source,
- *   coef16 = [M = Qs Qt^-1 (9, row major), mean_target (3), mean_source (3), ok].  ok = 0 where the reference's
+ *   fp64): mean per true channel, covariance of the 3 rows + eps I, Q = V sqrt(max(L, 0)) V^T for target and (single-frame)
+ *   source, coef16 = [M = Qs Qt^-1 (9, row major), mean_target (3), mean_source (3), ok].  ok = 0 where the reference's
  *   `except RuntimeError` path would fire (non-finite statistics, singular Qt).
- * maua_color_match_apply: replaces `ts = M t; match = ts + mu_s; output += match / len(sources)` (utils.py:137-146):
- *   out (+)= weight * (M (x + amp * noise - mean_target) + mean_source); if any of the n_coef entries of all_coef has
- *   ok == 0 the untouched x is written instead (the reference returns its backup copy for the whole call). */
+ * maua_color_match_apply: replaces `ts = M t; match = ts + mu_s; output += match / len(sources)` (utils.py:137-146) for one
+ *   plane slot: out (+)= weight * (M (x + amp * noise - mean_target) + mean_source); if any of the n_coef entries of
+ *   all_coef has ok == 0 the untouched x is written instead (the reference returns its backup copy for the whole call). */
 size_t maua_channel_stats_workspace_bytes(int h, int w);
-int maua_channel_stats(const float* x_chw, const float* noise_whc, float noise_amp, int h, int w, double* stats9, void* workspace,
-                       size_t workspace_bytes, maua_stream_t stream);
-int maua_color_match_solve(const double* stats_target, int64_t count_target, const double* stats_source, int64_t count_source,
-                           float eps, float* coef16, maua_stream_t stream);
-int maua_color_match_apply(const float* x_chw, const float* noise_whc, float noise_amp, const float* coef16, const float* all_coef,
-                           int n_coef, float weight, int accumulate, int h, int w, float* out_chw, maua_stream_t stream);
+int maua_channel_stats(const float* x_bchw, const float* noise_bwhc, float noise_amp, int frames, int slot, int h, int w,
+                       double* stats9, void* workspace, size_t workspace_bytes, maua_stream_t stream);
+int maua_color_match_solve(const double* stats_target, int frames, int64_t pixels_target, const double* stats_source,
+                           int64_t pixels_source, float eps, float* coef16, maua_stream_t stream);
+int maua_color_match_apply(const float* x_bchw, const float* noise_bwhc, float noise_amp, const float* coef16, const float* all_coef,
+                           int n_coef, float weight, int accumulate, int frames, int slot, int h, int w, float* out_bchw,
+                           maua_stream_t stream);
 /* F.interpolate(..., mode="bilinear", align_corners=False) as style.py:38-66 calls it (content / style / pastiche rescaling
  * between scales): y[planes][oh][ow] from x[planes][h][w]; source index = max(0, scale * (dst + 0.5) - 0.5) in fp32 with
  * scale = float(1 / scale_factor) (scale_factor form) or in / out (size form) - ATen's area_pixel_compute_source_index. */

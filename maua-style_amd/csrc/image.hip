@@ -11,27 +11,33 @@
 
 namespace maua {
 
-// Jitter layout: the reference adds `1e-3 * randn(size=frame.shape)` to the frame viewed as (1, W, H, C), so the draw is
-// laid out [w][h][c]; element (c, h, w) of the image meets noise[(w * H + h) * 3 + c].  Lanes run along h: the three noise
-// values of a lane are 12 contiguous bytes and a wave reads 768 contiguous bytes; the image reads are strided (one row per
-// lane) but a workgroup walks 16 neighbouring columns, so every 64-byte sector it touches is used completely out of L1.
+// Layout.  The reference views the (B, C, H, W) tensor as (B, W, H, C) and, for the whole batch at once, reshapes the centred
+// tensor `h.permute(0, 3, 1, 2).reshape(C, -1)` (utils.py:91): the B*C planes (order p = 3 b + c) are cut into C = 3 rows of B
+// whole planes each, so "component" k of pseudo-pixel (j, h, w) is plane k * B + j - for a single image (B = 1) simply
+// channel k, for a clip a mix of frames and channels (that is what the reference computes, and the colour map is applied
+// through the same reshape, so it is reproduced, not repaired).  Means are per TRUE channel c = p % 3.
+// Jitter: `1e-3 * randn(size=frame.shape)` is drawn in the (B, W, H, C) view, so element (b, c, h, w) meets
+// noise[((b * W + w) * H + h) * 3 + c].  Lanes run along h: the noise values of a lane are contiguous and a wave reads 768
+// contiguous bytes; the image reads are strided (one row per lane) but a workgroup walks 16 neighbouring columns, so every
+// 64-byte sector it touches is used completely out of L1.
 constexpr int ST_ROWS = 64, ST_COLS = 16;
 
-__device__ __forceinline__ void jittered_pixel(const float* __restrict__ x, const float* __restrict__ noise, float amp, int H, int W,
-                                               int h, int w, float (&v)[3]) {
+__device__ __forceinline__ void jittered_pixel(const float* __restrict__ x, const float* __restrict__ noise, float amp, int B, int j,
+                                               int H, int W, int h, int w, float (&v)[3]) {
     const int64_t plane = (int64_t)H * W;
     const int64_t o = (int64_t)h * W + w;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float xv = x[c * plane + o];
+    for (int k = 0; k < 3; ++k) {
+        const int p = k * B + j, b = p / 3, c = p - 3 * b;
+        const float xv = x[p * plane + o];
         // frame + 1e-3 * randn, both roundings as torch performs them (fp32 multiply, then fp32 add)
-        v[c] = noise ? xv + __fmul_rn(amp, noise[((int64_t)w * H + h) * 3 + c]) : xv;
+        v[k] = noise ? xv + __fmul_rn(amp, noise[(((int64_t)b * W + w) * H + h) * 3 + c]) : xv;
     }
 }
 
 // partial[block][9] = sum x_c (3) and sum x_a x_b for (a, b) in (0,0) (0,1) (0,2) (1,1) (1,2) (2,2) over the block's tile
 __global__ void __launch_bounds__(256) channel_stats_kernel(const float* __restrict__ x, const float* __restrict__ noise, float amp,
-                                                            int H, int W, int tiles_w, double* __restrict__ partial) {
+                                                            int B, int j, int H, int W, int tiles_w, double* __restrict__ partial) {
     __shared__ double scratch[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int th = blockIdx.x / tiles_w, tw = blockIdx.x - th * tiles_w;
@@ -43,7 +49,7 @@ __global__ void __launch_bounds__(256) channel_stats_kernel(const float* __restr
             const int w = tw * ST_COLS + wave * (ST_COLS / 4) + k;
             if (w < W) {
                 float v[3];
-                jittered_pixel(x, noise, amp, H, W, h, w, v);
+                jittered_pixel(x, noise, amp, B, j, H, W, h, w, v);
                 const double a = v[0], b = v[1], c = v[2];
                 s[0] += a;
                 s[1] += b;
@@ -109,13 +115,25 @@ __device__ void jacobi3(double a[3][3], double v[3][3], double e[3]) {
     for (int i = 0; i < 3; ++i) e[i] = a[i][i];
 }
 
-// mean and covariance (+ eps I) from the raw sums; Q = cov^(1/2) (negative eigenvalues -> 0, utils.py:129 `Et[Et != Et] = 0`)
-__device__ bool sqrt_cov(const double* __restrict__ st, double count, double eps, double mu[3], double q[3][3]) {
+// Mean per true channel and covariance (+ eps I) of the 3 reshaped rows from the raw sums st[B][9] (one 9-tuple per plane
+// slot j, `hw` pixels each); Q = cov^(1/2) (negative eigenvalues -> 0, utils.py:129 `Et[Et != Et] = 0`).
+__device__ bool sqrt_cov(const double* __restrict__ st, int B, double hw, double eps, double mu[3], double q[3][3]) {
     double a[3][3], v[3][3], e[3];
-    for (int c = 0; c < 3; ++c) mu[c] = st[c] / count;
+    const double count = hw * B;
+    for (int c = 0; c < 3; ++c) mu[c] = 0.0;
+    for (int j = 0; j < B; ++j)
+        for (int k = 0; k < 3; ++k) mu[(k * B + j) % 3] += st[j * 9 + k];
+    for (int c = 0; c < 3; ++c) mu[c] /= count;
     const int idx[3][3] = {{3, 4, 5}, {4, 6, 7}, {5, 7, 8}};
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) a[i][j] = st[idx[i][j]] / count - mu[i] * mu[j] + (i == j ? eps : 0.0);
+    for (int r1 = 0; r1 < 3; ++r1)
+        for (int r2 = 0; r2 < 3; ++r2) {
+            double acc = 0.0;
+            for (int j = 0; j < B; ++j) {  // sum (x1 - m1)(x2 - m2) = sum x1 x2 - m1 sum x2 - m2 sum x1 + hw m1 m2
+                const double m1 = mu[(r1 * B + j) % 3], m2 = mu[(r2 * B + j) % 3];
+                acc += st[j * 9 + idx[r1][r2]] - m1 * st[j * 9 + r2] - m2 * st[j * 9 + r1] + hw * m1 * m2;
+            }
+            a[r1][r2] = acc / count + (r1 == r2 ? eps : 0.0);
+        }
     bool ok = true;
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) ok = ok && isfinite(a[i][j]);
@@ -132,11 +150,11 @@ __device__ bool sqrt_cov(const double* __restrict__ st, double count, double eps
 
 // coef[16]: M = Qs Qt^-1 (9, row-major), mu_t (3), mu_s (3), ok flag (1 / 0).  A singular Qt or non-finite statistics are
 // where the reference's torch.inverse / symeig raise and its `except RuntimeError` returns the untouched image: flag 0.
-__global__ void color_match_solve_kernel(const double* __restrict__ st_t, double n_t, const double* __restrict__ st_s, double n_s,
-                                         double eps, float* __restrict__ coef) {
+__global__ void color_match_solve_kernel(const double* __restrict__ st_t, int B, double hw_t, const double* __restrict__ st_s,
+                                         double hw_s, double eps, float* __restrict__ coef) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double mu_t[3], mu_s[3], qt[3][3], qs[3][3];
-    bool ok = sqrt_cov(st_t, n_t, eps, mu_t, qt) && sqrt_cov(st_s, n_s, eps, mu_s, qs);
+    bool ok = sqrt_cov(st_t, B, hw_t, eps, mu_t, qt) && sqrt_cov(st_s, 1, hw_s, eps, mu_s, qs);
     double inv[3][3];
     if (ok) {
         const double c00 = qt[1][1] * qt[2][2] - qt[1][2] * qt[2][1], c01 = qt[1][2] * qt[2][0] - qt[1][0] * qt[2][2],
@@ -175,8 +193,8 @@ __global__ void color_match_solve_kernel(const double* __restrict__ st_t, double
 // `except RuntimeError: return backup` covers the whole call).  `coef` = this source's 16 floats, `all_coef` = every source's.
 __global__ void __launch_bounds__(256) color_match_apply_kernel(const float* __restrict__ x, const float* __restrict__ noise, float amp,
                                                                 const float* __restrict__ coef, const float* __restrict__ all_coef,
-                                                                int n_coef, float weight, int accumulate, int H, int W, int tiles_w,
-                                                                float* __restrict__ out) {
+                                                                int n_coef, float weight, int accumulate, int B, int j, int H, int W,
+                                                                int tiles_w, float* __restrict__ out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int th = blockIdx.x / tiles_w, tw = blockIdx.x - th * tiles_w;
     const int h = th * ST_ROWS + lane;
@@ -192,6 +210,14 @@ __global__ void __launch_bounds__(256) color_match_apply_kernel(const float* __r
         ms[c] = coef[12 + c];
     }
     const int64_t plane = (int64_t)H * W;
+    int pl[3];  // plane of component k, and its true channel (for the two means)
+    float mtk[3], msk[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        pl[k] = k * B + j;
+        mtk[k] = mt[pl[k] % 3];
+        msk[k] = ms[pl[k] % 3];
+    }
 #pragma unroll
     for (int k = 0; k < ST_COLS / 4; ++k) {
         const int w = tw * ST_COLS + wave * (ST_COLS / 4) + k;
@@ -199,17 +225,17 @@ __global__ void __launch_bounds__(256) color_match_apply_kernel(const float* __r
         const int64_t o = (int64_t)h * W + w;
         if (!ok) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) out[c * plane + o] = x[c * plane + o];
+            for (int c = 0; c < 3; ++c) out[pl[c] * plane + o] = x[pl[c] * plane + o];
             continue;
         }
         float v[3];
-        jittered_pixel(x, noise, amp, H, W, h, w, v);
-        const float d0 = v[0] - mt[0], d1 = v[1] - mt[1], d2 = v[2] - mt[2];
+        jittered_pixel(x, noise, amp, B, j, H, W, h, w, v);
+        const float d0 = v[0] - mtk[0], d1 = v[1] - mtk[1], d2 = v[2] - mtk[2];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float r = fmaf(m[c * 3 + 2], d2, fmaf(m[c * 3 + 1], d1, m[c * 3] * d0)) + ms[c];
+            float r = fmaf(m[c * 3 + 2], d2, fmaf(m[c * 3 + 1], d1, m[c * 3] * d0)) + msk[c];
             r *= weight;  // `matched / len(sources)` (utils.py:146)
-            out[c * plane + o] = accumulate ? out[c * plane + o] + r : r;
+            out[pl[c] * plane + o] = accumulate ? out[pl[c] * plane + o] + r : r;
         }
     }
 }
@@ -264,14 +290,15 @@ size_t maua_channel_stats_workspace_bytes(int h, int w) {
     return tiles * 9 * sizeof(double);
 }
 
-int maua_channel_stats(const float* x_chw, const float* noise_whc, float noise_amp, int h, int w, double* stats9, void* workspace,
-                       size_t workspace_bytes, maua_stream_t stream) {
-    MAUA_REQUIRE(x_chw && stats9 && workspace, MAUA_E_INVAL, "channel_stats: null pointer");
+int maua_channel_stats(const float* x_bchw, const float* noise_bwhc, float noise_amp, int frames, int slot, int h, int w,
+                       double* stats9, void* workspace, size_t workspace_bytes, maua_stream_t stream) {
+    MAUA_REQUIRE(x_bchw && stats9 && workspace, MAUA_E_INVAL, "channel_stats: null pointer");
     MAUA_REQUIRE(h > 0 && w > 0 && (int64_t)h * w < (1ll << 31), MAUA_E_INVAL, "channel_stats: bad dims %d x %d", h, w);
+    MAUA_REQUIRE(frames > 0 && slot >= 0 && slot < frames, MAUA_E_INVAL, "channel_stats: slot %d of %d frames", slot, frames);
     MAUA_REQUIRE(workspace_bytes >= maua_channel_stats_workspace_bytes(h, w), MAUA_E_WORKSPACE, "channel_stats: workspace too small");
     const int tiles_w = (w + ST_COLS - 1) / ST_COLS, tiles_h = (h + ST_ROWS - 1) / ST_ROWS;
-    hipLaunchKernelGGL(channel_stats_kernel, dim3(tiles_w * tiles_h), dim3(256), 0, (hipStream_t)stream, x_chw, noise_whc, noise_amp, h, w,
-                       tiles_w, (double*)workspace);
+    hipLaunchKernelGGL(channel_stats_kernel, dim3(tiles_w * tiles_h), dim3(256), 0, (hipStream_t)stream, x_bchw, noise_bwhc, noise_amp, frames,
+                       slot, h, w, tiles_w, (double*)workspace);
     int rc = check_launch("channel_stats_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(channel_stats_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace,
@@ -279,22 +306,24 @@ int maua_channel_stats(const float* x_chw, const float* noise_whc, float noise_a
     return check_launch("channel_stats_finish_kernel");
 }
 
-int maua_color_match_solve(const double* stats_target, int64_t count_target, const double* stats_source, int64_t count_source,
-                           float eps, float* coef16, maua_stream_t stream) {
+int maua_color_match_solve(const double* stats_target, int frames, int64_t pixels_target, const double* stats_source,
+                           int64_t pixels_source, float eps, float* coef16, maua_stream_t stream) {
     MAUA_REQUIRE(stats_target && stats_source && coef16, MAUA_E_INVAL, "color_match_solve: null pointer");
-    MAUA_REQUIRE(count_target > 0 && count_source > 0, MAUA_E_INVAL, "color_match_solve: empty image");
-    hipLaunchKernelGGL(color_match_solve_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats_target, (double)count_target,
-                       stats_source, (double)count_source, (double)eps, coef16);
+    MAUA_REQUIRE(frames > 0 && pixels_target > 0 && pixels_source > 0, MAUA_E_INVAL, "color_match_solve: empty image");
+    hipLaunchKernelGGL(color_match_solve_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats_target, frames, (double)pixels_target,
+                       stats_source, (double)pixels_source, (double)eps, coef16);
     return check_launch("color_match_solve_kernel");
 }
 
-int maua_color_match_apply(const float* x_chw, const float* noise_whc, float noise_amp, const float* coef16, const float* all_coef,
-                           int n_coef, float weight, int accumulate, int h, int w, float* out_chw, maua_stream_t stream) {
-    MAUA_REQUIRE(x_chw && coef16 && all_coef && out_chw, MAUA_E_INVAL, "color_match_apply: null pointer");
+int maua_color_match_apply(const float* x_bchw, const float* noise_bwhc, float noise_amp, const float* coef16, const float* all_coef,
+                           int n_coef, float weight, int accumulate, int frames, int slot, int h, int w, float* out_bchw,
+                           maua_stream_t stream) {
+    MAUA_REQUIRE(x_bchw && coef16 && all_coef && out_bchw, MAUA_E_INVAL, "color_match_apply: null pointer");
     MAUA_REQUIRE(h > 0 && w > 0 && n_coef > 0 && (int64_t)h * w < (1ll << 31), MAUA_E_INVAL, "color_match_apply: bad dims");
+    MAUA_REQUIRE(frames > 0 && slot >= 0 && slot < frames, MAUA_E_INVAL, "color_match_apply: slot %d of %d frames", slot, frames);
     const int tiles_w = (w + ST_COLS - 1) / ST_COLS, tiles_h = (h + ST_ROWS - 1) / ST_ROWS;
-    hipLaunchKernelGGL(color_match_apply_kernel, dim3(tiles_w * tiles_h), dim3(256), 0, (hipStream_t)stream, x_chw, noise_whc, noise_amp,
-                       coef16, all_coef, n_coef, weight, accumulate, h, w, tiles_w, out_chw);
+    hipLaunchKernelGGL(color_match_apply_kernel, dim3(tiles_w * tiles_h), dim3(256), 0, (hipStream_t)stream, x_bchw, noise_bwhc, noise_amp,
+                       coef16, all_coef, n_coef, weight, accumulate, frames, slot, h, w, tiles_w, out_bchw);
     return check_launch("color_match_apply_kernel");
 }
 

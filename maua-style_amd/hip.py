@@ -58,9 +58,9 @@ SIGNATURES = {
     "maua_sum_small": (c_i, [c_p, c_i, c_p, c_p]),
     "maua_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_f, c_f, c_f, c_f, c_p]),
     "maua_channel_stats_workspace_bytes": (c_sz, [c_i, c_i]),
-    "maua_channel_stats": (c_i, [c_p, c_p, c_f, c_i, c_i, c_p, c_p, c_sz, c_p]),
-    "maua_color_match_solve": (c_i, [c_p, c_i64, c_p, c_i64, c_f, c_p, c_p]),
-    "maua_color_match_apply": (c_i, [c_p, c_p, c_f, c_p, c_p, c_i, c_f, c_i, c_i, c_i, c_p, c_p]),
+    "maua_channel_stats": (c_i, [c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_p, c_p, c_sz, c_p]),
+    "maua_color_match_solve": (c_i, [c_p, c_i, c_i64, c_p, c_i64, c_f, c_p, c_p]),
+    "maua_color_match_apply": (c_i, [c_p, c_p, c_f, c_p, c_p, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "maua_resize_bilinear": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
     "maua_deprocess_u8": (c_i, [c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_p]),
     "maua_lbfgs_state_bytes": (c_sz, [c_i64, c_i]),
@@ -432,34 +432,38 @@ def adam_step(x, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, ep
 # ------------------------------------------------------------------------------------------
 # image-space steps between two optimisation runs (csrc/image.hip)
 # ------------------------------------------------------------------------------------------
-def channel_stats(x, noise_whc=None, noise_amp=1e-3, out=None, workspace=None):
-    """Raw colour statistics of one 3-channel frame x (3,H,W), optionally jittered by noise_amp * noise (laid out [W][H][3],
-    the order the reference draws it in): 9 doubles = channel sums (3) and the upper triangle of sum x x^T (6)."""
-    c, h, w = x.shape
+def channel_stats(x, noise=None, noise_amp=1e-3, out=None, workspace=None):
+    """Raw colour statistics of a batch x (B,3,H,W), optionally jittered by noise_amp * noise (laid out [B][W][H][3], the
+    order the reference draws it in): out[B][9] doubles, one row per plane slot j of the reference's reshape (component k =
+    plane k * B + j; for B = 1 the three channels): component sums (3) and the upper triangle of the product sums (6)."""
+    b, c, h, w = x.shape
     if c != 3:
         raise HipError("channel_stats: 3-channel images")
     if out is None:
-        out = torch.empty(9, dtype=torch.float64, device=x.device)
+        out = torch.empty(b, 9, dtype=torch.float64, device=x.device)
     workspace = _ws(workspace, lib().maua_channel_stats_workspace_bytes(h, w), x.device)
-    if noise_whc is not None and noise_whc.numel() != x.numel():
-        raise HipError("channel_stats: noise must have the frame's element count")
-    _check(lib().maua_channel_stats(_ptr(_f32(x, "x")), _ptr(noise_whc), float(noise_amp), h, w, _ptr(out), workspace.data_ptr(),
-                                    workspace.numel() * workspace.element_size(), _stream()), "maua_channel_stats")
+    if noise is not None and noise.numel() != x.numel():
+        raise HipError("channel_stats: noise must have the batch's element count")
+    for j in range(b):
+        _check(lib().maua_channel_stats(_ptr(_f32(x, "x")), _ptr(noise), float(noise_amp), b, j, h, w, _ptr(out[j]),
+                                        workspace.data_ptr(), workspace.numel() * workspace.element_size(), _stream()),
+               "maua_channel_stats")
     return out
 
 
-def color_match_solve(stats_t, count_t, stats_s, count_s, eps, coef_out):
+def color_match_solve(stats_t, pixels_t, stats_s, pixels_s, eps, coef_out):
     """coef_out (16 floats) = [M = cov_s^(1/2) cov_t^(-1/2) (9), mean_t (3), mean_s (3), ok]; no host sync."""
-    _check(lib().maua_color_match_solve(_ptr(stats_t), int(count_t), _ptr(stats_s), int(count_s), float(eps), _ptr(coef_out),
-                                        _stream()), "maua_color_match_solve")
+    _check(lib().maua_color_match_solve(_ptr(stats_t), stats_t.shape[0], int(pixels_t), _ptr(stats_s), int(pixels_s), float(eps),
+                                        _ptr(coef_out), _stream()), "maua_color_match_solve")
     return coef_out
 
 
-def color_match_apply(x, noise_whc, noise_amp, coef, all_coef, weight, accumulate, out):
-    c, h, w = x.shape
-    _check(lib().maua_color_match_apply(_ptr(_f32(x, "x")), _ptr(noise_whc), float(noise_amp), _ptr(coef), _ptr(all_coef),
-                                        all_coef.numel() // 16, float(weight), int(accumulate), h, w, _ptr(out), _stream()),
-           "maua_color_match_apply")
+def color_match_apply(x, noise, noise_amp, coef, all_coef, weight, accumulate, out):
+    b, c, h, w = x.shape
+    for j in range(b):
+        _check(lib().maua_color_match_apply(_ptr(_f32(x, "x")), _ptr(noise), float(noise_amp), _ptr(coef), _ptr(all_coef),
+                                            all_coef.numel() // 16, float(weight), int(accumulate), b, j, h, w, _ptr(out), _stream()),
+               "maua_color_match_apply")
     return out
 
 

@@ -340,8 +340,10 @@ def _optimize_video(content, styles, init, num_iters, args, net=None, losses=Non
     return output
 
 
-def optimize(content, styles, init, num_iters, args, net=None, losses=None):
-    """Optimise `init` towards `content` / `styles`; returns a CPU fp32 tensor shaped like `init`."""
+def optimize(content, styles, init, num_iters, args, net=None, losses=None, keep_on_device=False):
+    """Optimise `init` towards `content` / `styles`; returns a CPU fp32 tensor shaped like `init` (the reference's contract,
+    optim.py:249).  Inputs may already live on the device; `keep_on_device=True` (the workflow drivers of style.py) returns
+    the device tensor instead, so that colour matching, rescaling and the next scale run without a host round trip."""
     if "_vid" in args.transfer_type:
         return _optimize_video(content, styles, init, num_iters, args, net, losses)
     limit_host_threads()
@@ -378,4 +380,4 @@ def optimize(content, styles, init, num_iters, args, net=None, losses=None):
 
     for mod in losses:
         mod.loss = 0
-    return opt.x.detach().cpu()
+    return opt.x.detach() if keep_on_device else opt.x.detach().cpu()

@@ -38,8 +38,18 @@ def _scaled_styles(style_images_big, content_area, args):
     out = []
     for img in style_images_big:
         scale = math.sqrt(content_area / (img.size(3) * img.size(2))) * args.style_scale
-        out.append(F.interpolate(th.clone(img), scale_factor=scale, mode="bilinear", align_corners=False))
+        out.append(_resize(th.clone(img), scale_factor=scale))
     return out
+
+
+def _resize(img, size=None, scale_factor=None):
+    """F.interpolate(mode="bilinear", align_corners=False) (reference style.py:38-66); device tensors take the HIP kernel."""
+    if img.is_cuda:
+        import hip
+        return hip.resize_bilinear(img.float().contiguous(), size=size, scale_factor=scale_factor)
+    if size is not None:
+        return F.interpolate(img, size, mode="bilinear", align_corners=False)
+    return F.interpolate(img, scale_factor=scale_factor, mode="bilinear", align_corners=False)
 
 
 def _single_rank_only(what):
@@ -53,39 +63,51 @@ def _single_rank_only(what):
 
 
 def img_img(args):
+    """Coarse-to-fine single image (reference style.py:22-73).  The content image, the style images and the pastiche are
+    uploaded once and stay in HBM: colour matching (utils.match_histogram), the bilinear rescaling between scales and the
+    optimisation itself all run on the device; the only transfers are the jitter draws of the colour matching (host RNG,
+    upload) and the 8-bit image of every finished scale (download for the PNG, written by a background thread)."""
     if not _single_rank_only("img_img"):
         return None
     limit_host_threads()
-    style_images_big = load.process_style_images(args)
-    content_image_big = match_histogram(load.preprocess(args.content), style_images_big, mode=args.match_histograms)
+    on_gpu = th.cuda.is_available()
+    up = (lambda t: t.cuda()) if on_gpu else (lambda t: t)
+    style_images_big = [up(t) for t in load.process_style_images(args)]
+    content_image_big = match_histogram(up(load.preprocess(args.content)), style_images_big, mode=args.match_histograms)
     content_size = np.array(content_image_big.size()[-2:])
-    pastiche = load.preprocess(args.init) if args.init not in ("content", "random") else None
+    pastiche = up(load.preprocess(args.init)) if args.init not in ("content", "random") else None
 
+    writer, pending = concurrent.futures.ThreadPoolExecutor(max_workers=1), []
     for current_size, num_iters in zip(args.image_sizes, args.num_iters):
         print("\nCurrent size {}px".format(current_size))
         done = f"{args.output}_{current_size}.png"
         if os.path.exists(done):  # resume: a finished scale is reloaded instead of recomputed
-            pastiche = load.preprocess(done)
+            pastiche = up(load.preprocess(done))
             continue
 
         content_scale = current_size / max(*content_size)
-        content_image = F.interpolate(content_image_big, scale_factor=content_scale, mode="bilinear", align_corners=False)
+        content_image = _resize(content_image_big, scale_factor=content_scale)
         style_images = _scaled_styles(style_images_big, content_image.shape[2] * content_image.shape[3], args)
 
         hw = tuple(int(v) for v in content_image.shape[2:])
         if args.init == "random" and pastiche is None:
-            pastiche = th.randn(1, 3, *hw).mul(0.001)
+            pastiche = up(th.randn(1, 3, *hw).mul(0.001))
         elif args.init == "content" and pastiche is None:
-            pastiche = F.interpolate(content_image_big.clone(), hw, mode="bilinear", align_corners=False)
+            pastiche = _resize(content_image_big.clone(), size=hw)
         else:
-            pastiche = F.interpolate(pastiche.clone(), hw, mode="bilinear", align_corners=False)
+            pastiche = _resize(pastiche.clone(), size=hw)
         pastiche = match_histogram(pastiche, style_images_big, mode=args.match_histograms)
 
-        output_image = optim.optimize(content_image, style_images, pastiche, num_iters, args)
+        output_image = optim.optimize(content_image, style_images, pastiche, num_iters, args, keep_on_device=on_gpu)
 
-        pastiche = match_histogram(output_image.detach().cpu(), style_images_big, mode=args.match_histograms)
-        load.save_tensor_to_file(pastiche.detach().cpu(), args, size=current_size)
-    return pastiche
+        pastiche = match_histogram(output_image.detach(), style_images_big, mode=args.match_histograms)
+        # deprocessing = one kernel + a 3-byte-per-pixel download, here; PNG encoding (host only) runs beside the next scale
+        pending.append(writer.submit(load.save_image_to_file, load.deprocess(pastiche.detach()), args,
+                                     f"{args.output}_{current_size}"))
+    for fut in pending:
+        fut.result()
+    writer.shutdown()
+    return pastiche.cpu() if pastiche is not None else None
 
 
 def img_vid(args):

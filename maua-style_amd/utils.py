@@ -3,9 +3,10 @@
 `match_histogram` is the colour transfer run before/after every scale (reference
 utils.py:88-151, called at style.py:24,67,71).  The reference calls `torch.symeig`,
 which modern torch removed; its own `except RuntimeError` then turns the whole function
-into a no-op.  This version performs the transfer the code describes, with
-`torch.linalg.eigh(UPLO="U")` in place of `symeig(upper=True)`, and draws from the global
-RNG in the same order so seeded runs see the same jitter.
+into a no-op.  This version performs the transfer the code describes - on the device
+(csrc/image.hip: one reduction pass, a 3x3 eigen-problem in one thread, one colour-map
+pass) - and draws the jitter from the global RNG in the same order so seeded runs see
+the same numbers.
 """
 import numpy as np
 import torch as th
@@ -44,51 +45,89 @@ def wrapping_slice(tensor, start, length, return_indices=False):
 
 
 def get_histogram(tensor, eps):
-    """Channel mean, centred channel matrix (C x N) and regularised covariance of a b,w,h,c tensor
-    (reference utils.py:88-93)."""
-    mu = tensor.mean(list(range(tensor.dim() - 1)))
-    h = (tensor - mu).permute(0, 3, 1, 2).reshape(tensor.size(3), -1)
-    cov = h @ h.T / h.shape[1] + eps * th.eye(h.shape[0])
-    return mu, h, cov
+    """Channel means and regularised covariance of ONE frame given as a b,w,h,c view (reference utils.py:88-93), from the
+    device reduction: (mu [3], None, cov [3,3]) as float64 CPU tensors.  (The reference also returns the centred C x N matrix;
+    the colour map is applied by a kernel here, so nothing of that size is materialised.)"""
+    import hip
+    frame = _device(tensor.permute(0, 3, 2, 1))[:1]  # back to b,c,h,w
+    st = hip.channel_stats(frame)[0].cpu()
+    n = frame[0, 0].numel()
+    mu = st[:3] / n
+    cov = th.empty(3, 3, dtype=th.float64)
+    k = 3
+    for i in range(3):
+        for j in range(i, 3):
+            cov[i, j] = cov[j, i] = st[k] / n - mu[i] * mu[j]
+            k += 1
+    return mu, None, cov + eps * th.eye(3, dtype=th.float64)
 
 
-def _sqrt_psd(cov):
-    eva, eve = th.linalg.eigh(cov, UPLO="U")
-    root = th.sqrt(th.diagflat(eva))
-    root[root != root] = 0  # negative eigenvalues -> nan -> 0, as the reference does
-    return eve @ root @ eve.T
+def _device(t):
+    return t.to(device="cuda", dtype=th.float32).contiguous()
+
+
+_SOURCE_CACHE = {}
+
+
+def _source_frames(source, per_frame):
+    """The source on the device, cached per tensor (the style images are matched against on every call of a job)."""
+    key = (source.data_ptr(), tuple(source.shape), source._version, str(source.device), per_frame)
+    hit = _SOURCE_CACHE.get(key)
+    if hit is None:
+        dev = _device(source)
+        if per_frame:
+            dev = dev.mean(0, keepdim=True)  # utils.py:118: matched against the source clip's mean frame
+        if len(_SOURCE_CACHE) > 64:
+            _SOURCE_CACHE.clear()
+        hit = _SOURCE_CACHE[key] = (dev, source)  # the tensor itself is kept so that its data_ptr stays unique
+    return hit[0]
 
 
 def match_histogram(target_tensor, source_tensor, eps=1e-2, mode="avg"):
-    """PCA colour transfer of `target_tensor` towards the colour statistics of each source, averaged over
-    sources (reference utils.py:96-151).  `mode` falsy -> identity; "avg" -> per-frame matching against the
-    source's mean frame; anything else -> one random source frame."""
+    """PCA colour transfer of `target_tensor` towards the colour statistics of each source, averaged over sources
+    (reference utils.py:96-151; called before / after every scale, style.py:24,67,71, and per frame, style.py:292).
+    `mode` falsy -> identity; "avg" -> every target frame against the source's mean frame; anything else -> the whole
+    target against one random source frame.
+
+    Runs on the MI355X (csrc/image.hip): the result lives on the device the target lives on (a CPU target is uploaded and
+    the result brought back), the statistics, the 3x3 eigen-problem and the colour map never touch the host - no
+    synchronisation.  The jitter `1e-3 * randn` is drawn from torch's GLOBAL CPU generator in the reference's order
+    (target draw, then source draw, per frame, per source) and uploaded, so seeded runs see the same numbers and every
+    later draw of the job (e.g. --init random) is unchanged.  Where the reference's `except RuntimeError` would return the
+    untouched input (non-finite statistics, singular square root), so does the device path (flag in the solve kernel)."""
+    import hip
     if not mode:
         return target_tensor
     per_frame = mode == "avg"
     sources = source_tensor if isinstance(source_tensor, list) else [source_tensor]
-    out = th.zeros_like(target_tensor)
+    tgt = _device(target_tensor)
+    B, C, H, W = tgt.shape
+    if C != 3:
+        raise ValueError("match_histogram works on 3-channel images")
+    out = th.empty_like(tgt)
+    n_solves = len(sources) * (B if per_frame else 1)
+    coef = th.empty(n_solves, 16, device=tgt.device)
+    plan = []  # (batch view being matched, its slice of `out`, its jitter, coefficient row)
     for source in sources:
-        tgt = target_tensor.permute(0, 3, 2, 1)  # b,w,h,c
-        src = source.permute(0, 3, 2, 1)
-        if per_frame:
-            src = src.mean(0).unsqueeze(0)
-        else:
-            src = src[np.random.randint(0, src.shape[0])].unsqueeze(0)
-        matched = th.zeros_like(tgt)
-        for idx in range(tgt.shape[0] if per_frame else 1):
-            frame = tgt[idx].unsqueeze(0) if per_frame else tgt
-            _, t, cov_t = get_histogram(frame + 1e-3 * th.randn(size=frame.shape), eps)
-            mu_s, _, cov_s = get_histogram(src + 1e-3 * th.randn(size=src.shape), eps)
-            q_t, q_s = _sqrt_psd(cov_t), _sqrt_psd(cov_s)
-            ts = q_s @ th.inverse(q_t) @ t
-            m = ts.reshape(*frame.permute(0, 3, 1, 2).shape).permute(0, 2, 3, 1) + mu_s
-            if per_frame:
-                matched[idx] = m
-            else:
-                matched = m
-        out += matched.permute(0, 3, 2, 1) / len(sources)
-    return out
+        src = _source_frames(source, per_frame)
+        if not per_frame:
+            src = src[np.random.randint(0, src.shape[0])][None]  # utils.py:120 (numpy's global RNG, as there)
+        sh, sw = src.shape[2], src.shape[3]
+        for idx in range(B if per_frame else 1):
+            batch, dst = (tgt[idx:idx + 1], out[idx:idx + 1]) if per_frame else (tgt, out)
+            # utils.py:123-124: randn(size=frame.shape) with the frame viewed as (b, W, H, C) - the layout the kernels index
+            noise_t = th.randn(size=(batch.shape[0], W, H, 3)).to(tgt.device, non_blocking=True)
+            noise_s = th.randn(size=(1, sw, sh, 3)).to(tgt.device, non_blocking=True)
+            st_t = hip.channel_stats(batch, noise_t)
+            st_s = hip.channel_stats(src[:1], noise_s)
+            hip.color_match_solve(st_t, H * W, st_s, sh * sw, eps, coef[len(plan)])
+            plan.append((batch, dst, noise_t, len(plan)))
+    written = set()
+    for batch, dst, noise_t, row in plan:  # every solve is enqueued before the first map: a failed one makes the whole call the identity
+        key = dst.data_ptr()
+        hip.color_match_apply(batch, noise_t, 1e-3, coef[row], coef, 1.0 / len(sources), key in written, dst)
+        written.add(key)
+    return out if target_tensor.is_cuda else out.cpu()
 
 
 def limit_host_threads(limit=16):

@@ -25,6 +25,9 @@ from .style_oracle import (  # noqa: F401
     adam_run,
     build_spec,
     gram_matrix,
+    deprocess_u8,
     lbfgs_run,
+    match_histogram,
     optimize,
+    resize_bilinear,
 )

@@ -679,3 +679,72 @@ def optimize_video(content, styles, init, num_iters, cfg, state_dict, window, av
             raise ValueError(cfg.optimizer)
         output[idx] = out.reshape(shape).to(output.dtype)
     return output
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Image-space steps around the loop, CPU restatements
+# ---------------------------------------------------------------------------------------------------------
+def _colour_stats(t_bwhc, eps):
+    """reference utils.py:88-93: mean over every dim but the last, the centred tensor reshaped to (C, -1) exactly as written
+    there (`h.permute(0, 3, 1, 2).reshape(C, -1)`: for a batch of more than one frame the rows are NOT the channels - the
+    B*C planes in (frame, channel) order are cut into C runs of B planes), and its covariance + eps I."""
+    mu = t_bwhc.mean(list(range(t_bwhc.dim() - 1)))
+    rows = (t_bwhc - mu).permute(0, 3, 1, 2).reshape(t_bwhc.size(3), -1)
+    return mu, rows, rows @ rows.T / rows.shape[1] + eps * torch.eye(rows.shape[0], dtype=t_bwhc.dtype)
+
+
+def _psd_sqrt(cov):
+    """utils.py:127-131 with torch.linalg.eigh(UPLO="U") standing in for the removed torch.symeig(upper=True)."""
+    vals, vecs = torch.linalg.eigh(cov, UPLO="U")
+    root = torch.sqrt(torch.diagflat(vals))
+    root[root != root] = 0
+    return vecs @ root @ vecs.T
+
+
+def match_histogram(target, sources, eps=1e-2, mode="avg", dtype=None):
+    """reference utils.py:96-151 (PCA colour transfer; jitter from torch's global generator and, for the random-frame
+    mode, numpy's, in the reference's order).  `dtype=torch.float64` evaluates the same formula in double (the jitter is
+    still drawn in fp32, so both precisions see the same numbers)."""
+    import numpy as np
+    if not mode:
+        return target
+    backup = target.clone()
+    work = dtype or target.dtype
+    try:
+        per_frame = mode == "avg"
+        sources = sources if isinstance(sources, list) else [sources]
+        out = torch.zeros_like(target, dtype=work)
+        for source in sources:
+            tgt = target.permute(0, 3, 2, 1).to(work)
+            src = source.permute(0, 3, 2, 1).to(work)
+            src = src.mean(0).unsqueeze(0) if per_frame else src[np.random.randint(0, src.shape[0])].unsqueeze(0)
+            matched = torch.zeros_like(tgt)
+            for idx in range(tgt.shape[0] if per_frame else 1):
+                frame = tgt[idx].unsqueeze(0) if per_frame else tgt
+                _, t, cov_t = _colour_stats(frame + (1e-3 * torch.randn(size=frame.shape)).to(work), eps)
+                mu_s, _, cov_s = _colour_stats(src + (1e-3 * torch.randn(size=src.shape)).to(work), eps)
+                ts = _psd_sqrt(cov_s) @ torch.inverse(_psd_sqrt(cov_t)) @ t
+                m = ts.reshape(*frame.permute(0, 3, 1, 2).shape).permute(0, 2, 3, 1) + mu_s
+                if per_frame:
+                    matched[idx] = m
+                else:
+                    matched = m
+            out += matched.permute(0, 3, 2, 1) / len(sources)
+        return out
+    except RuntimeError:
+        return backup
+
+
+def resize_bilinear(x, size=None, scale_factor=None):
+    """style.py:38-66: F.interpolate(mode="bilinear", align_corners=False) in the two forms the reference uses."""
+    if scale_factor is not None:
+        return F.interpolate(x, scale_factor=scale_factor, mode="bilinear", align_corners=False)
+    return F.interpolate(x, size, mode="bilinear", align_corners=False)
+
+
+def deprocess_u8(x):
+    """load.py:47-52 (+ torchvision ToPILImage's `mul(255).byte()`): (1,3,H,W) BGR mean-subtracted -> (H,W,3) uint8 RGB."""
+    mean = torch.tensor([103.939, 116.779, 123.68])
+    t = x.squeeze(0).float() + mean[:, None, None]
+    rgb = (t[torch.LongTensor([2, 1, 0])] / 255).clamp_(0, 1)
+    return rgb.mul(255).byte().permute(1, 2, 0).contiguous()

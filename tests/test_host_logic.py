@@ -195,23 +195,52 @@ def test_cpu_mode_and_multidevice_are_refused(tmp_path):
         models.load_model(a)
 
 
-def test_match_histogram_against_reference_fixture():
+def test_oracle_match_histogram_against_reference_fixture():
+    """The CPU oracle of utils.match_histogram (reference utils.py:88-151) against outputs of the reference itself
+    (tools/make_golden.py::gen_hist, torch.symeig shimmed by linalg.eigh): single images against one / two sources in both
+    modes, a 3-frame clip against a 4-frame and a 1-frame source (the reference's batch reshape mixes frames and channels -
+    reproduced), and a strongly correlated image.  The device path is checked against the same fixture in
+    tests/test_kernels_gpu.py."""
     import numpy as np
-    import utils
+    from oracle import match_histogram
     g = np.load(os.path.join(GOLDEN, "match_histogram.npz"))
     target, src1, src2 = (torch.from_numpy(g[k]) for k in ("target", "src1", "src2"))
     for tag, srcs in (("one", [src1]), ("two", [src1, src2])):
         torch.manual_seed(1234)
-        out = utils.match_histogram(target.clone(), srcs, mode=True)
-        assert torch.allclose(out, torch.from_numpy(g[f"out_{tag}"]), rtol=1e-4, atol=1e-3)
+        out = match_histogram(target.clone(), srcs, mode=True)
+        assert torch.allclose(out, torch.from_numpy(g[f"out_{tag}"]), rtol=1e-5, atol=1e-4)
         torch.manual_seed(1234)
-        out = utils.match_histogram(target.clone(), srcs, mode="avg")
-        assert torch.allclose(out, torch.from_numpy(g[f"out_avg_{tag}"]), rtol=1e-4, atol=1e-3)
-    assert torch.equal(utils.match_histogram(target.clone(), [src1], mode=False), target)
+        out = match_histogram(target.clone(), srcs, mode="avg")
+        assert torch.allclose(out, torch.from_numpy(g[f"out_avg_{tag}"]), rtol=1e-5, atol=1e-4)
+    assert torch.equal(match_histogram(target.clone(), [src1], mode=False), target)
+    clip, vsrc = torch.from_numpy(g["clip"]), torch.from_numpy(g["vsrc"])
+    for tag, mode in (("avg", "avg"), ("rand", True)):
+        torch.manual_seed(77)
+        np.random.seed(5)
+        out = match_histogram(clip.clone(), [vsrc, src2], mode=mode)
+        assert torch.allclose(out, torch.from_numpy(g[f"out_clip_{tag}"]), rtol=1e-5, atol=1e-4), tag
+    torch.manual_seed(99)
+    out = match_histogram(torch.from_numpy(g["big"]).clone(), [src1], mode=True)
+    assert torch.allclose(out, torch.from_numpy(g["out_big"]), rtol=1e-4, atol=1e-3)
     # the transfer does what it says: channel means of the result equal the source's
     torch.manual_seed(0)
-    out = utils.match_histogram(target.clone(), [src1], mode=True)
+    out = match_histogram(target.clone(), [src1], mode=True)
     assert torch.allclose(out.mean((0, 2, 3)), src1.mean((0, 2, 3)), atol=0.05)
+    # a non-finite input takes the reference's `except RuntimeError` exit: the untouched image comes back
+    bad = target.clone()
+    bad[0, 1, 3, 3] = float("nan")
+    res = match_histogram(bad.clone(), [src1], mode=True)
+    assert torch.equal(torch.isnan(res), torch.isnan(bad)) and torch.equal(res[~torch.isnan(res)], bad[~torch.isnan(bad)])
+
+
+def test_oracle_resize_matches_reference_fixture():
+    import numpy as np
+    from oracle import resize_bilinear
+    g = np.load(os.path.join(GOLDEN, "resize_bilinear.npz"))
+    img = torch.from_numpy(g["img"])
+    for k in range(4):
+        assert torch.equal(resize_bilinear(img, scale_factor=float(g[f"sf_{k}"])), torch.from_numpy(g[f"out_sf_{k}"]))
+        assert torch.equal(resize_bilinear(img, size=tuple(int(v) for v in g[f"hw_{k}"])), torch.from_numpy(g[f"out_hw_{k}"]))
 
 
 def test_video_windows_schedule_matches_reference_formula():

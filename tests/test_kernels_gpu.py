@@ -11,7 +11,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import PKG, REPO, rel_l2
+from conftest import GOLDEN, PKG, REPO, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -795,3 +795,130 @@ def test_masks_on_pool_mse_gram_backward(hip):
     torch.cuda.synchronize()
     ref = (d.double() @ fm.reshape(C, HW).double() + base.double()) * (fm.reshape(C, HW) > 0)
     assert rel_l2(gf.cpu(), ref) <= TOL
+
+
+# ---------------------------------------------------------------------------------------------------------
+# image-space steps between two optimisation runs (csrc/image.hip): colour transfer, bilinear resize, deprocess
+# ---------------------------------------------------------------------------------------------------------
+def _hist_fixture():
+    import numpy as np
+    return np.load(os.path.join(GOLDEN, "match_histogram.npz"))
+
+
+@pytest.mark.parametrize("on_device", [True, False])
+def test_match_histogram_device_vs_reference_fixture(hip, on_device):
+    """utils.match_histogram on the MI355X against outputs of the reference's own function (tests/golden/match_histogram.npz,
+    tools/make_golden.py::gen_hist): same seeds -> same jitter -> same result to 1e-5; device targets stay on the device,
+    CPU targets come back on the CPU."""
+    import numpy as np
+    import utils
+    g = _hist_fixture()
+    put = (lambda t: t.cuda()) if on_device else (lambda t: t)
+    target, src1, src2 = (torch.from_numpy(g[k]) for k in ("target", "src1", "src2"))
+    cases = []
+    for tag, srcs in (("one", [src1]), ("two", [src1, src2])):
+        cases += [(target, srcs, True, f"out_{tag}", 1234, None), (target, srcs, "avg", f"out_avg_{tag}", 1234, None)]
+    clip, vsrc = torch.from_numpy(g["clip"]), torch.from_numpy(g["vsrc"])
+    cases += [(clip, [vsrc, src2], "avg", "out_clip_avg", 77, 5), (clip, [vsrc, src2], True, "out_clip_rand", 77, 5),
+              (torch.from_numpy(g["big"]), [src1], True, "out_big", 99, None)]
+    for tgt, srcs, mode, key, seed, npseed in cases:
+        torch.manual_seed(seed)
+        if npseed is not None:
+            np.random.seed(npseed)
+        out = utils.match_histogram(put(tgt.clone()), srcs, mode=mode)
+        assert out.is_cuda == on_device and out.shape == tgt.shape
+        want = torch.from_numpy(g[key])
+        tol = 1e-4 if key == "out_big" else 1e-5  # cond(cov) ~ 1e3 there: the reference's own fp32 eigen-solve is that far from fp64
+        assert rel_l2(out.cpu(), want) <= tol, (key, rel_l2(out.cpu(), want))
+    same = utils.match_histogram(put(target.clone()), [src1], mode=False)
+    assert torch.equal(same.cpu(), target)
+
+
+def test_match_histogram_device_keeps_the_global_rng_order(hip):
+    """The jitter comes from torch's global CPU generator in the reference's order, so whatever is drawn afterwards
+    (e.g. the --init random pastiche, style.py:55) is the same as after the oracle's run of the reference formula."""
+    from oracle import match_histogram as oracle_mh
+    import utils
+    g = _hist_fixture()
+    target, src1, src2 = (torch.from_numpy(g[k]) for k in ("target", "src1", "src2"))
+    torch.manual_seed(5)
+    oracle_mh(target.clone(), [src1, src2], mode=True)
+    after_oracle = torch.randn(7)
+    torch.manual_seed(5)
+    utils.match_histogram(target.clone().cuda(), [src1, src2], mode=True)
+    assert torch.equal(torch.randn(7), after_oracle)
+
+
+def test_match_histogram_device_full_size_vs_fp64_oracle(hip):
+    """1024x1024 target against a 900x700 source: the device result agrees with the same formula evaluated in fp64 on the
+    CPU (same jitter draws) to 1e-5, is deterministic, and moves the channel statistics onto the source's."""
+    from oracle import match_histogram as oracle_mh
+    import utils
+    gen = torch.Generator().manual_seed(3)
+    base = torch.rand(1, 1, 1024, 1024, generator=gen)
+    target = torch.cat([base * (150 + 20 * k) + torch.rand(1, 1, 1024, 1024, generator=gen) * 40 for k in range(3)], 1) - 110
+    source = torch.rand(1, 3, 900, 700, generator=gen) * torch.tensor([200.0, 120.0, 60.0]).view(1, 3, 1, 1) - 90
+    torch.manual_seed(11)
+    ref = oracle_mh(target.clone(), [source], mode=True, dtype=torch.float64)
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(11)
+        outs.append(utils.match_histogram(target.clone().cuda(), [source], mode=True))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    assert rel_l2(outs[0].cpu(), ref) <= 1e-5
+    assert torch.allclose(outs[0].mean((0, 2, 3)).cpu(), source.mean((0, 2, 3)), atol=0.05)
+    cov = lambda t: torch.cov(t[0].reshape(3, -1).double())
+    assert rel_l2(cov(outs[0].cpu()), cov(source)) <= 1e-2
+
+
+def test_match_histogram_device_non_finite_input_returns_the_input(hip):
+    """Reference utils.py:147-150: a RuntimeError inside (symeig / inverse on non-finite statistics) returns the backup copy."""
+    import utils
+    g = _hist_fixture()
+    target, src1 = torch.from_numpy(g["target"]), torch.from_numpy(g["src1"])
+    bad = target.clone()
+    bad[0, 1, 3, 3] = float("inf")
+    out = utils.match_histogram(bad.clone().cuda(), [src1], mode=True).cpu()
+    assert torch.equal(out, bad)
+
+
+def test_resize_bilinear_device_vs_reference_fixture(hip):
+    import numpy as np
+    g = np.load(os.path.join(GOLDEN, "resize_bilinear.npz"))
+    img = torch.from_numpy(g["img"]).cuda()
+    for k in range(4):
+        got = hip.resize_bilinear(img, scale_factor=float(g[f"sf_{k}"])).cpu()
+        want = torch.from_numpy(g[f"out_sf_{k}"])
+        assert got.shape == want.shape and float((got - want).abs().max()) <= 2e-4 and rel_l2(got, want) <= 1e-6, ("sf", k)
+        got = hip.resize_bilinear(img, size=tuple(int(v) for v in g[f"hw_{k}"])).cpu()
+        want = torch.from_numpy(g[f"out_hw_{k}"])
+        assert got.shape == want.shape and float((got - want).abs().max()) <= 2e-4 and rel_l2(got, want) <= 1e-6, ("hw", k)
+
+
+@pytest.mark.parametrize("src,dst", [(512, 1024), (1024, 2048), (1024, 724), (256, 362)])
+def test_resize_bilinear_device_full_size(hip, src, dst):
+    """The scale chain of img_img (style.py:57-66) at real sizes against ATen's CPU kernel."""
+    import torch.nn.functional as F
+    x = rnd(1, 3, src, src, seed=31) * 100
+    want = F.interpolate(x, (dst, dst), mode="bilinear", align_corners=False)
+    got = hip.resize_bilinear(dev(x), size=(dst, dst)).cpu()
+    assert rel_l2(got, want) <= 1e-6
+    want = F.interpolate(x, scale_factor=dst / src, mode="bilinear", align_corners=False)
+    got = hip.resize_bilinear(dev(x), scale_factor=dst / src).cpu()
+    assert got.shape == want.shape and rel_l2(got, want) <= 1e-6
+
+
+def test_deprocess_u8_is_bit_exact(hip):
+    """load.deprocess on the device: the same bytes as the CPU arithmetic of the reference (load.py:47-52), including
+    clamping, truncation and values exactly on a byte boundary."""
+    from oracle import deprocess_u8
+    import load
+    x = rnd(1, 3, 517, 389, seed=41) * 120
+    x[0, :, 0, :8] = torch.tensor([-200.0, 300.0, 0.0, 1.0, -103.939, 151.061, 0.5, 254.999])  # out of range / boundaries
+    want = deprocess_u8(x.clone())
+    got = hip.deprocess_u8(dev(x), load._MEAN_BGR).cpu()
+    assert torch.equal(got, want)
+    import numpy as np
+    assert np.array_equal(np.asarray(load.deprocess(x.clone())), want.numpy())
+    assert np.array_equal(np.asarray(load.deprocess(dev(x))), want.numpy())  # device tensors take the kernel
