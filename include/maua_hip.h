@@ -104,6 +104,19 @@ int maua_conv3x3_x3(const float* x, const void* bank, float w_scale, const float
                     int n, int cin, int h, int w, int cout, int pad, int relu, int accumulate, void* workspace,
                     size_t workspace_bytes, maua_stream_t stream);
 
+/* The same fp16x3 arithmetic on the second kernel structure (conv_x3w.hip): K chunks of 16 input channels (every tap a full
+ * K = 16 MFMA step), four 32x32 accumulators per wave, two workgroups per CU.  Replaces the same torch calls as
+ * maua_conv3x3_x3 (nn.Conv2d 3x3 + ReLU forward, models.py:129-130, and its backward-data) for layers with cin % 16 == 0
+ * and planes of at most 2^25 pixels (maua_conv_x3w_supported); bank layout [chunk16][cout tile][tap][part][octet][co][8 ch]. */
+size_t maua_conv_x3w_bank_bytes(int cout_produced, int cin_consumed);
+int maua_conv_pack_filters_x3w(const float* w_oihw, void* bank_fwd, void* bank_bwd, int cout, int cin, float w_scale,
+                               maua_stream_t stream);
+int maua_conv_x3w_supported(int cin, int h, int w, int pad);
+size_t maua_conv_x3w_workspace_bytes(int n, int cin, int h, int w, int cout, int pad);
+int maua_conv3x3_x3w(const float* x, const void* bank, float w_scale, const float* bias, const float* out_relu_mask, float* y,
+                     int n, int cin, int h, int w, int cout, int pad, int relu, int accumulate, void* workspace,
+                     size_t workspace_bytes, maua_stream_t stream);
+
 /* ---- KS x KS stride-1 convolution in the same fp16x3 arithmetic (conv_kxk_x3.hip; KS = 5: NIN's conv2, models.py:86).
  *      Banks as for maua_conv_pack_filters_x3 with KS*KS taps; backward-data of a pad-p conv: bank_bwd, cin/cout exchanged,
  *      pad KS-1-p.  workspace (nullable) as for maua_conv3x3_x6: lets small output grids split the channel loop. ---- */

@@ -90,11 +90,14 @@ struct ConvArgs {
     const float* omask;  // nullable, output-shaped: result is zeroed where omask <= 0 (ReLU mask applied by the producer)
     int ksplit;          // conv_x6 split-K: > 1 -> blockIdx.z = n*ksplit + split, raw partial sums go to `ws`
     float* ws;           // [n][ksplit][Cout][OH][OW] partial sums (split-K only)
+    int stagger;         // conv_x3w: start delay (units of 512 cycles) of the first-round workgroups in odd CU slots
 };
 int conv_mfma_dispatch(const ConvArgs& a, int ks, int n, hipStream_t stream);
 int conv3x3_few_out(const ConvArgs& a, int n, hipStream_t stream);
 int conv_splitk_finish(const ConvArgs& a, int n, int ksplit, hipStream_t stream);
 int conv_x3_launch(const ConvArgs& a, int n, float w_scale, hipStream_t stream);  // conv_x3.hip  // y = act(bias + sum of a.ws partials) ...
+int conv_x3w_launch(const ConvArgs& a, int n, float w_scale, hipStream_t stream);  // conv_x3w.hip (16-channel chunks, a.Cin % 16 == 0)
+bool conv_x3w_supports(const ConvArgs& a);
 int conv1x1_x3_launch(const ConvArgs& a, const float* xshift, int n, hipStream_t stream);  // conv1x1_x3.hip (a.w = [Cout][Cin], a.H*a.W pixels)
 size_t conv1x1_x3_workspace(int n, int cin, int64_t hw, int cout);
 int conv_mfma2_choose_split(const ConvArgs& a, int ks, int n);                     // 1 = no split  // 3x3, stride 1, Cout <= 4 (conv_direct.hip)

@@ -1,0 +1,574 @@
+// 3x3 stride-1 convolution in fp16x3 arithmetic (conv_x3.hip), second structure: "wide" register tiles, 16-channel chunks.
+//
+// conv_x3.hip runs four workgroups per CU (four waves per SIMD, 128 registers each): every MFMA is fed by one ds_read_b128,
+// every 8-channel chunk pays three workgroup barriers and a fold of the chunk's sums into the fp32 master accumulator, and
+// the ninth tap runs as a half-empty K = 8 step (10 % of the matrix-pipe time).  The kernel sits at 57 % pipe occupancy and
+// the chip holds ~1.8 GHz under it: what is left to win is energy and issue slots per useful product.
+// This structure spends the register file differently:
+//   * workgroup = 4 waves = 64 output channels x (8 rows x 32 px); a wave owns 64 channels x 2 rows x 32 px = FOUR 32x32
+//     accumulators (+ four fp32 masters): 128 accumulator registers, two workgroups per CU (two waves per SIMD, 256
+//     registers each).  One tap needs 4 filter fragments + 4 patch fragments for 12 MFMAs: 0.67 ds_read_b128 per MFMA
+//     instead of 1;
+//   * K chunk = 16 input channels: one MFMA k-step is ONE tap x 16 channels (lane half = channel octet), so all nine taps
+//     are full K = 16 steps - no K = 8 step; the fold into the masters and the workgroup's scale happen once per 16
+//     channels, with TWO barriers per chunk (three per 8 channels before);
+//   * image borders and the tail items of the staging loop are out-of-range BUFFER loads (the hardware returns 0): no
+//     per-value selects while staging;
+//   * the two workgroups of a CU are independent, so while one stages (split + LDS writes + filter DMA) the other owns the
+//     matrix pipe.
+// Arithmetic is exactly conv_x3.hip's: x s = xh + xl (two fp16 parts, round to nearest, s = power of two per workgroup and
+// chunk bringing the chunk's maximum into [2^11, 2^12)), filters pre-split and pre-scaled in the bank, products xl*wh, xh*wl,
+// xh*wh on v_mfma_f32_32x32x16_f16, per-chunk un-scaled fold into fp32 masters.  The scale now covers 16 channels.
+//
+// LDS per workgroup: patch [part][octet][pos 10x34 (+4)][8 ch] = 22,016 B, filters [tap][part][octet][co 64][8 ch] = 36,864 B.
+#include <stdlib.h>
+
+#include "common.hpp"
+
+namespace maua {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+constexpr int XW_COT = 64;
+constexpr int XW_ROWS = 8, XW_PR = 10, XW_PC = 34;
+constexpr int XW_NPOS = XW_PR * XW_PC;                          // 340
+constexpr int XW_NPOS_PAD = 344;
+constexpr int XW_PLANE = XW_NPOS_PAD * 16;                      // bytes of one [pos][8 ch] plane
+constexpr int XW_PATCH_BYTES = 4 * XW_PLANE;                    // [part][octet]
+constexpr int XW_W_BYTES = 9 * 2 * 2 * XW_COT * 16;             // 36 planes of 1 KiB: [tap][part][octet][co][16 B]
+constexpr int XW_ITEMS = 2 * XW_NPOS;                           // (octet, pos) staging items per chunk: 680 = 2.66 per thread
+
+__device__ __forceinline__ unsigned xw_cvt_pk_f16(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+__device__ __forceinline__ float xw_f16_lo(unsigned u) { return (float)__builtin_bit_cast(f16x2, u)[0]; }
+__device__ __forceinline__ float xw_f16_hi(unsigned u) { return (float)__builtin_bit_cast(f16x2, u)[1]; }
+
+// bank[dir][chunk16][cotile][tap][part][octet][co][ch] (fp16, pre-scaled): fwd: co = output channel, ch = input channel,
+// tap = ky*3+kx; bwd-data: roles swapped and taps flipped.  Zero padding for channels beyond the tensor.
+__global__ void pack_x3w_kernel(const float* __restrict__ w, unsigned short* __restrict__ bank, int cout, int cin, int backward,
+                                float w_scale) {
+    const int CO = backward ? cin : cout;
+    const int CI = backward ? cout : cin;
+    const int nchunk = (CI + 15) / 16, ntile = (CO + XW_COT - 1) / XW_COT;
+    const int64_t total = (int64_t)nchunk * ntile * 9 * 2 * XW_COT * 8;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = e;
+        const int ch = (int)(r % 8);
+        r /= 8;
+        const int co = (int)(r % XW_COT);
+        r /= XW_COT;
+        const int oct = (int)(r % 2);
+        r /= 2;
+        const int tap = (int)(r % 9);
+        r /= 9;
+        const int tile = (int)(r % ntile);
+        const int chunk = (int)(r / ntile);
+        const int o = tile * XW_COT + co, i = chunk * 16 + oct * 8 + ch;
+        float v = 0.f;
+        if (o < CO && i < CI) {
+            if (!backward) v = w[((int64_t)o * cin + i) * 9 + tap];
+            else v = w[((int64_t)i * cin + o) * 9 + (8 - tap)];
+        }
+        v *= w_scale;
+        const _Float16 h = (_Float16)v;
+        const _Float16 l = (_Float16)(v - (float)h);
+        // [tap][part][octet][co][ch]
+        const int64_t base = ((int64_t)chunk * ntile + tile) * (XW_W_BYTES / 2);
+        bank[base + ((((int64_t)tap * 2 + 0) * 2 + oct) * XW_COT + co) * 8 + ch] = __builtin_bit_cast(unsigned short, h);
+        bank[base + ((((int64_t)tap * 2 + 1) * 2 + oct) * XW_COT + co) * 8 + ch] = __builtin_bit_cast(unsigned short, l);
+    }
+}
+
+// Diagnostic build only (-DXW_STAMP, tools/x3w_clock.py): shader-clock stamps at the phase boundaries of every chunk go to a
+// buffer of their own (passed in p.mask, which this kernel does not use otherwise); no output value depends on them.
+#ifdef XW_STAMP
+#define XW_MARK(k)                                                                                          \
+    do {                                                                                                    \
+        if (lane == 0 && p.mask) {                                                                          \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                     \
+            const_cast<float*>(p.mask)[((((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 64 + (ch - ch_begin)) * 8 + (k)] = \
+                __builtin_bit_cast(float, (unsigned)t_);                                                    \
+        }                                                                                                   \
+    } while (0)
+#else
+#define XW_MARK(k) do {} while (0)
+#endif
+
+template <bool ACC, bool OM>
+__global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_inv_scale) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[XW_PATCH_BYTES + XW_W_BYTES + 16];
+    unsigned char* Pl = smem;                    // [part][octet][pos][16 B]
+    unsigned char* Wl = smem + XW_PATCH_BYTES;   // [tap][part][octet][co][16 B]
+    float* Ml = reinterpret_cast<float*>(smem + XW_PATCH_BYTES + XW_W_BYTES);  // per-wave maxima of the chunk being staged
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
+    const int n = blockIdx.z / ksplit, split = blockIdx.z - n * ksplit;
+    const int cotile = blockIdx.y;
+    const int co0 = cotile * XW_COT;
+    const int ntile = gridDim.y;
+    const int in_plane = p.H * p.W;
+    const int64_t out_plane = (int64_t)p.OH * p.OW;
+    const float* __restrict__ xin = p.x + (int64_t)n * p.Cin * in_plane;
+    // XCD-aware tile order (conv_x6.hip): XCD k owns the k-th contiguous band of tiles
+    const int tiles_total = p.tiles_x * ((p.OH + XW_ROWS - 1) / XW_ROWS);
+    const int per_xcd = (tiles_total + 7) >> 3;
+    const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= min(((int)(blockIdx.x & 7) + 1) * per_xcd, tiles_total)) return;  // whole workgroup leaves
+    const int x0 = (tile % p.tiles_x) * 32, y0 = (tile / p.tiles_x) * XW_ROWS;
+
+    // Staging items of this thread: item k = (octet, position) number tid + 256 k.  voff = byte offset of the item's first
+    // channel from the chunk's first plane; out-of-image positions and items past the end get an offset beyond the buffer's
+    // range, for which a buffer load returns 0 (no selects on the values).
+    unsigned voff[3], lds_w[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int idx = tid + 256 * k;
+        const int oct = idx >= XW_NPOS ? 1 : 0;
+        const int pos = idx - oct * XW_NPOS;
+        const int r = pos / XW_PC, c = pos - r * XW_PC;
+        const int iy = y0 + r - p.pad, ix = x0 + c - p.pad;
+        const bool ok = idx < XW_ITEMS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        voff[k] = ok ? (unsigned)(oct * 8 * in_plane + iy * p.W + ix) * 4u : 0x80000000u;
+        lds_w[k] = (unsigned)(oct * XW_PLANE + pos * 16);
+    }
+    // buffer resource over 16 planes from the chunk's first one: the range check sees the vector offset only
+    const unsigned range = (unsigned)in_plane * 64u;
+    float rp[3][8];
+    u32x4 hl[3][2];  // the split chunk waiting for its LDS write: [item][part]
+    auto load_patch = [&](int c0) {
+        asm volatile("" : "+s"(c0));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin + (int64_t)c0 * in_plane), 0, range, 0x00020000);
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                rp[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[k], c * in_plane * 4, 0));
+    };
+    auto publish_max = [&]() {
+        float m = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) m = fmaxf(m, fabsf(rp[k][c]));
+        m = wave_max_nonneg(m);
+        if (lane == 0) Ml[wave] = m;
+    };
+    // scale of the staged chunk: max in [2^11, 2^12) after scaling.  Returns the INVERSE scale, sets `sx`.
+    float sx = 1.f;
+    auto chunk_scale = [&]() {
+        const float m = fmaxf(fmaxf(Ml[0], Ml[1]), fmaxf(Ml[2], Ml[3]));
+        int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu) - 127;  // floor(log2 m) for normal m
+        e = m > 0.f ? max(e, -100) : 11;
+        sx = __builtin_bit_cast(float, (unsigned)(127 + 11 - e) << 23);
+        return __builtin_bit_cast(float, (unsigned)(127 + e - 11) << 23);
+    };
+    // split of one staged item in place: rp[k][0..3] <- packed high parts, rp[k][4..7] <- packed low parts (bit patterns)
+    auto split_item = [&](int k) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float v0 = rp[k][2 * q] * sx, v1 = rp[k][2 * q + 1] * sx;
+            const unsigned H = xw_cvt_pk_f16(v0, v1);
+            const unsigned Lo = xw_cvt_pk_f16(v0 - xw_f16_lo(H), v1 - xw_f16_hi(H));
+            hl[k][0][q] = H;
+            hl[k][1][q] = Lo;
+        }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (k == 2 && tid >= XW_ITEMS - 512) break;
+            *reinterpret_cast<u32x4*>(Pl + lds_w[k]) = hl[k][0];
+            *reinterpret_cast<u32x4*>(Pl + 2 * XW_PLANE + lds_w[k]) = hl[k][1];
+        }
+    };
+
+    const unsigned char* __restrict__ bank = reinterpret_cast<const unsigned char*>(p.w6);
+    // Filter slice of a chunk = 36 planes of 1 KiB in LDS order; wave w streams planes w, w + 4, ... (9 LDS-DMA instructions)
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned lane16 = lane * 16;
+    // planes [first, first + 4 count) of chunk ch, one per wave and step: taps 0-4 are planes 0-19 (5 per wave), taps 5-8 planes 20-35
+    auto dma_filters = [&](int ch, int first, int count) {
+        const unsigned char* src = bank + ((int64_t)ch * ntile + cotile) * XW_W_BYTES;
+#pragma unroll
+        for (int i = 0; i < count; ++i) {
+            const int q = first + wv + 4 * i;
+            const unsigned char* g = src + q * 1024;
+            const unsigned lds_dst = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(Wl + q * 1024);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(lane16), "s"(__builtin_amdgcn_readfirstlane(lds_dst)), "s"(g)
+                         : "memory");
+        }
+    };
+
+    // fragment byte offsets of this lane: patch (row 2 wave + row + ky, col j + kx, octet = lane half), filters (co = j)
+    const int b_base = half * XW_PLANE + ((2 * wave) * XW_PC + j) * 16;
+    const int a_base = half * 1024 + j * 16;
+
+    f32x16 acc[2][2], master[2][2];  // [32-channel half of the tile][row]
+    {
+        const bool with_bias = p.bias != nullptr && p.ksplit <= 1;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float b0 = 0.f;
+                if (with_bias) b0 = p.bias[min(co, p.Cout - 1)];
+                master[t][0][r] = b0;
+                master[t][1][r] = b0;
+                acc[t][0][r] = 0.f;
+                acc[t][1][r] = 0.f;
+            }
+    }
+
+    // One tap = 4 filter + 4 patch fragments (ds_read_b128) and 12 MFMAs, issued as two half-steps of 6 (one per 32-channel
+    // half of the tile).  Fragments are requested one to two half-steps (192-384 matrix cycles) before their MFMAs - two
+    // patch sets, one filter set per half, sched_barrier keeps the order - so LDS latency hides behind the matrix pipe
+    // instead of stalling the wave several times per tap.
+    typedef f16x8 AFrag[2];     // [part] of one 32-channel half
+    typedef f16x8 BFrag[2][2];  // [row][part]
+    auto load_a = [&](AFrag& a, int tap, int t) {
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+            a[part] = *reinterpret_cast<const f16x8*>(Wl + a_base + (tap * 2 + part) * 2048 + t * 512);
+    };
+    auto load_b = [&](BFrag& b, int tap) {
+        const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+        for (int row = 0; row < 2; ++row)
+#pragma unroll
+            for (int part = 0; part < 2; ++part)
+                b[row][part] = *reinterpret_cast<const f16x8*>(Pl + b_base + part * 2 * XW_PLANE + ((row + ky) * XW_PC + kx) * 16);
+    };
+    auto mfma_half = [&](const AFrag& a, const BFrag& b, int t) {
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+            acc[t][row] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[row][0], acc[t][row], 0, 0, 0);  // smallest terms first
+            acc[t][row] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[row][1], acc[t][row], 0, 0, 0);
+            acc[t][row] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[row][0], acc[t][row], 0, 0, 0);
+        }
+    };
+    AFrag a0, a1;
+    BFrag bx, by;
+#define XW_FENCE() __builtin_amdgcn_sched_barrier(0)
+// tap TAP with patch set BCUR; requests patch set BNXT and the first filter half of tap TAP + 1 (when HAS_NEXT); EXTRA0 / EXTRA1
+// are scheduled among the MFMAs of the two half-steps
+#define XW_TAP(TAP, BCUR, BNXT, HAS_NEXT, EXTRA0, EXTRA1) \
+    do {                                                  \
+        load_a(a1, TAP, 1);                               \
+        if (HAS_NEXT) load_b(BNXT, (TAP) + 1);            \
+        XW_FENCE();                                       \
+        mfma_half(a0, BCUR, 0);                           \
+        EXTRA0;                                           \
+        XW_FENCE();                                       \
+        if (HAS_NEXT) load_a(a0, (TAP) + 1, 0);           \
+        XW_FENCE();                                       \
+        mfma_half(a1, BCUR, 1);                           \
+        EXTRA1;                                           \
+        XW_FENCE();                                       \
+    } while (0)
+
+    // chunk c:  [buffer loads of patch(c+1)]  taps 0-4, max(c+1) -> LDS | XM | DMA filter planes of taps 0-4 (c+1), scale(c+1),
+    //           taps 5-8 with the split of patch(c+1) between them | X1 | DMA planes of taps 5-8, write patch(c+1), fold acc x inv(c),
+    //           wait | X2 | next chunk
+    const int nchunks_all = p.Cin / 16;
+    const int cps = (nchunks_all + ksplit - 1) / ksplit;
+    const int ch_begin = split * cps;
+    const int nchunks = min(nchunks_all, ch_begin + cps);
+    dma_filters(ch_begin, 0, 9);
+    load_patch(ch_begin * 16);
+    publish_max();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    float inv_cur = chunk_scale() * w_inv_scale;  // un-scaling factor of the chunk whose products are accumulating
+    float inv_next = inv_cur;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) split_item(k);
+    store_patch();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // Two workgroups share a CU (one wave each per SIMD).  Launched together they run in lockstep - both in their matrix
+    // phases (each at half rate), then both staging (the pipe idle): measured 2 x 3456 + 4400 cycles per chunk.  The
+    // workgroups of the first round that sit in an odd slot of their CU start half a period late, so that one stages while
+    // the other multiplies; later rounds inherit the offset (partners then finish at different times).
+    if (p.stagger > 0) {
+        const int tg_slot = (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 16 << 6 | 4) & 1);  // hwreg(HW_REG_HW_ID, 16, 4): TG_ID
+        const int flat = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (tg_slot && flat < 512)
+            for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(8);  // 8 x 64 cycles each
+    }
+
+#ifdef XW_STAMP
+    if (lane == 0 && p.mask) {  // which CU / SIMD this wave runs on, shader clock and 100 MHz clock at loop start: slot 63
+        float* d_ = const_cast<float*>(p.mask) + ((((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 64 + 63) * 8;
+        d_[0] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4));
+        d_[1] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_s_memtime());
+        d_[2] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_s_memrealtime());
+    }
+#endif
+    for (int ch = ch_begin; ch < nchunks; ++ch) {
+        const bool more = ch + 1 < nchunks;
+        XW_MARK(0);
+        load_b(bx, 0);
+        load_a(a0, 0, 0);
+        if (more) load_patch((ch + 1) * 16);
+        XW_FENCE();
+        XW_TAP(0, bx, by, true, (void)0, (void)0);
+        XW_TAP(1, by, bx, true, (void)0, (void)0);
+        XW_TAP(2, bx, by, true, (void)0, (void)0);
+        XW_TAP(3, by, bx, true, (void)0, (void)0);
+        XW_TAP(4, bx, by, true, (void)0, if (more) publish_max());  // requests tap 5: patch and planes 20-35 stay across XM
+        XW_MARK(1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        XW_MARK(2);
+        __builtin_amdgcn_s_barrier();  // XM: the filter planes of taps 0-4 are free; the maxima of the next chunk are visible
+        XW_MARK(3);
+        if (more) {
+            dma_filters(ch + 1, 0, 5);
+            inv_next = chunk_scale() * w_inv_scale;
+        }
+        XW_FENCE();
+        XW_TAP(5, by, bx, true, if (more) split_item(0), (void)0);
+        XW_TAP(6, bx, by, true, if (more) split_item(1), (void)0);
+        XW_TAP(7, by, bx, true, if (more) split_item(2), (void)0);
+        XW_TAP(8, bx, by, false, (void)0, (void)0);
+        XW_MARK(4);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // X1: every wave is done reading the patch and the remaining filter planes
+        XW_MARK(5);
+        if (more) {
+            dma_filters(ch + 1, 20, 4);
+            store_patch();
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int row = 0; row < 2; ++row)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    master[t][row][r] = fmaf(acc[t][row][r], inv_cur, master[t][row][r]);  // fold + un-scale (power of two: exact)
+                    acc[t][row][r] = 0.f;
+                }
+        inv_cur = inv_next;
+        XW_MARK(6);
+        if (more) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            XW_MARK(7);
+            __builtin_amdgcn_s_barrier();  // X2: patch and filters of the next chunk are in LDS
+        }
+    }
+
+#ifdef XW_STAMP
+    if (lane == 0 && p.mask) {
+        float* d_ = const_cast<float*>(p.mask) + ((((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 64 + 63) * 8;
+        d_[3] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_s_memtime());
+        d_[4] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_s_memrealtime());
+    }
+#endif
+    // epilogue: lane holds pixel column j of rows y0 + 2 wave + {0, 1}; register r is output channel (r&3)+8*(r>>2)+4*half
+    float* __restrict__ yout = p.y + (int64_t)n * p.Cout * out_plane;
+    const float* __restrict__ om = p.omask ? p.omask + (int64_t)n * p.Cout * out_plane : nullptr;
+    const int ox = x0 + j;
+#pragma unroll
+    for (int row = 0; row < 2; ++row) {
+        const int oy = y0 + 2 * wave + row;
+        const bool pvalid = oy < p.OH && ox < p.OW;
+        const int64_t opix = (int64_t)oy * p.OW + ox;
+        if (p.ksplit > 1) {  // split-K: un-scaled partial sums, finished by conv_splitk_finish_kernel in split order
+            float* wsp = p.ws + (int64_t)blockIdx.z * p.Cout * out_plane;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (pvalid && co < p.Cout) wsp[(int64_t)co * out_plane + opix] = master[t][row][r];
+                }
+            continue;
+        }
+        if (!pvalid) continue;
+        const bool full = co0 + XW_COT <= p.Cout;
+        const int64_t lane_off = (int64_t)(co0 + 4 * half) * out_plane + opix;
+        float* __restrict__ yl = yout + lane_off;
+        const float* __restrict__ oml = OM ? om + lane_off : nullptr;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float prev[16], msk[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cr = t * 32 + (r & 3) + 8 * (r >> 2);
+                const int64_t o = (full || co0 + cr + 4 * half < p.Cout) ? (int64_t)cr * out_plane : 0;
+                prev[r] = 0.f;
+                msk[r] = 1.f;
+                if constexpr (ACC) prev[r] = yl[o];
+                if constexpr (OM) msk[r] = oml[o];
+            }
+            float outv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = master[t][row][r];
+                v += prev[r];
+                if (p.relu) v = v > 0.f ? v : 0.f;
+                outv[r] = msk[r] > 0.f ? v : 0.f;
+            }
+            if (full) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yl[(int64_t)(t * 32 + (r & 3) + 8 * (r >> 2)) * out_plane] = outv[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cr = t * 32 + (r & 3) + 8 * (r >> 2);
+                    if (co0 + cr + 4 * half < p.Cout) yl[(int64_t)cr * out_plane] = outv[r];
+                }
+            }
+        }
+    }
+}
+
+// split-K over 16-channel chunks when the grid leaves most of the 512 workgroup slots (2 per CU) empty
+static int x3w_choose_split(const ConvArgs& a, int n) {
+    const int64_t wgs = (int64_t)((a.OW + 31) / 32) * ((a.OH + XW_ROWS - 1) / XW_ROWS) * ((a.Cout + XW_COT - 1) / XW_COT) * n;
+    const int nchunks = a.Cin / 16;
+    if (wgs >= 2048 || nchunks < 4) return 1;
+    const double out_mb = (double)n * a.Cout * a.OH * a.OW * 4.0 / 1e6;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int ks = 1; ks <= 16 && ks <= nchunks / 2; ++ks) {
+        const double rounds = (double)((wgs * ks + 511) / 512);
+        double cost = rounds * ((double)((nchunks + ks - 1) / ks) + 1.0) * 4.0;  // ~4 us per 16-channel chunk of a full CU
+        if (ks > 1) cost += (ks + 1) * out_mb / 5.0 + 5.0;
+        if (cost < best_cost * 0.97) {
+            best_cost = cost;
+            best = ks;
+        }
+    }
+    return best;
+}
+
+bool conv_x3w_supports(const ConvArgs& a) {
+    return a.Cin % 16 == 0 && (int64_t)a.H * a.W <= (1ll << 25) && a.pad >= 0 && a.pad <= 2;
+}
+
+#ifdef XW_STAMP
+static float* g_xw_stamp = nullptr;
+extern "C" void maua_xw_set_stamp_buffer(float* buf) { g_xw_stamp = buf; }
+#endif
+
+int conv_x3w_launch(const ConvArgs& a, int n, float w_scale, hipStream_t stream) {
+    ConvArgs p = a;
+#ifdef XW_STAMP
+    p.mask = g_xw_stamp;
+#endif
+    p.tiles_x = (a.OW + 31) / 32;
+    const int64_t tiles = (int64_t)p.tiles_x * ((a.OH + XW_ROWS - 1) / XW_ROWS);
+    const int ks = a.ws ? x3w_choose_split(a, n) : 1;
+    p.ksplit = ks;
+    const int64_t cot = (a.Cout + XW_COT - 1) / XW_COT, per_xcd = (tiles + 7) / 8;
+    dim3 grid((unsigned)(per_xcd * 8), (unsigned)cot, (unsigned)(n * ks));
+    const bool acc = ks == 1 && a.accumulate != 0, om = ks == 1 && a.omask != nullptr;
+    const float w_inv = 1.f / w_scale;
+    {
+        static const int stagger = [] {
+            const char* e = getenv("MAUA_X3W_STAGGER");
+            return e ? atoi(e) : 7;
+        }();
+        p.stagger = stagger;
+    }
+    if (acc && om) hipLaunchKernelGGL((conv_x3w_kernel<true, true>), grid, dim3(256), 0, stream, p, w_inv);
+    else if (acc) hipLaunchKernelGGL((conv_x3w_kernel<true, false>), grid, dim3(256), 0, stream, p, w_inv);
+    else if (om) hipLaunchKernelGGL((conv_x3w_kernel<false, true>), grid, dim3(256), 0, stream, p, w_inv);
+    else hipLaunchKernelGGL((conv_x3w_kernel<false, false>), grid, dim3(256), 0, stream, p, w_inv);
+    int rc = check_launch("conv_x3w_kernel");
+    if (rc || ks == 1) return rc;
+    return conv_splitk_finish(a, n, ks, stream);
+}
+
+}  // namespace maua
+
+using namespace maua;
+
+extern "C" {
+
+size_t maua_conv_x3w_bank_bytes(int cout_produced, int cin_consumed) {
+    if (cout_produced <= 0 || cin_consumed <= 0) return 0;
+    const size_t nchunk = (cin_consumed + 15) / 16, ntile = (cout_produced + XW_COT - 1) / XW_COT;
+    return nchunk * ntile * XW_W_BYTES;
+}
+
+int maua_conv_pack_filters_x3w(const float* w_oihw, void* bank_fwd, void* bank_bwd, int cout, int cin, float w_scale,
+                               maua_stream_t stream) {
+    MAUA_REQUIRE(w_oihw && (bank_fwd || bank_bwd) && cout > 0 && cin > 0 && w_scale > 0.f, MAUA_E_INVAL,
+                 "conv_pack_filters_x3w: bad args");
+    if (bank_fwd) {
+        hipLaunchKernelGGL(pack_x3w_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, w_oihw, (unsigned short*)bank_fwd, cout,
+                           cin, 0, w_scale);
+        int rc = check_launch("pack_x3w_kernel");
+        if (rc) return rc;
+    }
+    if (bank_bwd) {
+        hipLaunchKernelGGL(pack_x3w_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, w_oihw, (unsigned short*)bank_bwd, cout,
+                           cin, 1, w_scale);
+        return check_launch("pack_x3w_kernel");
+    }
+    return MAUA_OK;
+}
+
+int maua_conv_x3w_supported(int cin, int h, int w, int pad) {
+    ConvArgs a{};
+    a.Cin = cin;
+    a.H = h;
+    a.W = w;
+    a.pad = pad;
+    return cin > 0 && h > 0 && w > 0 && conv_x3w_supports(a) ? 1 : 0;
+}
+
+size_t maua_conv_x3w_workspace_bytes(int n, int cin, int h, int w, int cout, int pad) {
+    if (n <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || pad < 0) return 0;
+    ConvArgs a{};
+    a.Cin = cin;
+    a.Cout = cout;
+    a.OH = h + 2 * pad - 2;
+    a.OW = w + 2 * pad - 2;
+    if (a.OH <= 0 || a.OW <= 0) return 0;
+    const int ks = x3w_choose_split(a, n);
+    return ks > 1 ? (size_t)n * ks * cout * a.OH * a.OW * sizeof(float) : 0;
+}
+
+int maua_conv3x3_x3w(const float* x, const void* bank, float w_scale, const float* bias, const float* out_relu_mask, float* y,
+                     int n, int cin, int h, int w, int cout, int pad, int relu, int accumulate, void* workspace,
+                     size_t workspace_bytes, maua_stream_t stream) {
+    MAUA_REQUIRE(x && bank && y && w_scale > 0.f, MAUA_E_INVAL, "conv3x3_x3w: bad args");
+    MAUA_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0 && pad >= 0 && pad <= 2, MAUA_E_INVAL, "conv3x3_x3w: bad dims");
+    MAUA_REQUIRE(h + 2 * pad >= 3 && w + 2 * pad >= 3, MAUA_E_UNSUPPORTED, "conv3x3_x3w: input smaller than the filter");
+    ConvArgs a{};
+    a.x = x;
+    a.w6 = bank;
+    a.bias = bias;
+    a.omask = out_relu_mask;
+    a.y = y;
+    a.Cin = cin;
+    a.H = h;
+    a.W = w;
+    a.Cout = cout;
+    a.OH = h + 2 * pad - 2;
+    a.OW = w + 2 * pad - 2;
+    a.pad = pad;
+    a.relu = relu;
+    a.accumulate = accumulate;
+    MAUA_REQUIRE(conv_x3w_supports(a), MAUA_E_UNSUPPORTED, "conv3x3_x3w: needs cin %% 16 == 0 and a plane of at most 2^25 pixels");
+    a.ws = (workspace && workspace_bytes >= maua_conv_x3w_workspace_bytes(n, cin, h, w, cout, pad)) ? (float*)workspace : nullptr;
+    return conv_x3w_launch(a, n, w_scale, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -171,7 +171,9 @@ class StyleEngine:
                     ws = max(ws, hip.conv_x6_workspace_bytes(n, cin, h, w, cout, s.pad),
                              hip.conv_x6_workspace_bytes(n, cout, oh, ow, cin, 2 - s.pad),
                              hip.conv_x3_workspace_bytes(n, cin, h, w, cout, s.pad),
-                             hip.conv_x3_workspace_bytes(n, cout, oh, ow, cin, 2 - s.pad))
+                             hip.conv_x3_workspace_bytes(n, cout, oh, ow, cin, 2 - s.pad),
+                             hip.conv_x3w_workspace_bytes(n, cin, h, w, cout, s.pad),
+                             hip.conv_x3w_workspace_bytes(n, cout, oh, ow, cin, 2 - s.pad))
         self.ws = torch.empty(ws, dtype=torch.uint8, device=dev)
         self.x_static = torch.empty(self.shape, device=dev)
 

@@ -32,6 +32,11 @@ SIGNATURES = {
     "maua_conv_x6_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "maua_conv_x3_bank_bytes": (c_sz, [c_i, c_i]),
     "maua_conv_pack_filters_x3": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_p]),
+    "maua_conv_x3w_bank_bytes": (c_sz, [c_i, c_i]),
+    "maua_conv_pack_filters_x3w": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_p]),
+    "maua_conv_x3w_supported": (c_i, [c_i, c_i, c_i, c_i]),
+    "maua_conv_x3w_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    "maua_conv3x3_x3w": (c_i, [c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "maua_conv_kxk_x3_bank_bytes": (c_sz, [c_i, c_i, c_i]),
     "maua_conv_pack_filters_kxk_x3": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p]),
     "maua_conv_kxk_x3_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
@@ -231,6 +236,39 @@ def conv3x3_x3(x, bank, w_scale, bias, cout, pad, relu, out=None, out_relu_mask=
     wp, wn = _ws_args(workspace, conv_x3_workspace_bytes(n, cin, h, w, cout, pad) if workspace is None else 0, x.device)
     _check(lib().maua_conv3x3_x3(_ptr(_f32(x, "x")), bank.data_ptr(), float(w_scale), _ptr(bias), _ptr(out_relu_mask), _ptr(out), n,
                                  cin, h, w, cout, pad, int(relu), int(accumulate), wp, wn, _stream()), "maua_conv3x3_x3")
+    return out
+
+
+def conv_pack_filters_x3w(w):
+    """OIHW 3x3 weights -> (forward bank, backward-data bank, w_scale) for conv_x3w.hip (16-channel chunks; same split and
+    the same power-of-two filter scale as conv_pack_filters_x3)."""
+    import math
+    cout, cin = w.shape[:2]
+    m = float(w.abs().max())
+    w_scale = 2.0 ** (5 - math.floor(math.log2(m))) if m > 0 and math.isfinite(m) else 1.0
+    wc = _f32(w, "w").contiguous()
+    bf = torch.empty(lib().maua_conv_x3w_bank_bytes(cout, cin), dtype=torch.uint8, device=w.device)
+    bb = torch.empty(lib().maua_conv_x3w_bank_bytes(cin, cout), dtype=torch.uint8, device=w.device)
+    _check(lib().maua_conv_pack_filters_x3w(_ptr(wc), bf.data_ptr(), bb.data_ptr(), cout, cin, w_scale, _stream()),
+           "maua_conv_pack_filters_x3w")
+    return bf, bb, w_scale
+
+
+def conv_x3w_supported(cin, h, w, pad):
+    return bool(lib().maua_conv_x3w_supported(int(cin), int(h), int(w), int(pad)))
+
+
+def conv_x3w_workspace_bytes(n, cin, h, w, cout, pad):
+    return lib().maua_conv_x3w_workspace_bytes(n, cin, h, w, cout, pad)
+
+
+def conv3x3_x3w(x, bank, w_scale, bias, cout, pad, relu, out=None, out_relu_mask=None, accumulate=False, workspace=None):
+    n, cin, h, w = x.shape
+    if out is None:
+        out = torch.empty(n, cout, h + 2 * pad - 2, w + 2 * pad - 2, device=x.device, dtype=torch.float32)
+    wp, wn = _ws_args(workspace, conv_x3w_workspace_bytes(n, cin, h, w, cout, pad) if workspace is None else 0, x.device)
+    _check(lib().maua_conv3x3_x3w(_ptr(_f32(x, "x")), bank.data_ptr(), float(w_scale), _ptr(bias), _ptr(out_relu_mask), _ptr(out), n,
+                                  cin, h, w, cout, pad, int(relu), int(accumulate), wp, wn, _stream()), "maua_conv3x3_x3w")
     return out
 
 

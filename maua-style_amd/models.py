@@ -46,6 +46,13 @@ def _x3_enabled():
     return os.environ.get("MAUA_CONV_X3", "1") == "1"
 
 
+def _x3w_enabled():
+    """MAUA_CONV_X3W: "1" (default) = layers whose consumed channel count is a multiple of 16 run the wide-tile fp16x3 kernel
+    (conv_x3w.hip: 16-channel chunks, four accumulators per wave, two workgroups per CU); "0" = conv_x3.hip everywhere."""
+    import os
+    return os.environ.get("MAUA_CONV_X3W", "1") == "1"
+
+
 def conv3x3_mfma(x, mod, backward, out=None, out_relu_mask=None, relu=False, workspace=None):
     """The fp32-accurate reduced-width matrix-core convolution of a 3x3 stride-1 layer (forward, or backward-data when
     `backward`): fp16x3 or bf16x6 according to MAUA_CONV_X3."""
@@ -55,6 +62,10 @@ def conv3x3_mfma(x, mod, backward, out=None, out_relu_mask=None, relu=False, wor
     else:
         cout, p, bias = mod.out_channels, pad, mod.bias_device()
     consumed = mod.out_channels if backward else mod.in_channels
+    if _x3_enabled() and _x3w_enabled() and hip.conv_x3w_supported(consumed, x.shape[2], x.shape[3], p):
+        bf, bb, wsc = mod.banks3w()
+        return hip.conv3x3_x3w(x, bb if backward else bf, wsc, bias, cout, p, relu, out=out, out_relu_mask=out_relu_mask,
+                               workspace=workspace)
     if _x3_enabled() and consumed > 4:
         # (the image layer, 3 input channels, stays on the exact bf16x6 products: it differences neighbouring pixels of large
         # common magnitude - the one place where the 2 bits fp16x3 drops could show - and costs one partly empty chunk)
@@ -156,6 +167,15 @@ class Conv2d(nn.Conv2d):
             self._banks3 = hip.conv_pack_filters_x3(self.weight.detach().contiguous())
             self._bank3_key = key
         return self._banks3
+
+    def banks3w(self):
+        """Banks of the wide-tile fp16x3 kernel (conv_x3w.hip): the same pre-split, pre-scaled fp16 pairs as banks3 in
+        16-channel chunks, [chunk][cout tile][tap][part][octet][co][8 ch]."""
+        key = (self.weight.data_ptr(), self.weight._version, self.weight.device)
+        if getattr(self, "_bank3w_key", None) != key:
+            self._banks3w = hip.conv_pack_filters_x3w(self.weight.detach().contiguous())
+            self._bank3w_key = key
+        return self._banks3w
 
     def banks_kxk(self):
         """fp16x2 pre-split, pre-scaled banks (forward, backward-data, filter scale) of the k x k fp16x3 kernel."""
