@@ -52,6 +52,11 @@ class StyleEngine:
         self.steps = self._plan(list(net))
         self.shape = None
         self.graph, self.graph_key = None, None
+        # B > 1 frames are either ONE problem (img_vid's window: per-frame terms over B plus the cross-frame dynamic Gram term)
+        # or, with `independent`, B separate single-frame problems evaluated together (vid_img's frames without optical
+        # flow): every frame gets exactly the B = 1 arithmetic - its own loss slots, its own total - while the convolutions
+        # and pools run on the whole batch so that small images still fill the chip.
+        self.independent = False
         # 3x3 stride-1 convs run on the bf16 matrix cores with a 3-way operand split (fp32 accuracy, conv_x6.hip) unless
         # MAUA_CONV_X6=0 asks for the fp32-MFMA kernels (A/B comparisons)
         mode = os.environ.get("MAUA_CONV_X6", "1")  # "1" both passes, "fwd" / "bwd" one of them, "0" off
@@ -110,11 +115,12 @@ class StyleEngine:
 
     # -- buffers ---------------------------------------------------------------------------------------
     def _prepare(self, x):
-        if self.shape == tuple(x.shape):
+        if self.shape == tuple(x.shape) and getattr(self, "prepared_independent", None) == self.independent:
             return
         dev = x.device
         B = x.shape[0]
         self.shape = tuple(x.shape)
+        self.prepared_independent = self.independent
         self.graph = None
         shapes = {0: tuple(x.shape)}
         for s in self.steps:
@@ -130,15 +136,20 @@ class StyleEngine:
         # dynamic Gram term of a StyleLoss - each with its own slot behind the per-module ones
         self.terms = {}
         n_slots = max(len(self.losses), 1)
-        if B > 1:
+        if B > 1 and not self.independent:
             for s in self.steps:
                 if s.kind in ("style", "content"):
                     count = B + (1 if s.kind == "style" else 0)
                     self.terms[id(s)] = list(range(n_slots, n_slots + count))
                     n_slots += count
-        self.slots_all = torch.zeros(n_slots, device=dev)
-        self.slots = self.slots_all[:max(len(self.losses), 1)]
-        self.total = torch.zeros(1, device=dev)
+        if B > 1 and self.independent:  # one row of slots and one total per frame
+            self.slots_all = torch.zeros(B, n_slots, device=dev)
+            self.slots = self.slots_all
+            self.total = torch.zeros(B, device=dev)
+        else:
+            self.slots_all = torch.zeros(n_slots, device=dev)
+            self.slots = self.slots_all[:max(len(self.losses), 1)]
+            self.total = torch.zeros(1, device=dev)
         self.gram, self.dmat, self.mean = {}, {}, {}
         self.gram_d, self.dmat_d, self.mean_d = {}, {}, {}
         ws = hip.reduce_workspace_bytes(max(t.numel() for t in self.gbuf.values()))
@@ -151,7 +162,7 @@ class StyleEngine:
                 self.mean[id(s)] = (torch.empty(B, c, device=dev) if B > 1 else torch.empty(c, device=dev)) \
                     if s.mod.use_covariance else None
                 ws = max(ws, hip.gram_workspace_bytes(c, hw), 4 * c + 256)
-                if B > 1:  # the dynamic term's (B C) x (B C) Gram over the whole window
+                if B > 1 and not self.independent:  # the dynamic term's (B C) x (B C) Gram over the whole window
                     self.gram_d[id(s)] = torch.empty(B * c, B * c, device=dev)
                     self.dmat_d[id(s)] = torch.empty(B * c, B * c, device=dev)
                     self.mean_d[id(s)] = torch.empty(B * c, device=dev) if s.mod.use_covariance else None
@@ -219,7 +230,10 @@ class StyleEngine:
                 return False  # temporal module without a target (loss.py:46-47) or never captured
             if tuple(m.target.shape[1:]) != tuple(shapes_src[1:]):
                 return False  # loss.py:44
-            if shapes_src[0] > 1 and (m.weights is not None or m.target.shape[0] != 1):
+            if shapes_src[0] > 1 and self.independent:
+                if m.weights is not None or m.target.shape[0] != shapes_src[0]:
+                    raise UnsupportedNet("independent frames need one unweighted content target per frame")
+            elif shapes_src[0] > 1 and (m.weights is not None or m.target.shape[0] != 1):
                 raise UnsupportedNet("weighted / multi-frame-target ContentLoss on B > 1 frames runs on the module path")
             if m.weights is not None:
                 w = m.weights
@@ -285,6 +299,16 @@ class StyleEngine:
                 hip.relu_(a[s.src])
             elif s.kind == "pool":
                 hip.pool2d_fwd(a[s.src], s.k, s.stride, s.ceil, s.mode, out=a[s.dst])
+            elif s.kind == "style" and self.independent and a[s.src].shape[0] > 1 and self._active(s, a[s.src].shape):
+                f = a[s.src]
+                c, n = f.shape[1], f[0].nelement()
+                lw, gw = self._coefficients(s)  # the single-frame weights: static + dynamic term of the same Gram
+                for b in range(f.shape[0]):
+                    mean_b = self.mean[id(s)][b] if s.mod.use_covariance else None
+                    self._timed("gram_fwd", 2 * c * c * (n // c), n * 4 + c * c * 4, lambda: hip.gram_fwd(
+                        f[b:b + 1], 1.0 / n, s.mod.use_covariance, out=self.gram[id(s)][b], mean_out=mean_b, workspace=self.ws))
+                    hip.mse_fwd_bwd(self.gram[id(s)][b], s.mod.target, self.dmat[id(s)][b], lw / (c * c), gw * 4.0 / (c * c) / n,
+                                    False, self.slots_all[b, s.slot:s.slot + 1], workspace=self.ws)
             elif s.kind == "style" and self._active(s, a[s.src].shape) and a[s.src].shape[0] > 1:
                 f = a[s.src]
                 B, c, n = f.shape[0], f.shape[1], f[0].nelement()
@@ -339,8 +363,29 @@ class StyleEngine:
             return final_writer.get(s.src) is s and s.src in relu_acts
 
         cur = None  # activation index whose gradient buffer currently holds d loss / d act
+        indep = self.independent and x.shape[0] > 1
         for s in reversed(self.steps):
-            if s.kind == "style" and a[s.src].shape[0] > 1:
+            if indep and s.kind in ("style", "content", "tv"):
+                if s.kind != "tv" and not self._active(s, a[s.src].shape):
+                    continue
+                f = a[s.src]
+                acc = cur == s.src
+                for b in range(f.shape[0]):
+                    slot = self.slots_all[b, s.slot:s.slot + 1]
+                    if s.kind == "style":
+                        c, n = f.shape[1], f[0].nelement()
+                        self._timed("gram_bwd", 2 * c * c * (n // c), n * 4 * 3 + c * c * 4, lambda: hip.gram_bwd(
+                            self.dmat[id(s)][b], f[b], self.mean[id(s)][b] if s.mod.use_covariance else None, g[s.src][b], acc,
+                            workspace=self.ws, relu_mask=f[b] if premask(s) else None))
+                    elif s.kind == "content":
+                        lw, gw = self._coefficients(s)
+                        n = f[0].nelement()
+                        hip.mse_fwd_bwd(f[b], s.mod.target[b], g[s.src][b], lw / n, gw * 2.0 / n, acc, slot, workspace=self.ws,
+                                        mask_grad_by_x=premask(s))
+                    else:
+                        hip.tv_fwd_bwd(f[b:b + 1], g[0][b:b + 1], s.mod.strength, acc, slot, workspace=self.ws)
+                cur = s.src
+            elif s.kind == "style" and a[s.src].shape[0] > 1:
                 if self._active(s, a[s.src].shape):
                     f = a[s.src]
                     B, c, n = f.shape[0], f.shape[1], f[0].nelement()
@@ -425,6 +470,10 @@ class StyleEngine:
                 cur = s.src
         if cur != 0:
             hip.fill_(g[0], 0.0)
+        if indep:
+            for b in range(x.shape[0]):
+                hip.sum_small(self.slots_all[b], self.total[b:b + 1])
+            return
         hip.sum_small(self.slots_all, self.total)
         for s in self.steps:  # B > 1: a module's reported loss is the sum of its terms (after the total, which has them once)
             if id(s) in self.terms:

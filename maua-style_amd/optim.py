@@ -56,7 +56,7 @@ def set_content_targets(net, content_image, args):
     _describe("Capturing content targets...", args)
     image = _device_image(content_image, args)
     eng = _engine_of(net)
-    if eng is not None and image.shape[0] == 1:
+    if eng is not None and (image.shape[0] == 1 or eng.independent):
         try:
             eng.capture_content(image)
             return
@@ -157,8 +157,11 @@ GRAPH_MIN_ITERS = 128
 class PixelOptimizer:
     """The iteration loop for one image: fused feval + device-side optimizer step."""
 
-    def __init__(self, net, losses, init, args, planned_iters=None, grad_hook=None):
+    def __init__(self, net, losses, init, args, planned_iters=None, grad_hook=None, independent=False):
+        """`independent`: `init` holds B separate single-frame problems (vid_img's frames without optical flow) that are
+        evaluated together - one L-BFGS state (or Adam moment pair) per frame, the single-frame loss arithmetic per frame."""
         self.args = args
+        self.independent = bool(independent) and init.shape[0] > 1
         self.grad_hook = grad_hook  # in-place edit of the gradient before the optimiser sees it (img_vid's overlap masking)
         try:
             self.engine = getattr(net, "_maua_engine", None) or engine_mod.StyleEngine(net, losses)
@@ -169,8 +172,14 @@ class PixelOptimizer:
         self.x = _device_image(init, args).clone()
         self.kind = args.optimizer
         self.step_count = 0
+        if self.engine is not None:
+            self.engine.independent = self.independent
+        elif self.independent:
+            raise engine_mod.UnsupportedNet("independent frame batches need the fused engine")
+        self.frames = [self.x[b] for b in range(self.x.shape[0])] if self.independent else [self.x]
         if self.kind == "lbfgs":
-            self.state = hip.LbfgsState(self.x.numel(), int(args.lbfgs_num_correction), self.x.device)
+            self.states = [hip.LbfgsState(f.numel(), int(args.lbfgs_num_correction), self.x.device) for f in self.frames]
+            self.state = self.states[0]
         elif self.kind == "adam":
             self.m, self.v = th.zeros_like(self.x), th.zeros_like(self.x)
         else:
@@ -189,6 +198,7 @@ class PixelOptimizer:
     def feval(self):
         """(loss slots, total, gradient) at the current image - device tensors, no sync."""
         if self.engine is not None:
+            self.engine.independent = self.independent
             try:
                 return self.engine.feval(self.x, capture=self.use_graph and self.kind != "lbfgs" and self.engine.timer is None)
             except engine_mod.UnsupportedNet:
@@ -212,17 +222,30 @@ class PixelOptimizer:
             mod.loss = 0
         return slots, total.detach().reshape(1), x.grad.contiguous()
 
+    def _lbfgs_move(self, grad, total):
+        """One L-BFGS update per frame (a single one unless `independent`): device-side, no sync."""
+        a = self.args
+        for b, (st, xf) in enumerate(zip(self.states, self.frames)):
+            gb = grad[b] if self.independent else grad
+            lb = None
+            if th.is_tensor(total) and total.is_cuda:
+                lb = total[b:b + 1] if self.independent else total
+            st.iterate(xf, gb, 1.0, float(a.lbfgs_tolerance_change), float(a.lbfgs_tolerance_grad), lb)
+
+    def stopped(self):
+        """Every frame's L-BFGS has hit one of its stop tests (host sync; called every 25 iterations)."""
+        return self.kind == "lbfgs" and all(st.status()["stopped"] for st in self.states)
+
     def _step_lbfgs_graph(self):
         """feval + L-BFGS update as one graph replay; the first call runs eagerly (a real iteration) and captures."""
         if self._graph is not None:
             self._graph.replay()
             self.step_count += 1
             return self.engine.slots, self.engine.total
-        a = self.args
         slots, total, grad = self.engine.feval(self.x)
         if self.grad_hook is not None:
             self.grad_hook(grad)
-        self.state.iterate(self.x, grad, 1.0, float(a.lbfgs_tolerance_change), float(a.lbfgs_tolerance_grad), total)
+        self._lbfgs_move(grad, total)
         self.step_count += 1
         th.cuda.synchronize()
         graph = th.cuda.CUDAGraph()
@@ -230,8 +253,7 @@ class PixelOptimizer:
             self.engine._run(self.x)
             if self.grad_hook is not None:
                 self.grad_hook(self.engine.gbuf[0])
-            self.state.iterate(self.x, self.engine.gbuf[0], 1.0, float(a.lbfgs_tolerance_change), float(a.lbfgs_tolerance_grad),
-                               self.engine.total)
+            self._lbfgs_move(self.engine.gbuf[0], self.engine.total)
         self._graph = graph
         return slots, total
 
@@ -248,8 +270,7 @@ class PixelOptimizer:
         self.step_count += 1
         a = self.args
         if self.kind == "lbfgs":
-            self.state.iterate(self.x, grad, 1.0, float(a.lbfgs_tolerance_change), float(a.lbfgs_tolerance_grad),
-                               total if th.is_tensor(total) and total.is_cuda else None)
+            self._lbfgs_move(grad, total)
         else:
             hip.adam_step(self.x, grad, self.m, self.v, self.step_count, float(a.learning_rate))
         return slots, total
@@ -273,9 +294,9 @@ def _run_iterations(opt, num_iters, args, save_offset=0, save_total=None):
         if not args.verbose and not (args.optimizer == "adam" and i == 1):
             PBAR.update(1)
         if args.print_iter > 0 and i % args.print_iter == 0 and args.verbose:
-            print(f"Iteration {i} / {args.num_iters}, Loss: {float(total)}")
-        if args.optimizer == "lbfgs" and i % 25 == 0 and opt.state.status()["stopped"]:
-            break  # g.d > -tolerance_change: the reference breaks out of LBFGS.step here
+            print(f"Iteration {i} / {args.num_iters}, Loss: {float(total.sum())}")
+        if args.optimizer == "lbfgs" and i % 25 == 0 and opt.stopped():
+            break  # g.d > -tolerance_change (or another stop test): the reference breaks out of LBFGS.step here
 
 
 def video_windows(init, styles, window):
@@ -340,6 +361,41 @@ def _optimize_video(content, styles, init, num_iters, args, net=None, losses=Non
     return output
 
 
+def optimize_frames(contents, styles, inits, num_iters, args, net, losses):
+    """B independent calls of `optimize` (same network, same style images, one content frame and one initial image each -
+    the frames of vid_img without optical flow, reference style.py:192-290) evaluated as ONE batch: the convolutions and
+    pools run on all B frames at once, every frame keeps its own loss terms and its own optimiser state, and each frame's
+    result is bit-identical to what a separate call gives.  Tensors may live on the device; returns the (B,3,H,W) device
+    tensor."""
+    limit_host_threads()
+    if contents.shape[0] != inits.shape[0]:
+        raise ValueError("one content frame per initial image")
+    eng = _engine_of(net)
+    if eng is None:
+        raise engine_mod.UnsupportedNet("frame batches need a network the fused engine covers")
+    eng.independent = contents.shape[0] > 1
+    if not args.verbose:
+        PBAR.reset()
+        PBAR.total = num_iters
+        PBAR.refresh()
+    set_content_targets(net, contents, args)
+    key = (tuple((s.data_ptr(), tuple(s.shape), s._version) for s in styles), tuple(args.style_blend_weights))
+    if getattr(net, "_maua_style_key", None) != key or any(m.target.nelement() == 0 for m in net.style_losses):
+        set_style_targets(net, styles, args)
+        net._maua_style_key = key
+        net._maua_style_refs = list(styles)
+    for mod in losses:
+        mod.mode = "loss"
+    if args.normalize_weights:
+        for mod in net.content_losses + net.style_losses + net.temporal_losses:
+            mod.strength = mod.strength / max(mod.target.size())
+    opt = PixelOptimizer(net, losses, inits, args, planned_iters=num_iters, independent=True)
+    _run_iterations(opt, num_iters, args)
+    for mod in losses:
+        mod.loss = 0
+    return opt.x.detach()
+
+
 def optimize(content, styles, init, num_iters, args, net=None, losses=None, keep_on_device=False):
     """Optimise `init` towards `content` / `styles`; returns a CPU fp32 tensor shaped like `init` (the reference's contract,
     optim.py:249).  Inputs may already live on the device; `keep_on_device=True` (the workflow drivers of style.py) returns
@@ -359,6 +415,9 @@ def optimize(content, styles, init, num_iters, args, net=None, losses=None, keep
         PBAR.total = num_iters
         PBAR.refresh()
 
+    eng = _engine_of(net)
+    if eng is not None:
+        eng.independent = False
     set_content_targets(net, content, args)
     # Style targets depend only on the style images and blend weights.  The reference recaptures them on every call
     # (style.py:178 keeps the hoisting commented out); the result is identical, so a prebuilt net that is called again

@@ -31,7 +31,7 @@ import dist
 import load
 import models
 import optim
-from utils import limit_host_threads, match_histogram, name
+from utils import draw_match_noise, limit_host_threads, match_histogram, name
 
 
 def _scaled_styles(style_images_big, content_area, args):
@@ -254,17 +254,40 @@ def _vid_img_flow(args, output_dir, frames, style_images_big, content_size):
         th.cuda.empty_cache()
 
 
-def _finish_frame(out, content, path, original_colors):
-    """Writing one finished frame (reference style.py:294-297): deprocess, optional colour transfer, PNG."""
-    disp = load.deprocess(out.clone())
+def _finish_frame(img, content_img, path, original_colors):
+    """Writing one finished frame (reference style.py:294-297): optional colour transfer, PNG.  Host only (the deprocessing
+    kernel already ran): safe on the background writer thread while the next batch optimises."""
     if original_colors == 1:
-        disp = load.original_colors(load.deprocess(content.clone()), disp)
-    disp.save(path)
+        img = load.original_colors(content_img, img)
+    img.save(path)
+
+
+def frames_per_batch(size):
+    """How many independent frames of side `size` are optimised together: enough pixels to fill the chip (4 x 1024^2), at
+    most 16 frames; MAUA_FRAME_BATCH overrides (1 = the reference's frame-by-frame loop)."""
+    forced = int(os.environ.get("MAUA_FRAME_BATCH", "0"))
+    if forced > 0:
+        return forced
+    return max(1, min(16, (4 << 20) // max(1, int(size) * int(size))))
+
+
+def _optimize_group(contents, style_images, inits, num_iters, args, net, losses):
+    """B frames at once through optim.optimize_frames; networks outside the fused plan go frame by frame."""
+    import engine
+    try:
+        return optim.optimize_frames(th.cat(contents), style_images, th.cat(inits), num_iters, args, net, losses)
+    except engine.UnsupportedNet:
+        return th.cat([optim.optimize(c, style_images, p, num_iters, args, net, losses, keep_on_device=True)
+                       for c, p in zip(contents, inits)])
 
 
 def vid_img(args):
     """Per-frame stylisation.  With a flow cache under <output_dir>/flow the reference's temporally consistent loop
-    runs (sequential, rank 0); without one the frames are independent and are sharded over the ranks of the job."""
+    runs (sequential, rank 0); without one the frames are independent problems (reference style.py:192-290 minus flow): they
+    are sharded over the ranks of the job, and every rank optimises its frames in batches (`frames_per_batch`) - the
+    convolutions of a batch run together, each frame keeps its own losses and optimiser state, results are bit-identical to
+    the frame-by-frame loop.  Frames stay on the device from decoding to the 8-bit image; the global RNG is drawn from in the
+    frame-by-frame order (colour-matching jitter, random initialisation)."""
     limit_host_threads()
     rank, _, world = dist.init()
     output_dir = args.output_dir + "/" + name(args.content) + "_" + "_".join([name(s) for s in args.style])
@@ -279,8 +302,11 @@ def vid_img(args):
     lo, hi = dist.shard_range(len(frames), rank, world)
     mine = frames[lo:hi]
     content_size = np.array(load.preprocess(frames[0]).size()[-2:])
-    style_images_big = load.process_style_images(args)
+    on_gpu = th.cuda.is_available()
+    up = (lambda t: t.cuda()) if on_gpu else (lambda t: t)
+    style_images_big = [up(t) for t in load.process_style_images(args)]
     passes = max(1, args.passes_per_scale)
+    mode = args.match_histograms
 
     prev_size = None
     writer, pending = concurrent.futures.ThreadPoolExecutor(max_workers=2), {}
@@ -294,33 +320,47 @@ def vid_img(args):
         optim.set_model_args(args, current_size)
         net, losses = models.load_model(args)
         dist.broadcast_network(net, src=0)
+        batch = frames_per_batch(current_size)
 
         for pass_n in range(passes):
+            out_path = lambda frame: "%s/%s/%s_%s.png" % (output_dir, current_size, pass_n + 1, name(frame))
+            todo = []
             for frame in mine:
-                args.output = "%s/%s/%s_%s.png" % (output_dir, current_size, pass_n + 1, name(frame))
-                if os.path.isfile(args.output):
+                if os.path.isfile(out_path(frame)):
                     print("Skipping pass: %s, frame: %s. File already exists." % (pass_n + 1, name(frame)))
-                    continue
-                print("Optimizing... size: %s, pass: %s, frame: %s" % (current_size, pass_n + 1, name(frame)))
-                content = F.interpolate(load.preprocess(frame), scale_factor=content_scale, mode="bilinear",
-                                        align_corners=False)
-                content = match_histogram(content, style_images_big[0], mode=args.match_histograms)
-                if size_n == 0 and pass_n == 0:
-                    pastiche = th.randn(content.size()).mul(0.001) if args.init == "random" else content.clone()
-                else:  # previous result of this frame: last pass of the previous size, or previous pass of this size
-                    src = ("%s/%s/%s_%s.png" % (output_dir, prev_size, passes, name(frame)) if pass_n == 0 else
-                           "%s/%s/%s_%s.png" % (output_dir, current_size, pass_n, name(frame)))
-                    if src in pending:  # still being written by the background writer
-                        pending.pop(src).result()
-                    pastiche = F.interpolate(load.preprocess(src), size=content.size()[2:], mode="bilinear",
-                                             align_corners=False)
-                out = optim.optimize(content, style_images, pastiche, num_iters // passes, args, net, losses)
-                out = match_histogram(out.detach().cpu(), style_images_big[0], mode=args.match_histograms)  # global RNG: stays here
-                # deprocessing and PNG encoding of this frame run beside the next frame's optimisation
-                pending[str(args.output)] = writer.submit(_finish_frame, out, content, str(args.output), args.original_colors)
+                else:
+                    todo.append(frame)
+            for g0 in range(0, len(todo), batch):
+                group = todo[g0:g0 + batch]
+                contents, inits, post_noise = [], [], []
+                for frame in group:  # host phase, frame by frame: every global-RNG draw in the reference's order
+                    print("Optimizing... size: %s, pass: %s, frame: %s" % (current_size, pass_n + 1, name(frame)))
+                    content = _resize(up(load.preprocess(frame)), scale_factor=content_scale)
+                    content = match_histogram(content, style_images_big[0], mode=mode)
+                    if size_n == 0 and pass_n == 0:
+                        pastiche = up(th.randn(content.size()).mul(0.001)) if args.init == "random" else content.clone()
+                    else:  # previous result of this frame: last pass of the previous size, or previous pass of this size
+                        src = ("%s/%s/%s_%s.png" % (output_dir, prev_size, passes, name(frame)) if pass_n == 0 else
+                               "%s/%s/%s_%s.png" % (output_dir, current_size, pass_n, name(frame)))
+                        if src in pending:  # still being written by the background writer
+                            pending.pop(src).result()
+                        pastiche = _resize(up(load.preprocess(src)), size=tuple(int(v) for v in content.size()[2:]))
+                    post_noise.append(draw_match_noise(content.shape, style_images_big[0], mode=mode))
+                    contents.append(content)
+                    inits.append(pastiche)
+                args.output = out_path(group[0])
+                outs = _optimize_group(contents, style_images, inits, num_iters // passes, args, net, losses)
+                for k, frame in enumerate(group):
+                    out = match_histogram(outs[k:k + 1], style_images_big[0], mode=mode, _noise=post_noise[k])
+                    # deprocessing = one kernel + a 3-byte-per-pixel download, here; colour transfer and PNG encoding of this
+                    # batch run on the writer threads beside the next batch's optimisation
+                    img = load.deprocess(out)
+                    cimg = load.deprocess(contents[k]) if args.original_colors == 1 else None
+                    pending[out_path(frame)] = writer.submit(_finish_frame, img, cimg, out_path(frame), args.original_colors)
         prev_size = current_size
         del net
-        th.cuda.empty_cache()
+        if on_gpu:
+            th.cuda.empty_cache()
     for fut in pending.values():  # surface any error of the background writer
         fut.result()
     writer.shutdown()

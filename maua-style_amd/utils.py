@@ -83,7 +83,25 @@ def _source_frames(source, per_frame):
     return hit[0]
 
 
-def match_histogram(target_tensor, source_tensor, eps=1e-2, mode="avg"):
+def draw_match_noise(target_shape, source_tensor, mode="avg"):
+    """The global-RNG draws one match_histogram call makes (torch jitter, numpy frame choice), in its order, WITHOUT running
+    it: lets a caller that batches frames draw for every frame in the reference's per-frame order first and hand each draw
+    to the matching call later (`_noise=`)."""
+    if not mode:
+        return None
+    per_frame = mode == "avg"
+    sources = source_tensor if isinstance(source_tensor, list) else [source_tensor]
+    B, _, H, W = target_shape
+    out = []
+    for source in sources:
+        pick = None if per_frame else int(np.random.randint(0, source.shape[0]))
+        sh, sw = source.shape[2], source.shape[3]
+        for _ in range(B if per_frame else 1):
+            out.append((pick, th.randn(size=(1 if per_frame else B, W, H, 3)), th.randn(size=(1, sw, sh, 3))))
+    return out
+
+
+def match_histogram(target_tensor, source_tensor, eps=1e-2, mode="avg", _noise=None):
     """PCA colour transfer of `target_tensor` towards the colour statistics of each source, averaged over sources
     (reference utils.py:96-151; called before / after every scale, style.py:24,67,71, and per frame, style.py:292).
     `mode` falsy -> identity; "avg" -> every target frame against the source's mean frame; anything else -> the whole
@@ -108,16 +126,25 @@ def match_histogram(target_tensor, source_tensor, eps=1e-2, mode="avg"):
     n_solves = len(sources) * (B if per_frame else 1)
     coef = th.empty(n_solves, 16, device=tgt.device)
     plan = []  # (batch view being matched, its slice of `out`, its jitter, coefficient row)
+    drawn = iter(_noise) if _noise is not None else None
     for source in sources:
         src = _source_frames(source, per_frame)
-        if not per_frame:
-            src = src[np.random.randint(0, src.shape[0])][None]  # utils.py:120 (numpy's global RNG, as there)
+        pick = None
+        if not per_frame and drawn is None:
+            pick = np.random.randint(0, src.shape[0])  # utils.py:120 (numpy's global RNG, as there)
         sh, sw = src.shape[2], src.shape[3]
         for idx in range(B if per_frame else 1):
             batch, dst = (tgt[idx:idx + 1], out[idx:idx + 1]) if per_frame else (tgt, out)
-            # utils.py:123-124: randn(size=frame.shape) with the frame viewed as (b, W, H, C) - the layout the kernels index
-            noise_t = th.randn(size=(batch.shape[0], W, H, 3)).to(tgt.device, non_blocking=True)
-            noise_s = th.randn(size=(1, sw, sh, 3)).to(tgt.device, non_blocking=True)
+            if drawn is not None:  # draws made earlier by draw_match_noise, in the reference's order
+                pick, noise_t, noise_s = next(drawn)
+            else:
+                # utils.py:123-124: randn(size=frame.shape) with the frame viewed as (b, W, H, C) - the layout the kernels index
+                noise_t = th.randn(size=(batch.shape[0], W, H, 3))
+                noise_s = th.randn(size=(1, sw, sh, 3))
+            if not per_frame and idx == 0:
+                src = src[pick][None]
+            noise_t = noise_t.to(tgt.device, non_blocking=True)
+            noise_s = noise_s.to(tgt.device, non_blocking=True)
             st_t = hip.channel_stats(batch, noise_t)
             st_s = hip.channel_stats(src[:1], noise_s)
             hip.color_match_solve(st_t, H * W, st_s, sh * sw, eps, coef[len(plan)])

@@ -314,3 +314,35 @@ def test_vid_img_sharded_over_two_ranks_matches_one_rank(tmp_path, weight_files)
     assert sorted(os.listdir(a)) == sorted(os.listdir(b)) == sorted(f"{p}_{i:05d}.png" for p in (1, 2) for i in range(5))
     for f in os.listdir(a):
         assert np.array_equal(np.asarray(Image.open(a / f)), np.asarray(Image.open(b / f))), f
+
+
+@pytest.mark.parametrize("variant", ["plain", "hist_random_init"])
+def test_vid_img_frame_batches_match_the_frame_by_frame_loop(tmp_path, weight_files, variant):
+    """vid_img optimises its independent frames in batches; MAUA_FRAME_BATCH=1 is the reference's frame-by-frame loop.  The
+    same files bit for bit - also with colour matching on and --init random, where every frame draws from the global RNG
+    (jitter before and after its optimisation, the initial image in between): the batched path draws in the same order."""
+    import synth
+    import load
+    frames_dir = tmp_path / "clip"
+    frames_dir.mkdir()
+    for i, f in enumerate(synth.frames(7, 48)):
+        load.deprocess(f[None].clone()).save(frames_dir / f"{i:05d}.png")
+    scaling = tmp_path / "scaling.json"
+    scaling.write_text(json.dumps({"100000": {"gpu": "0", "multidevice": False}}))
+    flags = ["--transfer_type", "vid_img", "--content", str(frames_dir), "--style", os.path.join(REPO, "tests", "synth_style_256.png"),
+             "--image_sizes", "48,64", "--num_iters", "6,4", "--passes_per_scale", "2", "--model_file", weight_files["vgg19"],
+             "--disable_check", "--scaling_args", str(scaling), "--seed", "0"]
+    flags += ["--no_hist_match", "--init", "content"] if variant == "plain" else ["--init", "random"]
+    outs = {}
+    for batch in ("1", "3"):
+        out = tmp_path / f"out{batch}"
+        env = dict(os.environ, PYTHONPATH=PKG, MAUA_FRAME_BATCH=batch)
+        r = subprocess.run([sys.executable, os.path.join(PKG, "style.py")] + flags + ["--output_dir", str(out)], cwd=PKG, env=env,
+                           capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[batch] = out / "clip_synth_style_256"
+    for size in ("48", "64"):
+        a, b = outs["1"] / size, outs["3"] / size
+        assert sorted(os.listdir(a)) == sorted(os.listdir(b)) and len(os.listdir(a)) == 14
+        for f in os.listdir(a):
+            assert np.array_equal(np.asarray(Image.open(a / f)), np.asarray(Image.open(b / f))), (size, f)

@@ -602,3 +602,42 @@ def test_pixel_gradient_is_as_close_to_fp64_as_the_reference_fp32(weight_files):
         torch.cuda.synchronize()
         ours, theirs = rel_l2(grad.cpu(), g64["grad"]), rel_l2(g32["grad"], g64["grad"])
         assert ours <= 1.5 * theirs, (S, ours, theirs)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# batches of INDEPENDENT frames (vid_img without optical flow): B separate problems evaluated together
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("opt,S,extra", [("lbfgs", 64, []), ("adam", 64, []), ("lbfgs", 96, ["--no_grad_norm", "--pooling", "avg"]),
+                                         ("lbfgs", 128, ["--use_covariance"])])
+def test_frame_batch_is_bit_identical_to_frame_by_frame(weight_files, opt, S, extra):
+    """optim.optimize_frames (B frames through the convolutions at once, per-frame losses and optimiser states, split-K policy
+    per image) against B separate optim.optimize calls on the same prebuilt network: the same bits, frame by frame."""
+    import models
+    import optim
+    B, N = 3, 7
+    style = synth.images(S)[1]
+    contents = torch.cat([synth.images(S, seed=50 + k)[0] for k in range(B)])
+    inits = torch.cat([synth.images(S, seed=60 + k)[2] for k in range(B)])
+    args = product_args(weight_files, extra, optimizer=opt, S=S, N=N)
+    optim.set_model_args(args, S)
+    net, losses = models.load_model(args)
+    together = optim.optimize_frames(contents.cuda(), [style], inits.cuda(), N, args, net, losses).cpu()
+    single = torch.cat([optim.optimize(contents[k:k + 1], [style], inits[k:k + 1].clone(), N, args, net, losses) for k in range(B)])
+    assert together.shape == single.shape
+    for k in range(B):
+        assert torch.equal(together[k], single[k]), (k, rel_l2(together[k], single[k]))
+    assert not torch.equal(together[0], together[1])
+
+
+def test_frame_batch_nin(weight_files):
+    import models
+    import optim
+    B, N, S = 2, 5, 99
+    style = synth.images(S)[1]
+    contents = torch.cat([synth.images(S, seed=70 + k)[0] for k in range(B)])
+    args = product_args(weight_files, NIN_FLAGS + ["--use_covariance"], model="nin", S=S, N=N)
+    optim.set_model_args(args, S)
+    net, losses = models.load_model(args)
+    together = optim.optimize_frames(contents.cuda(), [style], contents.clone().cuda(), N, args, net, losses).cpu()
+    single = torch.cat([optim.optimize(contents[k:k + 1], [style], contents[k:k + 1].clone(), N, args, net, losses) for k in range(B)])
+    assert torch.equal(together, single)
