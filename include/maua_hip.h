@@ -237,6 +237,16 @@ int maua_resize_bilinear(const float* x, float* y, int planes, int h, int w, int
 int maua_deprocess_u8(const float* x_bgr_chw, unsigned char* out_rgb_hwc, int h, int w, float mean_b, float mean_g, float mean_r,
                       maua_stream_t stream);
 
+/* ---- batches of independent frames (vid_img without optical flow, reference style.py:192-290) ---------- */
+/* The convolution entry points take a batch dimension n; deterministic split-K sums its slabs in a fixed order, but HOW MANY
+ * slabs a layer is cut into is a cost-model decision that would depend on n.  To keep a frame's result independent of how
+ * many frames happen to share a launch, the cost models count the frames the CALLER PLANS per launch: the host sets that
+ * number once per job (style.vid_img: frames_per_batch(size); 1 = single images, the default) and every launch of the job -
+ * a full batch, the short last batch, a single frame - uses the same split.  Process-wide setting, read at launch time and by
+ * the *_workspace_bytes functions (set it before sizing workspaces). */
+void maua_set_split_batch_hint(int frames);
+int maua_get_split_batch_hint(void);
+
 /* ---- L-BFGS pixel update: torch.optim.LBFGS as configured at optim.py:180-191 --------------------- */
 /* Device-resident state: `state` is an opaque caller-allocated buffer of maua_lbfgs_state_bytes(count, history)
  * bytes holding the (s, y) history slab [2*history][count], the previous gradient, the direction, the Gram matrix of

@@ -92,6 +92,7 @@ struct ConvArgs {
     float* ws;           // [n][ksplit][Cout][OH][OW] partial sums (split-K only)
     int stagger;         // conv_x3w: start delay (units of 512 cycles) of the first-round workgroups in odd CU slots
 };
+int split_batch_hint();  // conv_api.hip: frames per launch the caller plans with (split-K cost models), >= 1
 int conv_mfma_dispatch(const ConvArgs& a, int ks, int n, hipStream_t stream);
 int conv3x3_few_out(const ConvArgs& a, int n, hipStream_t stream);
 int conv_splitk_finish(const ConvArgs& a, int n, int ksplit, hipStream_t stream);

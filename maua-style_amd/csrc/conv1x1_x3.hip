@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(256, 4) conv1x1_x3_kernel(ConvArgs p, const fl
 
 static int p1_choose_split(const ConvArgs& a, int n) {
     const int64_t hw = (int64_t)a.H * a.W;
-    const int64_t wgs = ((hw + P1_PX - 1) / P1_PX) * ((a.Cout + P1_COT - 1) / P1_COT);  // per image: a batch computes every frame exactly as a single-frame launch would
+    const int64_t wgs = ((hw + P1_PX - 1) / P1_PX) * ((a.Cout + P1_COT - 1) / P1_COT) * split_batch_hint();  // planned frames, not this launch's (conv_x3w.hip)
     const int nchunks = (a.Cin + P1_KC - 1) / P1_KC;
     if (wgs >= 2048 || nchunks < 8) return 1;
     const double out_mb = (double)n * a.Cout * hw * 4.0 / 1e6;

@@ -6,6 +6,13 @@
 
 using namespace maua;
 
+namespace maua {
+// Frames the caller plans to evaluate per launch (see maua_set_split_batch_hint): the split-K cost models count
+// `frames` images' worth of workgroups, whatever the batch size of the launch at hand.
+static int g_split_batch_hint = 1;
+int split_batch_hint() { return g_split_batch_hint; }
+}  // namespace maua
+
 static inline bool mfma_geometry(int kh, int kw, int stride) {
     return stride == 1 && kh == kw && (kh == 1 || kh == 3 || kh == 5);
 }
@@ -16,6 +23,9 @@ static int conv_route(const ConvArgs& a, int ks, int n, hipStream_t stream) {
 }
 
 extern "C" {
+
+void maua_set_split_batch_hint(int frames) { maua::g_split_batch_hint = frames > 0 ? frames : 1; }
+int maua_get_split_batch_hint(void) { return maua::g_split_batch_hint; }
 
 size_t maua_conv_workspace_bytes(int n, int cin, int h, int w, int cout, int kh, int kw, int stride, int pad) {
     if (n <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0) return 0;

@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(256, 2) conv_kxk_x3_kernel(ConvArgs p, float w
 // of NIN's conv2 produces 96 channels = 2 channel tiles x 128 pixel tiles.
 static int kxk_choose_split(const ConvArgs& a, int n) {
     const int64_t tiles = (int64_t)((a.OW + KX_TC - 1) / KX_TC) * ((a.OH + KX_TR - 1) / KX_TR);
-    const int64_t wgs = tiles * ((a.Cout + KX_COT - 1) / KX_COT);  // per image (see conv_x3w.hip)
+    const int64_t wgs = tiles * ((a.Cout + KX_COT - 1) / KX_COT) * split_batch_hint();  // planned frames (see conv_x3w.hip)
     const int nchunks = (a.Cin + 7) / 8;
     int ks = (int)(512 / (wgs > 0 ? wgs : 1));
     if (ks > nchunks / 4) ks = nchunks / 4;

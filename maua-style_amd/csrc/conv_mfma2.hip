@@ -350,7 +350,7 @@ int conv_mfma2_choose_split(const ConvArgs& a, int ks, int n) {
     if (ks != 1 && ks != 3 && ks != 5) return 1;
     const int64_t opix = (int64_t)a.OH * a.OW;
     const int64_t tiles = (ks == 1) ? (opix + 127) / 128 : (int64_t)((a.OW + 31) / 32) * ((a.OH + 3) / 4);
-    const int64_t wgs = tiles * ((a.Cout + 63) / 64);  // per image (see conv_x3w.hip)
+    const int64_t wgs = tiles * ((a.Cout + 63) / 64) * split_batch_hint();  // planned frames (see conv_x3w.hip)
     const int nchunks = (a.Cin + 7) / 8;
     if (wgs >= 384 || nchunks < 16) return 1;
     int s = (int)((768 + wgs - 1) / wgs);

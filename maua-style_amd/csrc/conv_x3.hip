@@ -357,10 +357,10 @@ __global__ void __launch_bounds__(256, 4) conv_x3_kernel(ConvArgs p, float w_inv
 
 // same cost model as conv_x6.hip with this kernel's ~2.7 us per chunk
 static int x3_choose_split(const ConvArgs& a, int n) {
-    const int64_t wgs = (int64_t)((a.OW + 31) / 32) * ((a.OH + X3_PH - 1) / X3_PH) * ((a.Cout + X3_COT - 1) / X3_COT);  // per image (see conv_x3w.hip)
+    const int64_t wgs = (int64_t)((a.OW + 31) / 32) * ((a.OH + X3_PH - 1) / X3_PH) * ((a.Cout + X3_COT - 1) / X3_COT) * split_batch_hint();  // planned frames (see conv_x3w.hip)
     const int nchunks = (a.Cin + 7) / 8;
     if (wgs >= 4096 || nchunks < 8) return 1;
-    const double out_mb = (double)a.Cout * a.OH * a.OW * 4.0 / 1e6;
+    const double out_mb = (double)split_batch_hint() * a.Cout * a.OH * a.OW * 4.0 / 1e6;
     int best = 1;
     double best_cost = 1e30;
     for (int ks = 1; ks <= 16 && ks <= nchunks / 4; ++ks) {

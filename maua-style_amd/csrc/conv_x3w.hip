@@ -438,12 +438,13 @@ __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_in
 
 // split-K over 16-channel chunks when the grid leaves most of the 512 workgroup slots (2 per CU) empty
 static int x3w_choose_split(const ConvArgs& a, int n) {
-    const int64_t wgs = (int64_t)((a.OW + 31) / 32) * ((a.OH + XW_ROWS - 1) / XW_ROWS) * ((a.Cout + XW_COT - 1) / XW_COT);
-    (void)n;  // The policy looks at ONE image: a batch of independent frames (vid_img) then computes every frame with exactly the
-              // summation order of a single-frame launch - bit-identical results whatever the batch size.
+    const int64_t wgs = (int64_t)((a.OW + 31) / 32) * ((a.OH + XW_ROWS - 1) / XW_ROWS) * ((a.Cout + XW_COT - 1) / XW_COT) * split_batch_hint();
+    (void)n;  // The policy does not look at THIS launch's batch size but at the number of frames the caller plans to evaluate per
+              // launch (maua_set_split_batch_hint, 1 by default): vid_img's frames are then computed with the same summation
+              // order whether they run one at a time or sixteen together - bit-identical results whatever the grouping.
     const int nchunks = a.Cin / 16;
     if (wgs >= 2048 || nchunks < 4) return 1;
-    const double out_mb = (double)a.Cout * a.OH * a.OW * 4.0 / 1e6;
+    const double out_mb = (double)split_batch_hint() * a.Cout * a.OH * a.OW * 4.0 / 1e6;
     int best = 1;
     double best_cost = 1e30;
     for (int ks = 1; ks <= 16 && ks <= nchunks / 2; ++ks) {

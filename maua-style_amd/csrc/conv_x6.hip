@@ -484,10 +484,10 @@ __global__ void __launch_bounds__(256, 4) conv_x6_kernel(ConvArgs p) {
 // 2208 = 2.16 rounds.  Cost model per candidate split: rounds x (chunks per workgroup + 1.5 chunk-times of prologue /
 // epilogue) x 5 us per chunk, plus the finish kernel's traffic (ks partial reads + one write at ~5 TB/s).
 static int x6_choose_split(const ConvArgs& a, int n) {
-    const int64_t wgs = (int64_t)((a.OW + 31) / 32) * ((a.OH + X6_PH - 1) / X6_PH) * ((a.Cout + X6_COT - 1) / X6_COT);  // per image (see conv_x3w.hip)
+    const int64_t wgs = (int64_t)((a.OW + 31) / 32) * ((a.OH + X6_PH - 1) / X6_PH) * ((a.Cout + X6_COT - 1) / X6_COT) * split_batch_hint();  // planned frames (see conv_x3w.hip)
     const int nchunks = (a.Cin + 7) / 8;
     if (wgs >= 4096 || nchunks < 8) return 1;
-    const double out_mb = (double)a.Cout * a.OH * a.OW * 4.0 / 1e6;
+    const double out_mb = (double)split_batch_hint() * a.Cout * a.OH * a.OW * 4.0 / 1e6;
     int best = 1;
     double best_cost = 1e30;
     for (int ks = 1; ks <= 16 && ks <= nchunks / 4; ++ks) {

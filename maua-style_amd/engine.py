@@ -57,6 +57,7 @@ class StyleEngine:
         # flow): every frame gets exactly the B = 1 arithmetic - its own loss slots, its own total - while the convolutions
         # and pools run on the whole batch so that small images still fill the chip.
         self.independent = False
+        self.batch_hint = 1  # frames per launch the job plans with: fixes the convolutions' split-K policy (hip.set_split_batch_hint)
         # 3x3 stride-1 convs run on the bf16 matrix cores with a 3-way operand split (fp32 accuracy, conv_x6.hip) unless
         # MAUA_CONV_X6=0 asks for the fp32-MFMA kernels (A/B comparisons)
         mode = os.environ.get("MAUA_CONV_X6", "1")  # "1" both passes, "fwd" / "bwd" one of them, "0" off
@@ -115,12 +116,13 @@ class StyleEngine:
 
     # -- buffers ---------------------------------------------------------------------------------------
     def _prepare(self, x):
-        if self.shape == tuple(x.shape) and getattr(self, "prepared_independent", None) == self.independent:
+        hip.set_split_batch_hint(self.batch_hint)
+        if self.shape == tuple(x.shape) and getattr(self, "prepared_for", None) == (self.independent, self.batch_hint):
             return
         dev = x.device
         B = x.shape[0]
         self.shape = tuple(x.shape)
-        self.prepared_independent = self.independent
+        self.prepared_for = (self.independent, self.batch_hint)
         self.graph = None
         shapes = {0: tuple(x.shape)}
         for s in self.steps:
@@ -275,6 +277,7 @@ class StyleEngine:
         return self.use_x6 and s.k == 3 and s.stride == 1 and s.pad <= 2 and produced_channels > 32
 
     def _run(self, x):
+        hip.set_split_batch_hint(self.batch_hint)  # host-side setting read when a launch picks its split: nothing is enqueued
         a, g = self.act, self.gbuf
         a[0] = x
         hip.fill_(self.slots_all, 0.0)
@@ -524,6 +527,7 @@ class StyleEngine:
                             float(getattr(m, "video_style_factor", 0.0)), bool(getattr(m, "use_covariance", False))))
             elif s.kind == "conv":
                 key.append((id(m), m.weight.data_ptr(), m.weight._version))
+        key.append(("hint", self.batch_hint, self.independent))
         return tuple(key)
 
     def feval(self, x, capture=False):

@@ -68,6 +68,8 @@ SIGNATURES = {
     "maua_color_match_apply": (c_i, [c_p, c_p, c_f, c_p, c_p, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "maua_resize_bilinear": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
     "maua_deprocess_u8": (c_i, [c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_p]),
+    "maua_set_split_batch_hint": (None, [c_i]),
+    "maua_get_split_batch_hint": (c_i, []),
     "maua_lbfgs_state_bytes": (c_sz, [c_i64, c_i]),
     "maua_lbfgs_init": (c_i, [c_p, c_sz, c_i64, c_i, c_p]),
     "maua_lbfgs_iterate": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_f, c_f, c_f, c_p]),
@@ -470,6 +472,13 @@ def adam_step(x, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, ep
 # ------------------------------------------------------------------------------------------
 # image-space steps between two optimisation runs (csrc/image.hip)
 # ------------------------------------------------------------------------------------------
+def set_split_batch_hint(frames):
+    """Frames per launch the job plans with (split-K policy of the convolutions); returns the previous value."""
+    prev = lib().maua_get_split_batch_hint()
+    lib().maua_set_split_batch_hint(int(frames))
+    return prev
+
+
 def channel_stats(x, noise=None, noise_amp=1e-3, out=None, workspace=None):
     """Raw colour statistics of a batch x (B,3,H,W), optionally jittered by noise_amp * noise (laid out [B][W][H][3], the
     order the reference draws it in): out[B][9] doubles, one row per plane slot j of the reference's reshape (component k =

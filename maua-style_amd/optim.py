@@ -157,7 +157,7 @@ GRAPH_MIN_ITERS = 128
 class PixelOptimizer:
     """The iteration loop for one image: fused feval + device-side optimizer step."""
 
-    def __init__(self, net, losses, init, args, planned_iters=None, grad_hook=None, independent=False):
+    def __init__(self, net, losses, init, args, planned_iters=None, grad_hook=None, independent=False, batch_hint=1):
         """`independent`: `init` holds B separate single-frame problems (vid_img's frames without optical flow) that are
         evaluated together - one L-BFGS state (or Adam moment pair) per frame, the single-frame loss arithmetic per frame."""
         self.args = args
@@ -172,8 +172,9 @@ class PixelOptimizer:
         self.x = _device_image(init, args).clone()
         self.kind = args.optimizer
         self.step_count = 0
+        self.batch_hint = max(1, int(batch_hint))
         if self.engine is not None:
-            self.engine.independent = self.independent
+            self.engine.independent, self.engine.batch_hint = self.independent, self.batch_hint
         elif self.independent:
             raise engine_mod.UnsupportedNet("independent frame batches need the fused engine")
         self.frames = [self.x[b] for b in range(self.x.shape[0])] if self.independent else [self.x]
@@ -198,7 +199,7 @@ class PixelOptimizer:
     def feval(self):
         """(loss slots, total, gradient) at the current image - device tensors, no sync."""
         if self.engine is not None:
-            self.engine.independent = self.independent
+            self.engine.independent, self.engine.batch_hint = self.independent, self.batch_hint
             try:
                 return self.engine.feval(self.x, capture=self.use_graph and self.kind != "lbfgs" and self.engine.timer is None)
             except engine_mod.UnsupportedNet:
@@ -361,19 +362,22 @@ def _optimize_video(content, styles, init, num_iters, args, net=None, losses=Non
     return output
 
 
-def optimize_frames(contents, styles, inits, num_iters, args, net, losses):
+def optimize_frames(contents, styles, inits, num_iters, args, net, losses, planned_frames=None):
     """B independent calls of `optimize` (same network, same style images, one content frame and one initial image each -
     the frames of vid_img without optical flow, reference style.py:192-290) evaluated as ONE batch: the convolutions and
     pools run on all B frames at once, every frame keeps its own loss terms and its own optimiser state, and each frame's
     result is bit-identical to what a separate call gives.  Tensors may live on the device; returns the (B,3,H,W) device
-    tensor."""
+    tensor.  `planned_frames`: how many frames the JOB evaluates per launch (default: this call's B); the convolutions' split-K
+    policy is fixed by it, so calls with the same value give the same bits for a frame whatever their own B (vid_img's short
+    last batch, or its frame-by-frame debugging mode)."""
     limit_host_threads()
     if contents.shape[0] != inits.shape[0]:
         raise ValueError("one content frame per initial image")
     eng = _engine_of(net)
     if eng is None:
         raise engine_mod.UnsupportedNet("frame batches need a network the fused engine covers")
-    eng.independent = contents.shape[0] > 1
+    hint = int(planned_frames) if planned_frames else int(contents.shape[0])
+    eng.independent, eng.batch_hint = contents.shape[0] > 1, hint
     if not args.verbose:
         PBAR.reset()
         PBAR.total = num_iters
@@ -389,7 +393,7 @@ def optimize_frames(contents, styles, inits, num_iters, args, net, losses):
     if args.normalize_weights:
         for mod in net.content_losses + net.style_losses + net.temporal_losses:
             mod.strength = mod.strength / max(mod.target.size())
-    opt = PixelOptimizer(net, losses, inits, args, planned_iters=num_iters, independent=True)
+    opt = PixelOptimizer(net, losses, inits, args, planned_iters=num_iters, independent=True, batch_hint=hint)
     _run_iterations(opt, num_iters, args)
     for mod in losses:
         mod.loss = 0
@@ -417,7 +421,8 @@ def optimize(content, styles, init, num_iters, args, net=None, losses=None, keep
 
     eng = _engine_of(net)
     if eng is not None:
-        eng.independent = False
+        eng.independent, eng.batch_hint = False, 1
+    hip.set_split_batch_hint(1)
     set_content_targets(net, content, args)
     # Style targets depend only on the style images and blend weights.  The reference recaptures them on every call
     # (style.py:178 keeps the hoisting commented out); the result is identical, so a prebuilt net that is called again

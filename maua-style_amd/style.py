@@ -262,20 +262,25 @@ def _finish_frame(img, content_img, path, original_colors):
     img.save(path)
 
 
-def frames_per_batch(size):
-    """How many independent frames of side `size` are optimised together: enough pixels to fill the chip (4 x 1024^2), at
-    most 16 frames; MAUA_FRAME_BATCH overrides (1 = the reference's frame-by-frame loop)."""
-    forced = int(os.environ.get("MAUA_FRAME_BATCH", "0"))
-    if forced > 0:
-        return forced
+def planned_frames(size):
+    """How many independent frames of side `size` vid_img plans to evaluate per launch: enough pixels to fill the chip
+    (4 x 1024^2), at most 16 frames.  This number fixes the convolutions' split-K policy for the whole job."""
     return max(1, min(16, (4 << 20) // max(1, int(size) * int(size))))
 
 
-def _optimize_group(contents, style_images, inits, num_iters, args, net, losses):
+def frames_per_batch(size):
+    """How many frames are actually optimised together: planned_frames, unless MAUA_FRAME_BATCH overrides it (1 = the
+    reference's frame-by-frame loop; same results bit for bit, the policy above does not change)."""
+    forced = int(os.environ.get("MAUA_FRAME_BATCH", "0"))
+    return forced if forced > 0 else planned_frames(size)
+
+
+def _optimize_group(contents, style_images, inits, num_iters, args, net, losses, planned):
     """B frames at once through optim.optimize_frames; networks outside the fused plan go frame by frame."""
     import engine
     try:
-        return optim.optimize_frames(th.cat(contents), style_images, th.cat(inits), num_iters, args, net, losses)
+        return optim.optimize_frames(th.cat(contents), style_images, th.cat(inits), num_iters, args, net, losses,
+                                     planned_frames=planned)
     except engine.UnsupportedNet:
         return th.cat([optim.optimize(c, style_images, p, num_iters, args, net, losses, keep_on_device=True)
                        for c, p in zip(contents, inits)])
@@ -349,7 +354,8 @@ def vid_img(args):
                     contents.append(content)
                     inits.append(pastiche)
                 args.output = out_path(group[0])
-                outs = _optimize_group(contents, style_images, inits, num_iters // passes, args, net, losses)
+                outs = _optimize_group(contents, style_images, inits, num_iters // passes, args, net, losses,
+                                       planned_frames(current_size))
                 for k, frame in enumerate(group):
                     out = match_histogram(outs[k:k + 1], style_images_big[0], mode=mode, _noise=post_noise[k])
                     # deprocessing = one kernel + a 3-byte-per-pixel download, here; colour transfer and PNG encoding of this

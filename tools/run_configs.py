@@ -33,27 +33,43 @@ def _png(path, side, seed):
 
 
 class Timed:
-    """Wraps optim.optimize: wall time (device-synchronised) and iteration count of every call."""
+    """Wraps optim.optimize / optim.optimize_frames: wall time (device-synchronised) and iteration count of every call
+    (a batch of B frames counts B function evaluations per iteration)."""
 
     def __init__(self):
         self.calls = []
         self._orig = optim.optimize
+        self._orig_frames = optim.optimize_frames
+
+    def _record(self, init, num_iters, args, t0):
+        steps = optim.lbfgs_moves(num_iters) if args.optimizer == "lbfgs" else num_iters + 1
+        self.calls.append({"size": int(max(init.shape[2:])), "frames": int(init.shape[0]), "optimizer": args.optimizer,
+                           "num_iters": int(num_iters), "fevals": int(steps) * int(init.shape[0]),
+                           "seconds": round(time.perf_counter() - t0, 4)})
 
     def __enter__(self):
-        def wrapped(content, styles, init, num_iters, args, net=None, losses=None):
+        def wrapped(content, styles, init, num_iters, args, net=None, losses=None, **kw):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            out = self._orig(content, styles, init, num_iters, args, net, losses)
+            out = self._orig(content, styles, init, num_iters, args, net, losses, **kw)
             torch.cuda.synchronize()
-            steps = optim.lbfgs_moves(num_iters) if args.optimizer == "lbfgs" else num_iters + 1
-            self.calls.append({"size": int(max(init.shape[2:])), "optimizer": args.optimizer, "num_iters": int(num_iters),
-                               "fevals": int(steps), "seconds": round(time.perf_counter() - t0, 4)})
+            self._record(init, num_iters, args, t0)
+            return out
+
+        def wrapped_frames(contents, styles, inits, num_iters, args, net, losses, **kw):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = self._orig_frames(contents, styles, inits, num_iters, args, net, losses, **kw)
+            torch.cuda.synchronize()
+            self._record(inits, num_iters, args, t0)
             return out
         optim.optimize = wrapped
+        optim.optimize_frames = wrapped_frames
         return self
 
     def __exit__(self, *exc):
         optim.optimize = self._orig
+        optim.optimize_frames = self._orig_frames
 
 
 def setup(tmp):
@@ -137,7 +153,8 @@ def config4(p, tmp, frames):
     n_png = sum(len([f for f in fs if f.endswith(".png")]) for _, _, fs in os.walk(out_dir))
     s = summarise(t.calls, wall)
     return {"config": 4, "workload": f"{frames} synthetic 512x512 frames, args-vid.json (no optical flow), 200 iters/frame in 4 passes, "
-                                    "L-BFGS, one GPU (all frames on this rank)", "optimize_calls": len(t.calls), "pngs_written": n_png,
+                                    "L-BFGS, one GPU (all frames on this rank)", "frames_per_batch": style.frames_per_batch(512), "optimize_calls": len(t.calls),
+            "pngs_written": n_png,
             "frames_per_second": round(frames / wall, 3), **s}
 
 
