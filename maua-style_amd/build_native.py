@@ -29,19 +29,36 @@ def _digest():
     return h.hexdigest()
 
 
-def build(force=False, verbose=False):
+SAN_LIB = os.path.join(HERE, "csrc", "build", "libmaua_hip_san.so")
+SAN_FLAGS = ["-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-sanitize-recover=undefined", "-g", "-O1"]
+
+
+def asan_runtime():
+    """clang's AddressSanitizer runtime: LD_PRELOAD it into the Python process that loads the sanitised library."""
+    import glob
+    hits = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    return hits[-1] if hits else None
+
+
+def build(force=False, verbose=False, sanitize=False):
+    """sanitize=True: the same sources with the HOST code instrumented by AddressSanitizer + UndefinedBehaviorSanitizer
+    (device code plain: GPU ASan is not available on this pool) -> csrc/build/libmaua_hip_san.so, for
+    tools/fuzz_abi_host.py and tests/test_abi.py in the GPU-less container."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read().strip() == dig:
-        return LIB
+    lib, stamp = (SAN_LIB, SAN_LIB + ".stamp") if sanitize else (LIB, STAMP)
+    if not force and os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return lib
     objs = []
-    objdir = os.path.join(HERE, "csrc", "build")
+    objdir = os.path.join(HERE, "csrc", "build", "san" if sanitize else "")
     os.makedirs(objdir, exist_ok=True)
     procs = []
     for src in _sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+        if sanitize:
+            cmd[2:3] = SAN_FLAGS
         if verbose:
             cmd.insert(4, "-Rpass-analysis=kernel-resource-usage")
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -55,12 +72,12 @@ def build(force=False, verbose=False):
             sys.stderr.write(out)
     if failed:
         raise RuntimeError("libmaua_hip.so: compilation failed")
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib] + (SAN_FLAGS[:2] if sanitize else []) + objs
     subprocess.check_call(cmd)
-    with open(STAMP, "w") as f:
+    with open(stamp, "w") as f:
         f.write(dig)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, sanitize="--sanitize" in sys.argv))

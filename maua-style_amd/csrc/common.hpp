@@ -29,6 +29,14 @@ inline int check_launch(const char* what) {
 
 constexpr int kWave = 64;
 
+// Extents every entry point accepts, checked BEFORE any shape arithmetic (found by the UBSan build: h + 2 * pad - 2 and
+// friends overflow int for extents near INT_MAX): planes below 2^30 pixels (32-bit pixel offsets in the kernels), channel
+// counts and batch sizes that keep every product the host forms inside int64.
+inline bool conv_dims_ok(int64_t n, int64_t cin, int64_t h, int64_t w, int64_t cout, int64_t pad) {
+    return n > 0 && n <= (1 << 16) && cin > 0 && cin <= (1 << 20) && cout > 0 && cout <= (1 << 20) && h > 0 && h <= (1 << 24) &&
+           w > 0 && w <= (1 << 24) && pad >= 0 && pad <= 64 && h * w < (1ll << 30);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

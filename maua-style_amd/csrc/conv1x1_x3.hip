@@ -337,7 +337,7 @@ using namespace maua;
 extern "C" {
 
 size_t maua_conv1x1_x3_workspace_bytes(int n, int cin, int64_t hw, int cout) {
-    if (n <= 0 || cin <= 0 || cout <= 0 || hw <= 0 || hw >= (1ll << 30)) return 0;
+    if (!conv_dims_ok(n, cin, 1, hw < (1 << 24) ? hw : 1, cout, 0) || hw <= 0 || hw >= (1ll << 30)) return 0;
     return conv1x1_x3_workspace(n, cin, hw, cout);
 }
 
@@ -345,7 +345,7 @@ int maua_conv1x1_x3(const float* x, const float* x_channel_shift, const float* w
                     const float* out_relu_mask, float* y, int n, int cin, int64_t hw, int cout, int relu, int accumulate,
                     void* workspace, size_t workspace_bytes, maua_stream_t stream) {
     MAUA_REQUIRE(x && w_rowmajor && y, MAUA_E_INVAL, "conv1x1_x3: null pointer");
-    MAUA_REQUIRE(n > 0 && cin > 0 && cout > 0 && hw > 0, MAUA_E_INVAL, "conv1x1_x3: bad dims");
+    MAUA_REQUIRE(hw > 0 && conv_dims_ok(n, cin, 1, hw < (1 << 24) ? hw : 1, cout, 0), MAUA_E_INVAL, "conv1x1_x3: bad dims");
     MAUA_REQUIRE(hw < (1ll << 30) && (int64_t)cin * cout < (1ll << 30), MAUA_E_UNSUPPORTED, "conv1x1_x3: operand too large");
     ConvArgs a{};
     a.x = x;

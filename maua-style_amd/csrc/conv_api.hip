@@ -28,7 +28,7 @@ void maua_set_split_batch_hint(int frames) { maua::g_split_batch_hint = frames >
 int maua_get_split_batch_hint(void) { return maua::g_split_batch_hint; }
 
 size_t maua_conv_workspace_bytes(int n, int cin, int h, int w, int cout, int kh, int kw, int stride, int pad) {
-    if (n <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0) return 0;
+    if (!conv_dims_ok(n, cin, h, w, cout, pad) || kh <= 0 || kw <= 0 || kh > 64 || kw > 64 || stride <= 0 || stride > 64) return 0;
     if (!mfma_geometry(kh, kw, stride) || h + 2 * pad < kh || w + 2 * pad < kw) return 0;
     ConvArgs a{};
     a.Cin = cin;
@@ -44,7 +44,7 @@ int maua_conv2d_fwd(const float* x, const float* in_mask, const float* wf, const
                     int h, int w, int cout, int kh, int kw, int stride, int pad, int relu, int accumulate, void* workspace,
                     size_t workspace_bytes, maua_stream_t stream) {
     MAUA_REQUIRE(x && wf && y, MAUA_E_INVAL, "conv2d_fwd: null pointer");
-    MAUA_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0, MAUA_E_INVAL,
+    MAUA_REQUIRE(conv_dims_ok(n, cin, h, w, cout, pad) && kh > 0 && kw > 0 && kh <= 64 && kw <= 64 && stride > 0 && stride <= 64, MAUA_E_INVAL,
                  "conv2d_fwd: bad dims n=%d cin=%d cout=%d h=%d w=%d k=%dx%d s=%d p=%d", n, cin, cout, h, w, kh, kw, stride,
                  pad);
     const int oh = (h + 2 * pad - kh) / stride + 1, ow = (w + 2 * pad - kw) / stride + 1;
@@ -80,7 +80,7 @@ int maua_conv2d_bwd_data(const float* gy, const float* out_mask, const float* wb
                          const float* in_relu_mask, float* gx, int n, int cin, int h, int w, int cout, int kh, int kw,
                          int stride, int pad, int accumulate, void* workspace, size_t workspace_bytes, maua_stream_t stream) {
     MAUA_REQUIRE(gy && gx && (wb || w_oihw), MAUA_E_INVAL, "conv2d_bwd_data: null pointer");
-    MAUA_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0, MAUA_E_INVAL,
+    MAUA_REQUIRE(conv_dims_ok(n, cin, h, w, cout, pad) && kh > 0 && kw > 0 && kh <= 64 && kw <= 64 && stride > 0 && stride <= 64, MAUA_E_INVAL,
                  "conv2d_bwd_data: bad dims");
     const int oh = (h + 2 * pad - kh) / stride + 1, ow = (w + 2 * pad - kw) / stride + 1;
     MAUA_REQUIRE(h + 2 * pad >= kh && w + 2 * pad >= kw, MAUA_E_UNSUPPORTED, "conv2d_bwd_data: input smaller than filter");

@@ -311,14 +311,14 @@ using namespace maua;
 extern "C" {
 
 size_t maua_conv_kxk_x3_bank_bytes(int cout_produced, int cin_consumed, int ks) {
-    if (cout_produced <= 0 || cin_consumed <= 0 || ks <= 0) return 0;
+    if (cout_produced <= 0 || cin_consumed <= 0 || ks <= 0 || ks > 16 || cout_produced > (1 << 20) || cin_consumed > (1 << 20)) return 0;
     const size_t nchunk = (cin_consumed + 7) / 8, ntile = (cout_produced + KX_COT - 1) / KX_COT;
     return nchunk * ntile * (size_t)ks * ks * 2 * KX_COT * 16;
 }
 
 int maua_conv_pack_filters_kxk_x3(const float* w_oihw, void* bank_fwd, void* bank_bwd, int cout, int cin, int ks, float w_scale,
                                   maua_stream_t stream) {
-    MAUA_REQUIRE(w_oihw && (bank_fwd || bank_bwd) && cout > 0 && cin > 0 && ks > 0 && w_scale > 0.f, MAUA_E_INVAL,
+    MAUA_REQUIRE(w_oihw && (bank_fwd || bank_bwd) && cout > 0 && cin > 0 && cout <= (1 << 20) && cin <= (1 << 20) && ks > 0 && w_scale > 0.f, MAUA_E_INVAL,
                  "conv_pack_filters_kxk_x3: bad args");
     for (int backward = 0; backward < 2; ++backward) {
         void* bank = backward ? bank_bwd : bank_fwd;
@@ -332,7 +332,7 @@ int maua_conv_pack_filters_kxk_x3(const float* w_oihw, void* bank_fwd, void* ban
 }
 
 size_t maua_conv_kxk_x3_workspace_bytes(int n, int cin, int h, int w, int cout, int ks, int pad) {
-    if (n <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || ks <= 0 || pad < 0) return 0;
+    if (!conv_dims_ok(n, cin, h, w, cout, pad) || ks <= 0 || ks > 16) return 0;
     ConvArgs a{};
     a.Cin = cin;
     a.Cout = cout;
@@ -347,7 +347,7 @@ int maua_conv_kxk_x3(const float* x, const void* bank, float w_scale, const floa
                      int n, int cin, int h, int w, int cout, int ks, int pad, int relu, int accumulate, void* workspace,
                      size_t workspace_bytes, maua_stream_t stream) {
     MAUA_REQUIRE(x && bank && y, MAUA_E_INVAL, "conv_kxk_x3: null pointer");
-    MAUA_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0 && w_scale > 0.f, MAUA_E_INVAL, "conv_kxk_x3: bad dims");
+    MAUA_REQUIRE(conv_dims_ok(n, cin, h, w, cout, pad) && w_scale > 0.f, MAUA_E_INVAL, "conv_kxk_x3: bad dims");
     MAUA_REQUIRE(ks == 5, MAUA_E_UNSUPPORTED, "conv_kxk_x3: %dx%d filters (5x5 is built; 3x3 has conv_x3, 1x1 conv1x1_x3)", ks, ks);
     MAUA_REQUIRE(pad >= 0 && pad <= ks - 1, MAUA_E_UNSUPPORTED, "conv_kxk_x3: pad %d", pad);
     const int oh = h + 2 * pad - ks + 1, ow = w + 2 * pad - ks + 1;

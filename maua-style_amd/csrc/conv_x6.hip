@@ -553,13 +553,13 @@ using namespace maua;
 extern "C" {
 
 size_t maua_conv_x6_bank_bytes(int cout_produced, int cin_consumed) {
-    if (cout_produced <= 0 || cin_consumed <= 0) return 0;
+    if (cout_produced <= 0 || cin_consumed <= 0 || cout_produced > (1 << 20) || cin_consumed > (1 << 20)) return 0;
     const size_t nchunk = (cin_consumed + 7) / 8, ntile = (cout_produced + X6_COT - 1) / X6_COT;
     return nchunk * ntile * X6_W_BYTES;
 }
 
 int maua_conv_pack_filters_x6(const float* w_oihw, void* bank_fwd, void* bank_bwd, int cout, int cin, maua_stream_t stream) {
-    MAUA_REQUIRE(w_oihw && (bank_fwd || bank_bwd) && cout > 0 && cin > 0, MAUA_E_INVAL, "conv_pack_filters_x6: bad args");
+    MAUA_REQUIRE(w_oihw && (bank_fwd || bank_bwd) && cout > 0 && cin > 0 && cout <= (1 << 20) && cin <= (1 << 20), MAUA_E_INVAL, "conv_pack_filters_x6: bad args");
     if (bank_fwd) {
         hipLaunchKernelGGL(pack_x6_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, w_oihw, (unsigned short*)bank_fwd,
                            cout, cin, 0);
@@ -575,7 +575,7 @@ int maua_conv_pack_filters_x6(const float* w_oihw, void* bank_fwd, void* bank_bw
 }
 
 size_t maua_conv_x6_workspace_bytes(int n, int cin, int h, int w, int cout, int pad) {
-    if (n <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || pad < 0) return 0;
+    if (!conv_dims_ok(n, cin, h, w, cout, pad)) return 0;
     ConvArgs a{};
     a.Cin = cin;
     a.Cout = cout;
@@ -590,7 +590,7 @@ int maua_conv3x3_x6(const float* x, const void* bank, const float* bias, const f
                     int cin, int h, int w, int cout, int pad, int relu, int accumulate, void* workspace,
                     size_t workspace_bytes, maua_stream_t stream) {
     MAUA_REQUIRE(x && bank && y, MAUA_E_INVAL, "conv3x3_x6: null pointer");
-    MAUA_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0 && pad >= 0 && pad <= 2, MAUA_E_INVAL, "conv3x3_x6: bad dims");
+    MAUA_REQUIRE(conv_dims_ok(n, cin, h, w, cout, pad) && pad <= 2, MAUA_E_INVAL, "conv3x3_x6: bad dims");
     MAUA_REQUIRE(h + 2 * pad >= 3 && w + 2 * pad >= 3, MAUA_E_UNSUPPORTED, "conv3x3_x6: input smaller than the filter");
     MAUA_REQUIRE((int64_t)h * w < (1ll << 30), MAUA_E_UNSUPPORTED, "conv3x3_x6: plane too large");
     ConvArgs a{};

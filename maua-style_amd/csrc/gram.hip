@@ -329,7 +329,7 @@ using namespace maua;
 extern "C" {
 
 size_t maua_gram_workspace_bytes(int c, int64_t hw) {
-    if (c <= 0 || hw <= 0) return 0;
+    if (c <= 0 || hw <= 0 || c > (1 << 16) || hw >= (1ll << 30)) return 0;
     int npairs, ksplit;
     int64_t chunk;
     gram_plan(c, hw, &npairs, &ksplit, &chunk);
@@ -342,7 +342,7 @@ size_t maua_gram_workspace_bytes(int c, int64_t hw) {
 
 int maua_gram_fwd(const float* f, float* gram, float* row_mean_out, int c, int64_t hw, float scale, int center,
                   void* workspace, size_t workspace_bytes, maua_stream_t stream) {
-    MAUA_REQUIRE(f && gram && workspace && c > 0 && hw > 0, MAUA_E_INVAL, "gram_fwd: bad args");
+    MAUA_REQUIRE(f && gram && workspace && c > 0 && hw > 0 && c <= (1 << 16) && hw < (1ll << 30), MAUA_E_INVAL, "gram_fwd: bad args");
     MAUA_REQUIRE(!center || row_mean_out, MAUA_E_INVAL, "gram_fwd: center needs row_mean_out");
     MAUA_REQUIRE(workspace_bytes >= maua_gram_workspace_bytes(c, hw), MAUA_E_WORKSPACE, "gram_fwd: workspace %zu < %zu",
                  workspace_bytes, maua_gram_workspace_bytes(c, hw));
@@ -379,7 +379,7 @@ int maua_gram_fwd(const float* f, float* gram, float* row_mean_out, int c, int64
 
 int maua_gram_bwd(const float* d_sym, const float* f, const float* row_mean, const float* relu_mask, float* gf, int c,
                   int64_t hw, int accumulate, void* workspace, size_t workspace_bytes, maua_stream_t stream) {
-    MAUA_REQUIRE(d_sym && f && gf && c > 0 && hw > 0, MAUA_E_INVAL, "gram_bwd: bad args");
+    MAUA_REQUIRE(d_sym && f && gf && c > 0 && hw > 0 && c <= (1 << 16) && hw < (1ll << 30), MAUA_E_INVAL, "gram_bwd: bad args");
     MAUA_REQUIRE(hw < (1ll << 31), MAUA_E_UNSUPPORTED, "gram_bwd: plane too large");
     static const bool use_x3 = [] {
         const char* e = getenv("MAUA_GRAM_BWD_X3");

@@ -285,7 +285,7 @@ using namespace maua;
 extern "C" {
 
 size_t maua_channel_stats_workspace_bytes(int h, int w) {
-    if (h <= 0 || w <= 0) return 0;
+    if (!conv_dims_ok(1, 3, h, w, 3, 0)) return 0;
     const size_t tiles = (size_t)((h + ST_ROWS - 1) / ST_ROWS) * ((w + ST_COLS - 1) / ST_COLS);
     return tiles * 9 * sizeof(double);
 }
@@ -293,7 +293,7 @@ size_t maua_channel_stats_workspace_bytes(int h, int w) {
 int maua_channel_stats(const float* x_bchw, const float* noise_bwhc, float noise_amp, int frames, int slot, int h, int w,
                        double* stats9, void* workspace, size_t workspace_bytes, maua_stream_t stream) {
     MAUA_REQUIRE(x_bchw && stats9 && workspace, MAUA_E_INVAL, "channel_stats: null pointer");
-    MAUA_REQUIRE(h > 0 && w > 0 && (int64_t)h * w < (1ll << 31), MAUA_E_INVAL, "channel_stats: bad dims %d x %d", h, w);
+    MAUA_REQUIRE(conv_dims_ok(1, 3, h, w, 3, 0), MAUA_E_INVAL, "channel_stats: bad dims %d x %d", h, w);
     MAUA_REQUIRE(frames > 0 && slot >= 0 && slot < frames, MAUA_E_INVAL, "channel_stats: slot %d of %d frames", slot, frames);
     MAUA_REQUIRE(workspace_bytes >= maua_channel_stats_workspace_bytes(h, w), MAUA_E_WORKSPACE, "channel_stats: workspace too small");
     const int tiles_w = (w + ST_COLS - 1) / ST_COLS, tiles_h = (h + ST_ROWS - 1) / ST_ROWS;
@@ -319,7 +319,7 @@ int maua_color_match_apply(const float* x_bchw, const float* noise_bwhc, float n
                            int n_coef, float weight, int accumulate, int frames, int slot, int h, int w, float* out_bchw,
                            maua_stream_t stream) {
     MAUA_REQUIRE(x_bchw && coef16 && all_coef && out_bchw, MAUA_E_INVAL, "color_match_apply: null pointer");
-    MAUA_REQUIRE(h > 0 && w > 0 && n_coef > 0 && (int64_t)h * w < (1ll << 31), MAUA_E_INVAL, "color_match_apply: bad dims");
+    MAUA_REQUIRE(conv_dims_ok(1, 3, h, w, 3, 0) && n_coef > 0, MAUA_E_INVAL, "color_match_apply: bad dims");
     MAUA_REQUIRE(frames > 0 && slot >= 0 && slot < frames, MAUA_E_INVAL, "color_match_apply: slot %d of %d frames", slot, frames);
     const int tiles_w = (w + ST_COLS - 1) / ST_COLS, tiles_h = (h + ST_ROWS - 1) / ST_ROWS;
     hipLaunchKernelGGL(color_match_apply_kernel, dim3(tiles_w * tiles_h), dim3(256), 0, (hipStream_t)stream, x_bchw, noise_bwhc, noise_amp,
@@ -330,7 +330,7 @@ int maua_color_match_apply(const float* x_bchw, const float* noise_bwhc, float n
 int maua_resize_bilinear(const float* x, float* y, int planes, int h, int w, int oh, int ow, float scale_h, float scale_w,
                          maua_stream_t stream) {
     MAUA_REQUIRE(x && y, MAUA_E_INVAL, "resize_bilinear: null pointer");
-    MAUA_REQUIRE(planes > 0 && h > 0 && w > 0 && oh > 0 && ow > 0 && scale_h > 0.f && scale_w > 0.f, MAUA_E_INVAL,
+    MAUA_REQUIRE(conv_dims_ok(1, planes, h, w, 1, 0) && conv_dims_ok(1, planes, oh, ow, 1, 0) && scale_h > 0.f && scale_w > 0.f, MAUA_E_INVAL,
                  "resize_bilinear: bad dims");
     const int64_t total = (int64_t)planes * oh * ow;
     hipLaunchKernelGGL(resize_bilinear_kernel, dim3(reduce_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, planes, h, w, oh,
@@ -341,7 +341,7 @@ int maua_resize_bilinear(const float* x, float* y, int planes, int h, int w, int
 int maua_deprocess_u8(const float* x_bgr_chw, unsigned char* out_rgb_hwc, int h, int w, float mean_b, float mean_g, float mean_r,
                       maua_stream_t stream) {
     MAUA_REQUIRE(x_bgr_chw && out_rgb_hwc, MAUA_E_INVAL, "deprocess_u8: null pointer");
-    MAUA_REQUIRE(h > 0 && w > 0, MAUA_E_INVAL, "deprocess_u8: bad dims");
+    MAUA_REQUIRE(conv_dims_ok(1, 3, h, w, 3, 0), MAUA_E_INVAL, "deprocess_u8: bad dims");
     hipLaunchKernelGGL(deprocess_u8_kernel, dim3(reduce_blocks((int64_t)h * w, 256)), dim3(256), 0, (hipStream_t)stream, x_bgr_chw,
                        out_rgb_hwc, h, w, mean_b, mean_g, mean_r);
     return check_launch("deprocess_u8_kernel");

@@ -443,12 +443,12 @@ using namespace maua;
 extern "C" {
 
 size_t maua_lbfgs_state_bytes(int64_t count, int history) {
-    if (count <= 0 || history <= 0) return 0;
+    if (count <= 0 || history <= 0 || history > 254 || count >= (1ll << 36)) return 0;
     return lbfgs_layout(count, history).total;
 }
 
 int maua_lbfgs_init(void* state, size_t state_bytes, int64_t count, int history, maua_stream_t stream) {
-    MAUA_REQUIRE(state && count > 0 && history > 0, MAUA_E_INVAL, "lbfgs_init: bad args");
+    MAUA_REQUIRE(state && count > 0 && count < (1ll << 36) && history > 0 && history <= 254, MAUA_E_INVAL, "lbfgs_init: bad args");
     MAUA_REQUIRE(2 * (history + 1) + 1 <= 512, MAUA_E_UNSUPPORTED, "lbfgs_init: history %d too large (at most 254)", history);
     const LbfgsLayout L = lbfgs_layout(count, history);
     MAUA_REQUIRE(state_bytes >= L.total, MAUA_E_WORKSPACE, "lbfgs_init: state %zu < %zu bytes", state_bytes, L.total);
@@ -460,7 +460,7 @@ int maua_lbfgs_init(void* state, size_t state_bytes, int64_t count, int history,
 
 int maua_lbfgs_iterate(void* state, float* x, const float* grad, const float* loss, int64_t count, int history, float lr,
                        float tolerance_change, float tolerance_grad, maua_stream_t stream) {
-    MAUA_REQUIRE(state && x && grad && count > 0 && history > 0, MAUA_E_INVAL, "lbfgs_iterate: bad args");
+    MAUA_REQUIRE(state && x && grad && count > 0 && count < (1ll << 36) && history > 0 && history <= 254, MAUA_E_INVAL, "lbfgs_iterate: bad args");
     const LbfgsLayout L = lbfgs_layout(count, history);
     char* b = (char*)state;
     LbfgsHeader* hdr = (LbfgsHeader*)b;
@@ -502,7 +502,7 @@ int maua_lbfgs_iterate(void* state, float* x, const float* grad, const float* lo
 }
 
 int maua_lbfgs_status(const void* state, int64_t count, int history, float* out5, maua_stream_t stream) {
-    MAUA_REQUIRE(state && out5 && count > 0 && history > 0, MAUA_E_INVAL, "lbfgs_status: bad args");
+    MAUA_REQUIRE(state && out5 && count > 0 && history > 0 && history <= 254, MAUA_E_INVAL, "lbfgs_status: bad args");
     hipLaunchKernelGGL(lbfgs_status_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const LbfgsHeader*)state, out5);
     return check_launch("lbfgs_status_kernel");
 }

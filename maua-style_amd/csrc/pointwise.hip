@@ -374,7 +374,7 @@ int maua_pool_out_size(int in, int k, int stride, int ceil_mode) {
 
 int maua_pool2d_fwd(const float* x, float* y, int n, int c, int h, int w, int k, int stride, int ceil_mode, int mode,
                     maua_stream_t stream) {
-    MAUA_REQUIRE(x && y && n > 0 && c > 0 && h > 0 && w > 0 && k > 0 && stride > 0 && (mode == 0 || mode == 1),
+    MAUA_REQUIRE(x && y && conv_dims_ok(n, c, h, w, 1, 0) && k > 0 && k <= 64 && stride > 0 && stride <= 64 && (mode == 0 || mode == 1),
                  MAUA_E_INVAL, "pool2d_fwd: bad args");
     const int oh = maua_pool_out_size(h, k, stride, ceil_mode), ow = maua_pool_out_size(w, k, stride, ceil_mode);
     MAUA_REQUIRE(oh > 0 && ow > 0, MAUA_E_UNSUPPORTED, "pool2d_fwd: input %dx%d smaller than window %d", h, w, k);
@@ -390,7 +390,7 @@ int maua_pool2d_fwd(const float* x, float* y, int n, int c, int h, int w, int k,
 
 int maua_pool2d_bwd(const float* gy, const float* x, float* gx, int n, int c, int h, int w, int k, int stride,
                     int ceil_mode, int mode, int relu_mask_by_x, maua_stream_t stream) {
-    MAUA_REQUIRE(gy && x && gx && n > 0 && c > 0 && h > 0 && w > 0 && k > 0 && stride > 0 && (mode == 0 || mode == 1),
+    MAUA_REQUIRE(gy && x && gx && conv_dims_ok(n, c, h, w, 1, 0) && k > 0 && k <= 64 && stride > 0 && stride <= 64 && (mode == 0 || mode == 1),
                  MAUA_E_INVAL, "pool2d_bwd: bad args");
     const int oh = maua_pool_out_size(h, k, stride, ceil_mode), ow = maua_pool_out_size(w, k, stride, ceil_mode);
     MAUA_REQUIRE(oh > 0 && ow > 0, MAUA_E_UNSUPPORTED, "pool2d_bwd: input %dx%d smaller than window %d", h, w, k);
@@ -449,7 +449,7 @@ int maua_mse_weighted_fwd_bwd(const float* x, const float* weights, const float*
 
 int maua_tv_fwd_bwd(const float* x, float* grad, int n, int c, int h, int w, float strength, int accumulate,
                     float* loss_out, void* workspace, size_t workspace_bytes, maua_stream_t stream) {
-    MAUA_REQUIRE(x && loss_out && workspace && n > 0 && c > 0 && h > 0 && w > 0, MAUA_E_INVAL, "tv_fwd_bwd: bad args");
+    MAUA_REQUIRE(x && loss_out && workspace && conv_dims_ok(n, c, h, w, 1, 0), MAUA_E_INVAL, "tv_fwd_bwd: bad args");
     const int64_t count = (int64_t)n * c * h * w;
     const int nb = reduce_blocks(count, 1024);
     MAUA_REQUIRE(workspace_bytes >= nb * sizeof(double), MAUA_E_WORKSPACE, "tv_fwd_bwd: workspace too small");

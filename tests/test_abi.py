@@ -83,3 +83,25 @@ def test_cpu_tensors_are_refused(libpath):
     import hip
     with pytest.raises(hip.HipError):
         hip.relu_(torch.zeros(4))
+
+
+def test_host_boundary_under_address_and_ub_sanitizers():
+    """SURVEY.md section 5 (sanitizers): the host half of every entry point - argument checks, workspace / bank sizing, split-K
+    cost models, grid arithmetic - built with -fsanitize=address,undefined (device code plain: GPU ASan is not available on
+    this pool) and driven by a shape fuzzer (tools/fuzz_abi_host.py: extents from -7 to INT_MAX, odd sizes, every kernel
+    family) in the GPU-less container.  A sanitizer report aborts the subprocess.  (The first run of this build found the
+    signed overflows of `h + 2 * pad - 2` near INT_MAX that common.hpp's conv_dims_ok now rules out before any arithmetic.)"""
+    import subprocess
+    import sys
+    import build_native
+    asan = build_native.asan_runtime()
+    if asan is None:
+        pytest.skip("clang's asan runtime not found under /opt/rocm")
+    lib = build_native.build(sanitize=True)
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1",
+               MAUA_FUZZ_ASSUME_NO_GPU="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    for seed in (0, 1):
+        out = subprocess.run([sys.executable, os.path.join(os.path.dirname(PKG), "tools", "fuzz_abi_host.py"), lib, "400", str(seed)],
+                             capture_output=True, text=True, env=env, timeout=900, cwd="/tmp")
+        assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+        assert "no sanitizer report" in out.stdout and "runtime error" not in out.stderr
