@@ -15,7 +15,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 
 constexpr int GT = 64;       // tile edge (channels)
-constexpr int GK = 64;       // pixels per stage
+#ifndef MAUA_GRAM_GK
+#define MAUA_GRAM_GK 64
+#endif
+constexpr int GK = MAUA_GRAM_GK;  // pixels per stage
 constexpr int GRS = GK + 4;  // LDS row stride (floats): 16-byte aligned rows, 4*row mod 64 banks -> conflict-free b128
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -144,6 +147,221 @@ gram_partial_kernel(const float* __restrict__ f, const float* __restrict__ mean,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same partial tile on the fp16 matrix cores in fp16x3 arithmetic (conv_x3.hip: value * s = high + low fp16 part, products
+// low*high, high*low, high*high on v_mfma_f32_32x32x16_f16, fp32 accumulate, un-scaled fold into an fp32 master).  The fp32
+// kernel above is bound by the fp32 matrix rate (64 cycles per 32x32x2 MFMA: 80-130 TFLOP/s on every style layer, 2-3x the
+// time an HBM-rate pass over the map would take); with three fp16 MFMAs per product block the arithmetic is 5x cheaper and
+// the kernel becomes a streaming one, so it is built as one:
+//   * loads run TWO 64-pixel stages ahead in registers (32 KB per diagonal workgroup in flight, 4 workgroups per CU);
+//   * the fp16 planes [tile][part][channel][64 px] are double-buffered in LDS: ONE barrier per stage;
+//   * no cross-wave exchange for the scales: a wave stages, for each tile, the unit (32-channel block w >> 1, 32-pixel half
+//     w & 1), takes ITS maximum (DPP), scales it into [2^11, 2^12) and leaves the inverse scale next to the planes.  A wave's
+//     32x32 output block therefore sees one scale pair per pixel half: k-steps 0-1 and 2-3 accumulate separately and are
+//     folded with (inverse scale of its row block) x (inverse scale of its column block).
+// Same slab format as gram_partial_kernel, same plan, same finish kernels; error against fp64 as for the fp32 kernel.
+typedef _Float16 g16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 g16x2 __attribute__((ext_vector_type(2)));
+typedef float g32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int gu32x2 __attribute__((ext_vector_type(2)));
+constexpr int GXROW = 144;                       // bytes per fp16 plane row: 64 px * 2 B + 16 (conflict-free b128 reads)
+constexpr int GXPLANE = GT * GXROW;              // one [channel][px] plane of one part
+constexpr int GXBUF = 2 * 2 * GXPLANE + 64;      // [tile][part] planes + 8 inverse scales [tile][block][half]
+
+__device__ __forceinline__ unsigned gx_cvt_pk(float a, float b) {
+    const g32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, g16x2));
+}
+
+__global__ void __launch_bounds__(256, 2)
+gram_x3_partial_kernel(const float* __restrict__ f, const float* __restrict__ mean, float* __restrict__ partial, int C,
+                       int64_t HW, int ksplit, int64_t chunk, int nplanes) {
+    // two buffers of `nplanes` planes (4 = [tile][part]; 2 when C <= 64: the single, diagonal tile pair needs no second tile,
+    // and four such workgroups fit a CU) + 64 bytes of inverse scales each
+    extern __shared__ __attribute__((aligned(16))) float smem_f32[];  // (one dynamic-LDS symbol per translation unit)
+    unsigned char* smem = reinterpret_cast<unsigned char*>(smem_f32);
+    const int GXBUFD = nplanes * GXPLANE + 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i32 = lane & 31, half = lane >> 5;
+    const int wi = wave >> 1, wj = wave & 1;
+    int pair = blockIdx.x, ti = 0;
+    const int ntile = (C + GT - 1) / GT;
+    while (pair >= ntile - ti) {
+        pair -= ntile - ti;
+        ++ti;
+    }
+    const int tj = ti + pair;
+    const bool diag = ti == tj;
+    const int ks = blockIdx.y;
+    const int64_t p_begin = (int64_t)ks * chunk;
+    const int64_t p_end = min(HW, p_begin + chunk);
+
+    // staging unit of this wave (in each tile): rows blk * 32 + lane / 8 + 8 r (r < 4), pixels pxh * 32 + (lane % 8) * 4 .. + 3
+    const int blk = wave >> 1, pxh = wave & 1;
+    const int srow = blk * 32 + (lane >> 3), spx = pxh * 32 + (lane & 7) * 4;
+    f32x4 ra[2][4], rb[2][4];  // two stages in flight: [slot][r]
+    // Raw values only: nothing here uses a loaded register, so the requests of two stages stay in flight (the row means of the
+    // covariance form are subtracted when the stage is split).  Interior stages of full tiles take the branch-free path.
+    auto load_unit = [&](f32x4 (&r4)[4], int tile, int64_t p0) {
+        const int64_t pp = p0 + spx;
+        if (p0 + GK <= p_end && tile * GT + GT <= C) {  // wave-uniform
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                r4[r] = *reinterpret_cast<const f32x4u*>(f + (int64_t)(tile * GT + srow + 8 * r) * HW + pp);
+            return;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = tile * GT + srow + 8 * r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row < C) {
+                if (pp + 4 <= p_end) {
+                    v = *reinterpret_cast<const f32x4u*>(f + (int64_t)row * HW + pp);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (pp + k < p_end) v[k] = f[(int64_t)row * HW + pp + k];
+                }
+            }
+            r4[r] = v;
+        }
+    };
+    // row means of this lane's four rows per tile (covariance form), and which (row, pixel) cells exist at all
+    float mrow[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = (t == 0 ? ti : tj) * GT + srow + 8 * r;
+            mrow[t][r] = (mean && row < C) ? mean[row] : 0.f;
+        }
+    auto load_stage = [&](int slot, int64_t p0) {
+#if defined(GX_ABL) && GX_ABL == 3
+        return;  // ablation: no global loads
+#endif
+        if (slot == 0) {
+            load_unit(ra[0], ti, p0);
+            if (!diag) load_unit(rb[0], tj, p0);
+        } else {
+            load_unit(ra[1], ti, p0);
+            if (!diag) load_unit(rb[1], tj, p0);
+        }
+    };
+    // split one unit (scale from this wave's own maximum) and write it into buffer `buf`
+    auto store_unit = [&](f32x4 (&r4)[4], int tile_slot, int64_t p0, unsigned char* buf) {
+        if (mean) {  // covariance form: centre the cells that exist (padding cells stay zero)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = (tile_slot == 0 ? ti : tj) * GT + srow + 8 * r;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (row < C && p0 + spx + k < p_end) r4[r][k] -= mrow[tile_slot][r];
+            }
+        }
+        float m = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m = fmaxf(m, fmaxf(fmaxf(fabsf(r4[r][0]), fabsf(r4[r][1])), fmaxf(fabsf(r4[r][2]), fabsf(r4[r][3]))));
+        m = wave_max_nonneg(m);
+        int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu) - 127;
+        e = m > 0.f ? max(e, -100) : 11;
+        const float sx = __builtin_bit_cast(float, (unsigned)(127 + 11 - e) << 23);
+        if (lane == 0)
+            reinterpret_cast<float*>(buf + nplanes * GXPLANE)[tile_slot * 4 + blk * 2 + pxh] = __builtin_bit_cast(float, (unsigned)(127 + e - 11) << 23);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v0 = r4[r][0] * sx, v1 = r4[r][1] * sx, v2 = r4[r][2] * sx, v3 = r4[r][3] * sx;
+            const unsigned h0 = gx_cvt_pk(v0, v1), h1 = gx_cvt_pk(v2, v3);
+            const g16x2 hh0 = __builtin_bit_cast(g16x2, h0), hh1 = __builtin_bit_cast(g16x2, h1);
+            const unsigned l0 = gx_cvt_pk(v0 - (float)hh0[0], v1 - (float)hh0[1]), l1 = gx_cvt_pk(v2 - (float)hh1[0], v3 - (float)hh1[1]);
+            unsigned char* dst = buf + (tile_slot * 2) * GXPLANE + (srow + 8 * r) * GXROW + spx * 2;
+            *reinterpret_cast<gu32x2*>(dst) = gu32x2{h0, h1};
+            *reinterpret_cast<gu32x2*>(dst + GXPLANE) = gu32x2{l0, l1};
+        }
+    };
+    auto store_stage = [&](int slot, int64_t p0, unsigned char* buf) {
+#if defined(GX_ABL) && GX_ABL == 2
+        asm volatile("" ::"v"(ra[0][0][0]), "v"(ra[1][0][0]));  // ablation: loads stay live, no split, no LDS writes
+        return;
+#endif
+        if (slot == 0) {
+            store_unit(ra[0], 0, p0, buf);
+            if (!diag) store_unit(rb[0], 1, p0, buf);
+        } else {
+            store_unit(ra[1], 0, p0, buf);
+            if (!diag) store_unit(rb[1], 1, p0, buf);
+        }
+    };
+
+    f32x16 master, acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) master[r] = acc0[r] = acc1[r] = 0.f;
+#if defined(GX_ABL) && GX_ABL == 1
+    const bool skip = true;  // ablation: no LDS fragment reads, no MFMAs
+#else
+    const bool skip = diag && wi == 1 && wj == 0;  // wave-uniform: the mirrored block of a diagonal tile
+#endif
+    const int bslot = diag ? 0 : 1;                 // the column operand comes from tile tj's planes
+    const int a_off = (wi * 32 + i32) * GXROW + half * 16;
+    const int b_off = (bslot * 2) * GXPLANE + (wj * 32 + i32) * GXROW + half * 16;
+
+    const int64_t nstages = p_begin < p_end ? (p_end - p_begin + GK - 1) / GK : 0;
+    if (nstages > 0) {
+        load_stage(0, p_begin);
+        if (nstages > 1) load_stage(1, p_begin + GK);
+        store_stage(0, p_begin, smem);
+        if (nstages > 2) load_stage(0, p_begin + 2 * GK);
+        __syncthreads();
+        for (int64_t st = 0; st < nstages; ++st) {
+            unsigned char* cur = smem + (st & 1) * GXBUFD;
+            unsigned char* nxt = smem + ((st + 1) & 1) * GXBUFD;
+            if (!skip) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const g16x8 ah = *reinterpret_cast<const g16x8*>(cur + a_off + q * 32);
+                    const g16x8 al = *reinterpret_cast<const g16x8*>(cur + GXPLANE + a_off + q * 32);
+                    const g16x8 bh = *reinterpret_cast<const g16x8*>(cur + b_off + q * 32);
+                    const g16x8 bl = *reinterpret_cast<const g16x8*>(cur + GXPLANE + b_off + q * 32);
+                    if (q < 2) {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc0, 0, 0, 0);
+                    } else {
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1, 0, 0, 0);
+                    }
+                }
+            }
+            // stage st + 1 (loaded a stage ago) -> the other buffer; then request stage st + 3 into the freed registers
+            if (st + 1 < nstages) {
+                if ((st + 1) & 1) store_stage(1, p_begin + (st + 1) * GK, nxt);
+                else store_stage(0, p_begin + (st + 1) * GK, nxt);
+                if (st + 3 < nstages) {
+                    if ((st + 1) & 1) load_stage(1, p_begin + (st + 3) * GK);
+                    else load_stage(0, p_begin + (st + 3) * GK);
+                }
+            }
+            if (!skip) {
+                const float* inv = reinterpret_cast<const float*>(cur + nplanes * GXPLANE);
+                const float s0 = inv[wi * 2 + 0] * inv[bslot * 4 + wj * 2 + 0], s1 = inv[wi * 2 + 1] * inv[bslot * 4 + wj * 2 + 1];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    master[r] = fmaf(acc0[r], s0, fmaf(acc1[r], s1, master[r]));
+                    acc0[r] = 0.f;
+                    acc1[r] = 0.f;
+                }
+            }
+            __syncthreads();  // buffer `nxt` is complete; every wave is done with `cur` (rewritten two stages on)
+        }
+    }
+    float* out = partial + ((int64_t)blockIdx.x * ksplit + ks) * (GT * GT);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        out[row * GT + wj * 32 + i32] = master[r];
+    }
+}
+
 // First level of the slab sum when there are many slabs (relu1_1 at 1024x1024: 745): grid (pairs, 16, groups), every thread
 // adds the GF_FOLD slabs of its group in index order (fp64) and leaves the sum in the group's first slab.  Fixed order.
 constexpr int GF_FOLD = 32;
@@ -207,7 +425,8 @@ template <bool ACC, bool MASK>
 __global__ void __launch_bounds__(256)
 gram_bwd_kernel(const float* __restrict__ d, const float* __restrict__ f, const float* __restrict__ mean,
                 const float* __restrict__ rmask, float* __restrict__ gf, int C, int64_t HW, int accumulate) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 x (Xl[32][256] + Wl[32][64])
+    extern __shared__ __attribute__((aligned(16))) float smem_f32[];  // 2 x (Xl[32][256] + Wl[32][64])
+    float* smem = smem_f32;
     constexpr int BUF = GB_KC * GB_PX + GB_KC * GB_CO;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, half = lane >> 5;
@@ -360,8 +579,25 @@ int maua_gram_fwd(const float* f, float* gram, float* row_mean_out, int c, int64
         rc = check_launch("row_mean_finish_kernel");
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(gram_partial_kernel, dim3(npairs, ksplit), dim3(256), 0, s, f, center ? row_mean_out : nullptr,
-                       (float*)workspace, c, hw, ksplit, chunk);
+    static const bool use_x3 = [] {
+        const char* e = getenv("MAUA_GRAM_X3");  // "0": the fp32-MFMA kernel (A/B comparisons)
+        return !(e && e[0] == '0');
+    }();
+    if (use_x3) {
+        const int nplanes = c <= GT ? 2 : 4;
+        const size_t lds = 2 * ((size_t)nplanes * GXPLANE + 64);
+        static bool attr_set = false;
+        if (!attr_set) {  // more than 64 KB of dynamic LDS needs the opt-in
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gram_x3_partial_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GXBUF);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(gram_x3_partial_kernel, dim3(npairs, ksplit), dim3(256), lds, s, f, center ? row_mean_out : nullptr,
+                           (float*)workspace, c, hw, ksplit, chunk, nplanes);
+    }
+    else
+        hipLaunchKernelGGL(gram_partial_kernel, dim3(npairs, ksplit), dim3(256), 0, s, f, center ? row_mean_out : nullptr,
+                           (float*)workspace, c, hw, ksplit, chunk);
     int rc = check_launch("gram_partial_kernel");
     if (rc) return rc;
     int kstride = 1;
