@@ -53,6 +53,19 @@ def _x3w_enabled():
     return os.environ.get("MAUA_CONV_X3W", "1") == "1"
 
 
+_X3W_MIN_PIXELS = None
+
+
+def _x3w_min_pixels():
+    """Planes smaller than this run conv_x3.hip (4-row tiles, 1024 workgroup slots): on maps of a few tiles the wide kernel's
+    8-row tiles and 512 slots leave the chip emptier (measured at 256 x 256: 726 vs 793 it/s).  MAUA_X3W_MIN_PIXELS overrides."""
+    global _X3W_MIN_PIXELS
+    if _X3W_MIN_PIXELS is None:
+        import os
+        _X3W_MIN_PIXELS = int(os.environ.get("MAUA_X3W_MIN_PIXELS", 64 * 64))
+    return _X3W_MIN_PIXELS
+
+
 def conv3x3_mfma(x, mod, backward, out=None, out_relu_mask=None, relu=False, workspace=None):
     """The fp32-accurate reduced-width matrix-core convolution of a 3x3 stride-1 layer (forward, or backward-data when
     `backward`): fp16x3 or bf16x6 according to MAUA_CONV_X3."""
@@ -62,7 +75,8 @@ def conv3x3_mfma(x, mod, backward, out=None, out_relu_mask=None, relu=False, wor
     else:
         cout, p, bias = mod.out_channels, pad, mod.bias_device()
     consumed = mod.out_channels if backward else mod.in_channels
-    if _x3_enabled() and _x3w_enabled() and hip.conv_x3w_supported(consumed, x.shape[2], x.shape[3], p):
+    if _x3_enabled() and _x3w_enabled() and x.shape[2] * x.shape[3] >= _x3w_min_pixels() and \
+            hip.conv_x3w_supported(consumed, x.shape[2], x.shape[3], p):
         bf, bb, wsc = mod.banks3w()
         return hip.conv3x3_x3w(x, bb if backward else bf, wsc, bias, cout, p, relu, out=out, out_relu_mask=out_relu_mask,
                                workspace=workspace)
