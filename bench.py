@@ -10,11 +10,12 @@ one RCCL broadcast of the conv weights and style targets; there is no per-iterat
 Before the timed region the L-BFGS history (100 pairs) is filled by running `history` real iterations, so the
 timed steps are steady-state iterations (the two-loop cost grows until the history is full).
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the split-precision 3x3 convolution, conv_x3.hip
-by default): algorithmic fp32-equivalent FLOPs per launch / average launch duration measured with HIP events on the launch
-stream, against the dense 16-bit MFMA peak divided by the MFMAs one product block costs (2500 / 3 for fp16x3, 2500 / 6 for
-bf16x6; 157.3 TFLOP/s when the fp32 matrix cores are selected with MAUA_CONV_X6=0); `traffic` comes from the committed
-PMC passes.  `cpu_baseline` times the CPU oracle on this host's cores on a bounded sample.
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the split-precision 3x3 convolution: conv_x3w.hip,
+with conv_x3.hip on maps below 64x64): algorithmic fp32-equivalent FLOPs per launch / average launch duration measured with
+HIP events on the launch stream, against the dense 16-bit MFMA peak divided by the MFMAs one product block costs (2500 / 3
+for fp16x3, 2500 / 6 for bf16x6; 157.3 TFLOP/s when the fp32 matrix cores are selected with MAUA_CONV_X6=0); `traffic` comes
+from the committed PMC passes.  `cpu_baseline` times the CPU oracle on this host's cores at the benchmarked size; `extra`
+carries the 512x512 figure.
 """
 import argparse
 import json
@@ -133,11 +134,11 @@ def cpu_baseline(S, optimizer, iters=5, repeats=3):
 
 
 def pmc_traffic(prefix):
-    """HBM-side bytes per launch of the dominant kernel from the committed PMC pass (profiles/pmc_r01_traffic.json, written
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC pass (profiles/pmc_r02_traffic.json, written
     by tools/pmc_summary.py from separate `rocprofv3 --pmc` runs of this same command).  Reads: request counters x 64 B,
     doubled as MI355X_MICROARCH.md prescribes for gfx950 (our own calibration, profiles/pmc_r01_calibration.json: x2.0
     for 16 B/lane streams, x1.2-1.6 for 4 B/lane patterns, so this is an upper bound); writes are exact."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_r01_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_r02_traffic.json")
     if not os.path.exists(path):
         return None
     with open(path) as f:
@@ -151,7 +152,7 @@ def pmc_traffic(prefix):
     if not n:
         return None
     return {"bytes": round((2 * rd + wr) / n),
-            "note": "per launch, from profiles/pmc_r01_traffic.json (separate rocprofv3 --pmc passes of this command): "
+            "note": "per launch, from profiles/pmc_r02_traffic.json (separate rocprofv3 --pmc passes of this command): "
                     "2 x TCC_EA0_RDREQ x 64 B (gfx950 correction, upper bound for 4 B/lane loads) + write requests"}
 
 
@@ -337,8 +338,9 @@ def main():
     dominant = "conv3x3_split" if x6 else "conv"  # with bf16x6 on, conv1_1 (3 channels) runs other kernels: not counted here
     conv = [(fl, e0.elapsed_time(e1)) for tag, fl, nb, e0, e1 in timer if tag.startswith(dominant)]
     roofline = None
-    pmc = pmc_traffic(("maua::conv_x3_kernel<" if models._x3_enabled() else "maua::conv_x6_kernel<") if x6
-                      else "maua::conv_mfma2_kernel<") if S == 1024 else None
+    x3w = x6 and models._x3_enabled() and models._x3w_enabled()
+    pmc = pmc_traffic((("maua::conv_x3w_kernel<" if x3w else "maua::conv_x3_kernel<") if models._x3_enabled() else
+                       "maua::conv_x6_kernel<") if x6 else "maua::conv_mfma2_kernel<") if S == 1024 else None
     if conv:
         tot_fl, tot_ms = sum(c[0] for c in conv), sum(c[1] for c in conv)
         achieved = tot_fl / (tot_ms * 1e-3) / 1e12
@@ -355,15 +357,19 @@ def main():
         per_product = 3 if x3 else X6_MFMAS_PER_PRODUCT
         peak = BF16_MFMA_PEAK_TFLOPS / per_product if x6 else FP32_MFMA_PEAK_TFLOPS
         roofline = {"bound": "mfma",
-                    "kernel": ("conv_x3_kernel (3x3 conv fwd + bwd-data, fp16x3)" if x3 else
+                    "kernel": (("conv_x3w_kernel (3x3 conv fwd + bwd-data, fp16x3, 16-channel chunks)" if x3w else
+                                "conv_x3_kernel (3x3 conv fwd + bwd-data, fp16x3)") if x3 else
                                "conv_x6_kernel (3x3 conv fwd + bwd-data, bf16x6)") if x6 else "conv_mfma2_kernel (fwd + bwd-data)",
                     "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     "peak_note": (f"algorithmic fp32-equivalent FLOPs; peak = 2500 TFLOP/s dense {'fp16' if x3 else 'bf16'} / "
-                                  f"{per_product} MFMAs per product block; 16-bit multiply-accumulate work = achieved x {per_product}; "
-                                  f"matrix-pipe time = achieved x {per_product} x 10/9 (the ninth tap's K=8 MFMA holds the pipe as "
-                                  "long as a K=16 one: 5 steps for 4.5)") if x6 else "fp32 MFMA peak",
+                                  f"{per_product} MFMAs per product block; 16-bit multiply-accumulate work = achieved x {per_product}"
+                                  + ("; every tap is a full K=16 MFMA step (16-channel chunks), so that is also the matrix-pipe time; "
+                                     "the kernel is power-bound: in-kernel clock 1.56 GHz under this load (profiles/probes_r02.md), "
+                                     "i.e. 1.63 PFLOP/s of fp16 MFMA at the clock the chip holds" if x3w else
+                                     f"; matrix-pipe time = achieved x {per_product} x 10/9 (the ninth tap's K=8 MFMA holds the pipe as "
+                                     "long as a K=16 one: 5 steps for 4.5)")) if x6 else "fp32 MFMA peak",
                     "hw_16bit_tflops": round(achieved * per_product, 1) if x6 else None,
-                    "hw_pipe_equiv_tflops": round(achieved * per_product * 10 / 9, 1) if x6 else None,
+                    "hw_pipe_equiv_tflops": round(achieved * per_product * (1.0 if x3w else 10 / 9), 1) if x6 else None,
                     "traffic": pmc["bytes"] if pmc else None, "traffic_note": pmc["note"] if pmc else None,
                     "algorithmic_bytes_per_launch": round(sum(nb for tag, fl, nb, e0, e1 in timer if tag.startswith(dominant)) / len(conv)),
                     "events_from": ("second pass of K eager iterations (the timed region replays a hipGraph)" if eager_ms is not None

@@ -189,6 +189,28 @@ class StyleEngine:
                              hip.conv_x3w_workspace_bytes(n, cout, oh, ow, cin, 2 - s.pad))
         self.ws = torch.empty(ws, dtype=torch.uint8, device=dev)
         self.x_static = torch.empty(self.shape, device=dev)
+        if os.environ.get("MAUA_DEBUG_POISON") == "1":  # tests: every buffer starts as NaN, so a read-before-write shows up
+            for t in list(self.act.values()) + list(self.gbuf.values()) + list(self.gram.values()) + list(self.dmat.values()) + \
+                    list(self.gram_d.values()) + list(self.dmat_d.values()):
+                if t is not None:
+                    t.fill_(float("nan"))
+            self.ws.view(torch.float32)[:] = float("nan") if self.ws.numel() % 4 == 0 else 0
+        # Independent frames: the per-frame kernels (Gram, losses, Gram backward, optimiser) of different frames share
+        # nothing, and most of them are too small to fill the chip or are latency-bound chains - they run on a few side
+        # streams so that the GPU overlaps them (fork after the kernel that produced their input, join before the next
+        # kernel that reads their output).  Every stream has its own reduction / split-K workspace.
+        self.side, self.side_ws, self.ev_main, self.ev_side = [], [], None, []
+        if B > 1 and self.independent and int(os.environ.get("MAUA_SIDE_STREAMS", "4")) > 0:
+            ns = min(B, int(os.environ.get("MAUA_SIDE_STREAMS", "4")))
+            small = hip.reduce_workspace_bytes(max(t.numel() for t in self.gbuf.values()) // B)
+            for s in self.steps:
+                if s.kind == "style":
+                    c, hw = shapes[s.src][1], shapes[s.src][2] * shapes[s.src][3]
+                    small = max(small, hip.gram_workspace_bytes(c, hw), 4 * c + 256)
+            self.side = [torch.cuda.Stream(device=dev) for _ in range(ns)]
+            self.side_ws = [torch.empty(small, dtype=torch.uint8, device=dev) for _ in range(ns)]
+            self.ev_main = torch.cuda.Event()
+            self.ev_side = [torch.cuda.Event() for _ in range(ns)]
 
     # -- one evaluation --------------------------------------------------------------------------------
     def _style_terms(self, s, B):
@@ -250,6 +272,29 @@ class StyleEngine:
             raise UnsupportedNet("dynamic style target of another shape")
         return True
 
+    def fork(self):
+        """Side streams wait for everything enqueued on the current stream so far."""
+        if self.side:
+            self.ev_main.record()
+            for st in self.side:
+                st.wait_event(self.ev_main)
+
+    def join(self):
+        """The current stream waits for everything enqueued on the side streams."""
+        cur = torch.cuda.current_stream()
+        for st, ev in zip(self.side, self.ev_side):
+            ev.record(st)
+            cur.wait_event(ev)
+
+    def frame_stream(self, b):
+        """(context manager selecting frame b's stream, that stream's workspace): the current stream and the shared workspace
+        when side streams are off."""
+        if not self.side:
+            import contextlib
+            return contextlib.nullcontext(), self.ws
+        k = b % len(self.side)
+        return torch.cuda.stream(self.side[k]), self.side_ws[k]
+
     def _timed(self, tag, flops, nbytes, fn):
         """Run one kernel launch; when a timer list is attached, bracket it with events on the launch stream."""
         if self.timer is None:
@@ -306,12 +351,15 @@ class StyleEngine:
                 f = a[s.src]
                 c, n = f.shape[1], f[0].nelement()
                 lw, gw = self._coefficients(s)  # the single-frame weights: static + dynamic term of the same Gram
+                self.fork()  # joined before the backward pass starts: nothing in the rest of the forward pass needs these
                 for b in range(f.shape[0]):
                     mean_b = self.mean[id(s)][b] if s.mod.use_covariance else None
-                    self._timed("gram_fwd", 2 * c * c * (n // c), n * 4 + c * c * 4, lambda: hip.gram_fwd(
-                        f[b:b + 1], 1.0 / n, s.mod.use_covariance, out=self.gram[id(s)][b], mean_out=mean_b, workspace=self.ws))
-                    hip.mse_fwd_bwd(self.gram[id(s)][b], s.mod.target, self.dmat[id(s)][b], lw / (c * c), gw * 4.0 / (c * c) / n,
-                                    False, self.slots_all[b, s.slot:s.slot + 1], workspace=self.ws)
+                    ctx, wsb = self.frame_stream(b)
+                    with ctx:
+                        self._timed("gram_fwd", 2 * c * c * (n // c), n * 4 + c * c * 4, lambda: hip.gram_fwd(
+                            f[b:b + 1], 1.0 / n, s.mod.use_covariance, out=self.gram[id(s)][b], mean_out=mean_b, workspace=wsb))
+                        hip.mse_fwd_bwd(self.gram[id(s)][b], s.mod.target, self.dmat[id(s)][b], lw / (c * c),
+                                        gw * 4.0 / (c * c) / n, False, self.slots_all[b, s.slot:s.slot + 1], workspace=wsb)
             elif s.kind == "style" and self._active(s, a[s.src].shape) and a[s.src].shape[0] > 1:
                 f = a[s.src]
                 B, c, n = f.shape[0], f.shape[1], f[0].nelement()
@@ -367,26 +415,33 @@ class StyleEngine:
 
         cur = None  # activation index whose gradient buffer currently holds d loss / d act
         indep = self.independent and x.shape[0] > 1
+        if indep:
+            self.join()  # the per-frame Gram / loss kernels of the forward pass
         for s in reversed(self.steps):
             if indep and s.kind in ("style", "content", "tv"):
                 if s.kind != "tv" and not self._active(s, a[s.src].shape):
                     continue
                 f = a[s.src]
                 acc = cur == s.src
+                last_step = s.kind == "tv"  # module 0: the totals can be formed on the frame's stream right behind it
+                self.fork()
                 for b in range(f.shape[0]):
                     slot = self.slots_all[b, s.slot:s.slot + 1]
-                    if s.kind == "style":
-                        c, n = f.shape[1], f[0].nelement()
-                        self._timed("gram_bwd", 2 * c * c * (n // c), n * 4 * 3 + c * c * 4, lambda: hip.gram_bwd(
-                            self.dmat[id(s)][b], f[b], self.mean[id(s)][b] if s.mod.use_covariance else None, g[s.src][b], acc,
-                            workspace=self.ws, relu_mask=f[b] if premask(s) else None))
-                    elif s.kind == "content":
-                        lw, gw = self._coefficients(s)
-                        n = f[0].nelement()
-                        hip.mse_fwd_bwd(f[b], s.mod.target[b], g[s.src][b], lw / n, gw * 2.0 / n, acc, slot, workspace=self.ws,
-                                        mask_grad_by_x=premask(s))
-                    else:
-                        hip.tv_fwd_bwd(f[b:b + 1], g[0][b:b + 1], s.mod.strength, acc, slot, workspace=self.ws)
+                    ctx, wsb = self.frame_stream(b)
+                    with ctx:
+                        if s.kind == "style":
+                            c, n = f.shape[1], f[0].nelement()
+                            self._timed("gram_bwd", 2 * c * c * (n // c), n * 4 * 3 + c * c * 4, lambda: hip.gram_bwd(
+                                self.dmat[id(s)][b], f[b], self.mean[id(s)][b] if s.mod.use_covariance else None, g[s.src][b],
+                                acc, workspace=wsb, relu_mask=f[b] if premask(s) else None))
+                        elif s.kind == "content":
+                            lw, gw = self._coefficients(s)
+                            n = f[0].nelement()
+                            hip.mse_fwd_bwd(f[b], s.mod.target[b], g[s.src][b], lw / n, gw * 2.0 / n, acc, slot, workspace=wsb,
+                                            mask_grad_by_x=premask(s))
+                        else:
+                            hip.tv_fwd_bwd(f[b:b + 1], g[0][b:b + 1], s.mod.strength, acc, slot, workspace=wsb)
+                self.join()
                 cur = s.src
             elif s.kind == "style" and a[s.src].shape[0] > 1:
                 if self._active(s, a[s.src].shape):

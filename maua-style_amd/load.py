@@ -34,6 +34,14 @@ def preprocess(image_path):
     return (bgr - _MEAN_BGR[:, None, None]).unsqueeze(0)
 
 
+def preprocess_u8(rgb_hwc):
+    """`preprocess` of an image that is already in memory as (H,W,3) uint8 RGB (CPU or device tensor): the same fp32
+    operations as reading it back from a (lossless) PNG, so the result is bit-identical to preprocess(path)."""
+    chw = rgb_hwc.permute(2, 0, 1).float() / 255
+    bgr = (chw * 255)[th.tensor([2, 1, 0], device=rgb_hwc.device)]
+    return (bgr - _MEAN_BGR.to(rgb_hwc.device)[:, None, None]).unsqueeze(0)
+
+
 def deprocess(output_tensor):
     """(1,3,H,W) network-space tensor -> PIL RGB image; values are clamped to [0,1] and truncated to 8 bits like
     torchvision's ToPILImage (load.py:47-52)."""

@@ -226,12 +226,22 @@ class PixelOptimizer:
     def _lbfgs_move(self, grad, total):
         """One L-BFGS update per frame (a single one unless `independent`): device-side, no sync."""
         a = self.args
+        eng = self.engine if self.independent else None
+        if eng is not None:
+            eng.fork()  # each frame's five kernels (two bandwidth-bound sweeps around a one-wave serial chain) on its own stream
         for b, (st, xf) in enumerate(zip(self.states, self.frames)):
             gb = grad[b] if self.independent else grad
             lb = None
             if th.is_tensor(total) and total.is_cuda:
                 lb = total[b:b + 1] if self.independent else total
-            st.iterate(xf, gb, 1.0, float(a.lbfgs_tolerance_change), float(a.lbfgs_tolerance_grad), lb)
+            if eng is not None:
+                ctx, _ = eng.frame_stream(b)
+                with ctx:
+                    st.iterate(xf, gb, 1.0, float(a.lbfgs_tolerance_change), float(a.lbfgs_tolerance_grad), lb)
+            else:
+                st.iterate(xf, gb, 1.0, float(a.lbfgs_tolerance_change), float(a.lbfgs_tolerance_grad), lb)
+        if eng is not None:
+            eng.join()
 
     def stopped(self):
         """Every frame's L-BFGS has hit one of its stop tests (host sync; called every 25 iterations)."""

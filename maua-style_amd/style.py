@@ -24,6 +24,7 @@ import random
 
 import numpy as np
 import torch as th
+from PIL import Image
 import torch.nn.functional as F
 
 import config
@@ -314,10 +315,15 @@ def vid_img(args):
     mode = args.match_histograms
 
     prev_size = None
-    writer, pending = concurrent.futures.ThreadPoolExecutor(max_workers=2), {}
+    writer, pending = concurrent.futures.ThreadPoolExecutor(max_workers=4), {}
+    # What the next pass reads back is what this pass wrote: the 8-bit image of every finished frame stays in memory (768 KB at
+    # 512 x 512), so the PNG only has to be decoded when it comes from an earlier run (resume) or was colour-transferred on
+    # the way out.  Decoded, rescaled content frames are kept per scale as well (every pass starts from them again).
+    written, content_cache = {}, {}
     for size_n, (current_size, num_iters) in enumerate(zip(args.image_sizes, args.num_iters)):
         print("\nCurrent size {}px".format(current_size))
         os.makedirs(output_dir + "/" + str(current_size), exist_ok=True)
+        content_cache.clear()
         content_scale = current_size / max(*content_size)
         content_area = content_scale ** 2 * content_size[0] * content_size[1]
         style_images = _scaled_styles(style_images_big, content_area, args)
@@ -340,16 +346,21 @@ def vid_img(args):
                 contents, inits, post_noise = [], [], []
                 for frame in group:  # host phase, frame by frame: every global-RNG draw in the reference's order
                     print("Optimizing... size: %s, pass: %s, frame: %s" % (current_size, pass_n + 1, name(frame)))
-                    content = _resize(up(load.preprocess(frame)), scale_factor=content_scale)
-                    content = match_histogram(content, style_images_big[0], mode=mode)
+                    if frame not in content_cache:
+                        content_cache[frame] = _resize(up(load.preprocess(frame)), scale_factor=content_scale)
+                    content = match_histogram(content_cache[frame], style_images_big[0], mode=mode)
                     if size_n == 0 and pass_n == 0:
                         pastiche = up(th.randn(content.size()).mul(0.001)) if args.init == "random" else content.clone()
                     else:  # previous result of this frame: last pass of the previous size, or previous pass of this size
                         src = ("%s/%s/%s_%s.png" % (output_dir, prev_size, passes, name(frame)) if pass_n == 0 else
                                "%s/%s/%s_%s.png" % (output_dir, current_size, pass_n, name(frame)))
-                        if src in pending:  # still being written by the background writer
-                            pending.pop(src).result()
-                        pastiche = _resize(up(load.preprocess(src)), size=tuple(int(v) for v in content.size()[2:]))
+                        if src in written:  # this run wrote it: same bytes as the file holds
+                            previous = load.preprocess_u8(written.pop(src))
+                        else:
+                            if src in pending:  # still being written by the background writer
+                                pending.pop(src).result()
+                            previous = up(load.preprocess(src))
+                        pastiche = _resize(previous, size=tuple(int(v) for v in content.size()[2:]))
                     post_noise.append(draw_match_noise(content.shape, style_images_big[0], mode=mode))
                     contents.append(content)
                     inits.append(pastiche)
@@ -360,7 +371,13 @@ def vid_img(args):
                     out = match_histogram(outs[k:k + 1], style_images_big[0], mode=mode, _noise=post_noise[k])
                     # deprocessing = one kernel + a 3-byte-per-pixel download, here; colour transfer and PNG encoding of this
                     # batch run on the writer threads beside the next batch's optimisation
-                    img = load.deprocess(out)
+                    if on_gpu and args.original_colors != 1:
+                        import hip
+                        u8 = hip.deprocess_u8(out.float().contiguous(), load._MEAN_BGR)
+                        written[out_path(frame)] = u8
+                        img = Image.fromarray(u8.cpu().numpy(), mode="RGB")
+                    else:
+                        img = load.deprocess(out)
                     cimg = load.deprocess(contents[k]) if args.original_colors == 1 else None
                     pending[out_path(frame)] = writer.submit(_finish_frame, img, cimg, out_path(frame), args.original_colors)
         prev_size = current_size
