@@ -648,3 +648,28 @@ def test_frame_batch_nin(weight_files):
     single = torch.cat([optim.optimize_frames(contents[k:k + 1].cuda(), [style], contents[k:k + 1].clone().cuda(), N, args, net, losses,
                                               planned_frames=B).cpu() for k in range(B)])
     assert torch.equal(together, single)
+
+
+def test_engine_reads_no_uninitialised_memory(weight_files, monkeypatch):
+    """MAUA_DEBUG_POISON=1 fills every engine buffer (activations, gradients, Gram / D matrices, workspace) with NaN when it is
+    allocated: a kernel that read before anything wrote would carry the NaN into the losses or the gradient.  Same bits as the
+    unpoisoned run, on the single-image plan and on a batch of independent frames."""
+    import engine
+    import models
+    import optim
+    res = {}
+    for poison in ("0", "1"):
+        monkeypatch.setenv("MAUA_DEBUG_POISON", poison)
+        args = product_args(weight_files, S=96)
+        content, style, init = synth.images(96)
+        net, losses = build(args, content, [style], 96)
+        eng = engine.StyleEngine(net, losses)
+        slots, total, grad = eng.feval(init.cuda())
+        torch.cuda.synchronize()
+        frames = torch.cat([synth.images(96, seed=80 + k)[0] for k in range(3)])
+        optim.set_model_args(args, 96)
+        net2, losses2 = models.load_model(args)
+        batch = optim.optimize_frames(frames.cuda(), [style], frames.clone().cuda(), 3, args, net2, losses2).cpu()
+        res[poison] = (slots.clone().cpu(), grad.clone().cpu(), batch)
+    for a, b in zip(res["0"], res["1"]):
+        assert torch.isfinite(b).all() and torch.equal(a, b)
