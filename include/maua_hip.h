@@ -153,6 +153,15 @@ int maua_pool2d_fwd(const float* x, float* y, int n, int c, int h, int w, int k,
 int maua_pool2d_bwd(const float* gy, const float* x, float* gx, int n, int c, int h, int w, int k, int stride,
                     int ceil_mode, int mode, int relu_mask_by_x, maua_stream_t stream);
 
+/* 2x2 stride-2 max pooling on even planes (every VGG pool, `nn.MaxPool2d(2, 2)` models.py:120) with the decision kept: the
+ * forward pass also writes one byte per window (bits 1:0 = position of the first maximum in scan order, ATen's tie rule; bit 2
+ * = the winning value is <= 0), the backward pass routes the gradient from those bytes without reading the input map again;
+ * `relu_mask` as in maua_pool2d_bwd's relu_mask_by_x.  Bit-identical to maua_pool2d_fwd / maua_pool2d_bwd. */
+int maua_pool2x2_codes_supported(int n, int c, int h, int w);
+int maua_pool2x2_fwd_codes(const float* x, float* y, unsigned char* codes, int n, int c, int h, int w, maua_stream_t stream);
+int maua_pool2x2_bwd_codes(const float* gy, const unsigned char* codes, float* gx, int n, int c, int h, int w, int relu_mask,
+                           maua_stream_t stream);
+
 /* ---- Gram / covariance matrix: loss.GramMatrix.forward, loss.py:67-91 (torch.mm at :91) ----------- */
 /* gram[C][C] = scale * Fc Fc^T with Fc = f[C][hw] (minus row means when `center` != 0, loss.py:87-89).
  * row_mean_out (nullable unless center): receives the C row means.  Split-K over hw with a fixed-order reduction.

@@ -239,6 +239,42 @@ pool2x2_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x, fl
     *reinterpret_cast<float2*>(gx + base + W) = make_float2(arg == 2 ? g : 0.f, arg == 3 ? g : 0.f);
 }
 
+// The same pair with the decision kept: the forward pass leaves one byte per window - the winner's position in scan order
+// (bits 1:0) and whether the winning value is <= 0 (bit 2: for a ReLU input, its threshold_backward) - so that the backward
+// pass routes the gradient without reading the input map again (pool1 at 1024x1024: 603 -> 352 MB).  Same decisions, same bits.
+__global__ void __launch_bounds__(256)
+pool2x2_fwd_codes_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ codes, int W, int OW) {
+    const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y;
+    if (ox >= OW) return;
+    const int64_t OHl = gridDim.y;
+    const float* p = x + ((int64_t)blockIdx.z * 2 * OHl + 2 * oy) * W + 2 * ox;
+    const float2 r0 = *reinterpret_cast<const float2*>(p), r1 = *reinterpret_cast<const float2*>(p + W);
+    float m = r0.x;
+    int arg = 0;
+    if (r0.y > m || r0.y != r0.y) { m = r0.y; arg = 1; }
+    if (r1.x > m || r1.x != r1.x) { m = r1.x; arg = 2; }
+    if (r1.y > m || r1.y != r1.y) { m = r1.y; arg = 3; }
+    const int64_t o = ((int64_t)blockIdx.z * OHl + oy) * OW + ox;
+    y[o] = m;
+    codes[o] = (unsigned char)(arg | (m > 0.f ? 0 : 4));
+}
+
+__global__ void __launch_bounds__(256)
+pool2x2_bwd_codes_kernel(const float* __restrict__ gy, const unsigned char* __restrict__ codes, float* __restrict__ gx, int W,
+                         int OW, int relu_mask) {
+    const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y;
+    if (ox >= OW) return;
+    const int64_t OHl = gridDim.y;
+    const int64_t base = ((int64_t)blockIdx.z * 2 * OHl + 2 * oy) * W + 2 * ox;
+    const int64_t o = ((int64_t)blockIdx.z * OHl + oy) * OW + ox;
+    const int code = codes[o];
+    const int arg = code & 3;
+    float g = gy[o];
+    if (relu_mask && (code & 4)) g = 0.f;
+    *reinterpret_cast<float2*>(gx + base) = make_float2(arg == 0 ? g : 0.f, arg == 1 ? g : 0.f);
+    *reinterpret_cast<float2*>(gx + base + W) = make_float2(arg == 2 ? g : 0.f, arg == 3 ? g : 0.f);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // MSE: partial[b] = sum over the block's elements of (x-t)^2 (double); grad (+)= gs * (x - t).
 __global__ void __launch_bounds__(256)
@@ -408,6 +444,27 @@ int maua_pool2d_bwd(const float* gy, const float* x, float* gx, int n, int c, in
     hipLaunchKernelGGL(pool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, gy, x, gx, (int64_t)n * c,
                        h, w, oh, ow, k, stride, mode, relu_mask_by_x);
     return check_launch("pool_bwd_kernel");
+}
+
+int maua_pool2x2_codes_supported(int n, int c, int h, int w) {
+    return conv_dims_ok(n, c, h, w, 1, 0) && h % 2 == 0 && w % 2 == 0 && (int64_t)n * c <= 65535 && h / 2 <= 65535;
+}
+
+int maua_pool2x2_fwd_codes(const float* x, float* y, unsigned char* codes, int n, int c, int h, int w, maua_stream_t stream) {
+    MAUA_REQUIRE(x && y && codes, MAUA_E_INVAL, "pool2x2_fwd_codes: null pointer");
+    MAUA_REQUIRE(maua_pool2x2_codes_supported(n, c, h, w), MAUA_E_UNSUPPORTED, "pool2x2_fwd_codes: needs even planes");
+    hipLaunchKernelGGL(pool2x2_fwd_codes_kernel, dim3((w / 2 + 255) / 256, h / 2, n * c), dim3(256), 0, (hipStream_t)stream, x, y,
+                       codes, w, w / 2);
+    return check_launch("pool2x2_fwd_codes_kernel");
+}
+
+int maua_pool2x2_bwd_codes(const float* gy, const unsigned char* codes, float* gx, int n, int c, int h, int w, int relu_mask,
+                           maua_stream_t stream) {
+    MAUA_REQUIRE(gy && gx && codes, MAUA_E_INVAL, "pool2x2_bwd_codes: null pointer");
+    MAUA_REQUIRE(maua_pool2x2_codes_supported(n, c, h, w), MAUA_E_UNSUPPORTED, "pool2x2_bwd_codes: needs even planes");
+    hipLaunchKernelGGL(pool2x2_bwd_codes_kernel, dim3((w / 2 + 255) / 256, h / 2, n * c), dim3(256), 0, (hipStream_t)stream, gy,
+                       codes, gx, w, w / 2, relu_mask);
+    return check_launch("pool2x2_bwd_codes_kernel");
 }
 
 size_t maua_reduce_workspace_bytes(int64_t count) { return (size_t)reduce_blocks(count, 1024) * sizeof(double); }

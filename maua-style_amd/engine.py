@@ -134,6 +134,13 @@ class StyleEngine:
                 shapes[s.dst] = (n, c, hip.pool_out_size(h, s.k, s.stride, s.ceil), hip.pool_out_size(w, s.k, s.stride, s.ceil))
         self.act = {k: (None if k == 0 else torch.empty(v, device=dev)) for k, v in shapes.items()}
         self.gbuf = {k: torch.empty(v, device=dev) for k, v in shapes.items()}
+        # 2x2/2 max pools on even planes keep their decisions (one byte per window) for the backward pass
+        self.pool_codes = {}
+        if os.environ.get("MAUA_POOL_CODES", "1") != "0":
+            for s in self.steps:
+                if s.kind == "pool" and s.k == 2 and s.stride == 2 and s.mode == "max" and \
+                        hip.pool2x2_codes_supported(*shapes[s.src]):
+                    self.pool_codes[id(s)] = torch.empty(shapes[s.dst], dtype=torch.uint8, device=dev)
         # B > 1 (img_vid's windows of frames): every loss module has several terms - one per frame, plus the cross-frame
         # dynamic Gram term of a StyleLoss - each with its own slot behind the per-module ones
         self.terms = {}
@@ -346,7 +353,10 @@ class StyleEngine:
             elif s.kind == "relu":
                 hip.relu_(a[s.src])
             elif s.kind == "pool":
-                hip.pool2d_fwd(a[s.src], s.k, s.stride, s.ceil, s.mode, out=a[s.dst])
+                if id(s) in self.pool_codes:
+                    hip.pool2x2_fwd_codes(a[s.src], a[s.dst], self.pool_codes[id(s)])
+                else:
+                    hip.pool2d_fwd(a[s.src], s.k, s.stride, s.ceil, s.mode, out=a[s.dst])
             elif s.kind == "style" and self.independent and a[s.src].shape[0] > 1 and self._active(s, a[s.src].shape):
                 f = a[s.src]
                 c, n = f.shape[1], f[0].nelement()
@@ -523,8 +533,11 @@ class StyleEngine:
                 hip.relu_bwd(g[s.src], a[s.src], out=g[s.src])
             elif s.kind == "pool":
                 assert cur == s.dst
-                hip.pool2d_bwd(g[s.dst], a[s.src], s.k, s.stride, s.ceil, s.mode, out=g[s.src],
-                               relu_mask_by_x=premask(s))
+                if id(s) in self.pool_codes:
+                    hip.pool2x2_bwd_codes(g[s.dst], self.pool_codes[id(s)], g[s.src], premask(s))
+                else:
+                    hip.pool2d_bwd(g[s.dst], a[s.src], s.k, s.stride, s.ceil, s.mode, out=g[s.src],
+                                   relu_mask_by_x=premask(s))
                 cur = s.src
         if cur != 0:
             hip.fill_(g[0], 0.0)

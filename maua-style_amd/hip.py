@@ -51,6 +51,9 @@ SIGNATURES = {
     "maua_pool_out_size": (c_i, [c_i, c_i, c_i, c_i]),
     "maua_pool2d_fwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "maua_pool2d_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "maua_pool2x2_codes_supported": (c_i, [c_i, c_i, c_i, c_i]),
+    "maua_pool2x2_fwd_codes": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "maua_pool2x2_bwd_codes": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "maua_gram_workspace_bytes": (c_sz, [c_i, c_i64]),
     "maua_gram_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i64, c_f, c_i, c_p, c_sz, c_p]),
     "maua_reduce_workspace_bytes": (c_sz, [c_i64]),
@@ -374,6 +377,25 @@ def pool2d_bwd(gy, x, k, stride, ceil_mode, mode, out=None, relu_mask_by_x=False
         out = torch.empty_like(x)
     _check(lib().maua_pool2d_bwd(_ptr(_f32(gy, "gy")), _ptr(x), _ptr(out), n, c, h, w, k, stride, int(ceil_mode),
                                  0 if mode == "max" else 1, int(relu_mask_by_x), _stream()), "maua_pool2d_bwd")
+    return out
+
+
+def pool2x2_codes_supported(n, c, h, w):
+    return bool(lib().maua_pool2x2_codes_supported(int(n), int(c), int(h), int(w)))
+
+
+def pool2x2_fwd_codes(x, out, codes):
+    """2x2/2 max pooling that also records each window's decision (one byte) for pool2x2_bwd_codes."""
+    n, c, h, w = x.shape
+    _check(lib().maua_pool2x2_fwd_codes(_ptr(_f32(x, "x")), _ptr(out), codes.data_ptr(), n, c, h, w, _stream()),
+           "maua_pool2x2_fwd_codes")
+    return out
+
+
+def pool2x2_bwd_codes(gy, codes, out, relu_mask):
+    n, c, h, w = out.shape
+    _check(lib().maua_pool2x2_bwd_codes(_ptr(_f32(gy, "gy")), codes.data_ptr(), _ptr(out), n, c, h, w, int(relu_mask), _stream()),
+           "maua_pool2x2_bwd_codes")
     return out
 
 

@@ -922,3 +922,26 @@ def test_deprocess_u8_is_bit_exact(hip):
     import numpy as np
     assert np.array_equal(np.asarray(load.deprocess(x.clone())), want.numpy())
     assert np.array_equal(np.asarray(load.deprocess(dev(x))), want.numpy())  # device tensors take the kernel
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 128, 256), (2, 7, 34, 66), (1, 512, 16, 16)])
+def test_pool2x2_with_kept_decisions_equals_the_recomputing_pair(hip, shape):
+    """maua_pool2x2_fwd_codes / _bwd_codes against maua_pool2d_fwd / _bwd (which recompute the arg-max from the input): the
+    same bits, ties, zeros (ReLU inputs) and NaNs included."""
+    n, c, h, w = shape
+    x = torch.relu(rnd(*shape, seed=51))
+    x[..., 0:2, 0:2] = 0.5           # a four-way tie
+    x[..., 2:4, 2:4] = 0.0           # an all-zero window
+    x[0, 0, 4, 5] = float("nan")
+    gy = rnd(n, c, h // 2, w // 2, seed=52)
+    xd, gyd = dev(x), dev(gy)
+    y0 = hip.pool2d_fwd(xd, 2, 2, False, "max")
+    codes = torch.empty(n, c, h // 2, w // 2, dtype=torch.uint8, device="cuda")
+    y1 = hip.pool2x2_fwd_codes(xd, torch.empty_like(y0), codes)
+    for mask in (False, True):
+        g0 = hip.pool2d_bwd(gyd, xd, 2, 2, False, "max", relu_mask_by_x=mask)
+        g1 = hip.pool2x2_bwd_codes(gyd, codes, torch.empty_like(xd), mask)
+        torch.cuda.synchronize()
+        assert torch.equal(torch.nan_to_num(g0, nan=7.0), torch.nan_to_num(g1, nan=7.0))
+    assert torch.equal(torch.nan_to_num(y0, nan=7.0), torch.nan_to_num(y1, nan=7.0))
+    assert int(codes.max()) <= 7

@@ -70,6 +70,8 @@ def main():
             L.maua_conv_kxk_x3(ptr, ptr, 1.0, ptr, None, ptr, n, cin, h, w, cout, k, pad, 1, 0, ptr, ws_bytes, None),
             L.maua_conv1x1_x3(ptr, None, ptr, ptr, None, ptr, n, cin, h * w if abs(h * w) < 1 << 40 else 1, cout, 1, 0, ptr, ws_bytes, None),
             L.maua_pool2d_fwd(ptr, ptr, n, cin, h, w, rng.choice([2, 3]), 2, rng.randint(0, 1), rng.randint(0, 1), None),
+            L.maua_pool2x2_fwd_codes(ptr, ptr, ptr, n, cin, h, w, None),
+            L.maua_pool2x2_bwd_codes(ptr, ptr, ptr, n, cin, h, w, rng.randint(0, 1), None),
             L.maua_gram_fwd(ptr, ptr, None, cin, h * w if abs(h * w) < 1 << 40 else 1, 1.0, 0, ptr, ws_bytes, None),
             L.maua_gram_bwd(ptr, ptr, None, None, ptr, cin, h * w if abs(h * w) < 1 << 40 else 1, 0, ptr, ws_bytes, None),
             L.maua_mse_fwd_bwd(ptr, ptr, ptr, h * w, 1.0, 1.0, 0, 0, ptr, ptr, ws_bytes, None),
