@@ -66,7 +66,7 @@ def _x3w_min_pixels():
     return _X3W_MIN_PIXELS
 
 
-def conv3x3_mfma(x, mod, backward, out=None, out_relu_mask=None, relu=False, workspace=None):
+def conv3x3_mfma(x, mod, backward, out=None, out_relu_mask=None, relu=False, accumulate=False, workspace=None):
     """The fp32-accurate reduced-width matrix-core convolution of a 3x3 stride-1 layer (forward, or backward-data when
     `backward`): fp16x3 or bf16x6 according to MAUA_CONV_X3."""
     pad = mod.padding[0]
@@ -79,16 +79,16 @@ def conv3x3_mfma(x, mod, backward, out=None, out_relu_mask=None, relu=False, wor
             hip.conv_x3w_supported(consumed, x.shape[2], x.shape[3], p):
         bf, bb, wsc = mod.banks3w()
         return hip.conv3x3_x3w(x, bb if backward else bf, wsc, bias, cout, p, relu, out=out, out_relu_mask=out_relu_mask,
-                               workspace=workspace)
+                               accumulate=accumulate, workspace=workspace)
     if _x3_enabled() and consumed > 4:
         # (the image layer, 3 input channels, stays on the exact bf16x6 products: it differences neighbouring pixels of large
         # common magnitude - the one place where the 2 bits fp16x3 drops could show - and costs one partly empty chunk)
         bf, bb, wsc = mod.banks3()
         return hip.conv3x3_x3(x, bb if backward else bf, wsc, bias, cout, p, relu, out=out, out_relu_mask=out_relu_mask,
-                              workspace=workspace)
+                              accumulate=accumulate, workspace=workspace)
     bf, bb = mod.banks6()
     return hip.conv3x3_x6(x, bb if backward else bf, bias, cout, p, relu, out=out, out_relu_mask=out_relu_mask,
-                          workspace=workspace)
+                          accumulate=accumulate, workspace=workspace)
 
 
 def conv1x1_is_mfma(mod, backward):
