@@ -200,6 +200,28 @@ int maua_gram_bwd(const float* d_sym, const float* f, const float* row_mean, con
 int maua_tv_fwd_bwd(const float* x, float* grad, int n, int c, int h, int w, float strength, int accumulate,
                     float* loss_out, void* workspace, size_t workspace_bytes, maua_stream_t stream);
 
+/* ---- deferred loss finishing ------------------------------------------------------------------------
+ * The reference adds up its modules' losses after the forward pass (`total_loss += mod.loss`, optim.py:207-211).  The entry
+ * points above finish each loss with a launch of its own; these variants leave their per-workgroup partial sums in a "ledger"
+ * (caller-allocated, maua_loss_ledger_bytes(frames, slots), zero-filled once: `frames` x `slots` records) and ONE launch of
+ * maua_loss_ledger_sum per evaluation turns every filled record into its loss value - the partial sums added in the same fixed
+ * order as the immediate entry points, so the values are bit-identical - marks the records empty again and writes, per frame,
+ * totals[f] = sum of losses[f][0..slots), left to right.  Slots whose record is empty keep the value an immediate entry point
+ * wrote there.  `ledger` arguments of the *_ledger functions point at a frame's first record, `slot` selects the record.
+ * maua_gram_fwd_mse_ledger = maua_gram_fwd followed by maua_mse_fwd_bwd of the Gram matrix against `target` (StyleLoss,
+ * loss.py:141-157): gram, dmat = grad_scale (G - target) and the loss partials from one finishing launch; it needs
+ * maua_gram_mse_ledger_supported(c) (c <= 1408 channels). */
+size_t maua_loss_ledger_bytes(int frames, int slots);
+int maua_mse_fwd_bwd_ledger(const float* x, const float* target, float* grad, int64_t count, float loss_scale, float grad_scale,
+                            int accumulate, int mask_grad_by_x, double* ledger, int slot, maua_stream_t stream);
+int maua_tv_fwd_bwd_ledger(const float* x, float* grad, int n, int c, int h, int w, float strength, int accumulate,
+                           double* ledger, int slot, maua_stream_t stream);
+int maua_gram_mse_ledger_supported(int c);
+int maua_gram_fwd_mse_ledger(const float* f, float* gram, float* row_mean_out, int c, int64_t hw, float scale, int center,
+                             const float* target, float* dmat, float loss_scale, float grad_scale, double* ledger, int slot,
+                             void* workspace, size_t workspace_bytes, maua_stream_t stream);
+int maua_loss_ledger_sum(double* ledger, int frames, int slots, float* losses, float* totals, maua_stream_t stream);
+
 /* ---- small vector helpers used by the host engine -------------------------------------------------- */
 int maua_fill(float* x, int64_t count, float value, maua_stream_t stream);
 int maua_axpy(float* y, const float* x, float alpha, int64_t count, maua_stream_t stream); /* y += alpha x */

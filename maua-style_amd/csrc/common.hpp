@@ -81,6 +81,11 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
     return r;
 }
 
+// Loss ledger: one record of LEDGER_STRIDE doubles per loss slot - {number of partial sums, scale, partial sums ...} - filled by
+// the *_ledger entry points and summed (in finish_sum_kernel's order) by maua_loss_ledger_sum at the end of an evaluation.
+constexpr int LEDGER_MAX = 4096;
+constexpr int LEDGER_STRIDE = LEDGER_MAX + 2;
+
 // Fixed-order second stage: one workgroup sums `n` per-block partials (doubles) in index order.
 __global__ void finish_sum_kernel(const double* __restrict__ partial, int n, float scale, float* __restrict__ out);
 

@@ -401,6 +401,52 @@ gram_finish_kernel(const float* __restrict__ partial, float* __restrict__ gram, 
     }
 }
 
+// gram_finish_kernel and the MSE against the style target in one launch (loss.py:150-157 on top of GramMatrix.forward): G as
+// above, D = grad_scale (G - T) (mirrored like G), and the workgroup's share of sum (G - T)^2 - off-diagonal tiles count twice -
+// as one partial sum of the slot's ledger record.
+__global__ void __launch_bounds__(256)
+gram_finish_mse_kernel(const float* __restrict__ partial, float* __restrict__ gram, int C, int ksplit, int kstride, float scale,
+                       const float* __restrict__ target, float* __restrict__ dmat, float grad_scale, float loss_scale,
+                       double* __restrict__ rec) {
+    __shared__ double scratch[16];
+    int pair = blockIdx.x, ti = 0;
+    const int ntile = (C + GT - 1) / GT;
+    while (pair >= ntile - ti) {
+        pair -= ntile - ti;
+        ++ti;
+    }
+    const int tj = ti + pair;
+    const float* base = partial + (int64_t)blockIdx.x * ksplit * (GT * GT);
+    const int e = blockIdx.y * 256 + threadIdx.x;
+    const int er = e / GT, ec = e % GT;
+    const int src = (ti == tj && er > ec) ? ec * GT + er : e;
+    double sd = 0.0;
+    for (int k = 0; k < ksplit; k += kstride) sd += (double)base[(int64_t)k * (GT * GT) + src];
+    const float s = (float)(sd * (double)scale);
+    const int gi = ti * GT + er, gj = tj * GT + ec;
+    double sq = 0.0;
+    if (gi < C && gj < C) {
+        const float d = s - target[(int64_t)gi * C + gj];
+        gram[(int64_t)gi * C + gj] = s;
+        dmat[(int64_t)gi * C + gj] = grad_scale * d;
+        sq = (double)d * (double)d;
+        if (ti != tj) {
+            const float dt = s - target[(int64_t)gj * C + gi];
+            gram[(int64_t)gj * C + gi] = s;
+            dmat[(int64_t)gj * C + gi] = grad_scale * dt;
+            sq += (double)dt * (double)dt;
+        }
+    }
+    sq = block_sum(sq, scratch);
+    if (threadIdx.x == 0) {
+        rec[2 + blockIdx.x * gridDim.y + blockIdx.y] = sq;
+        if (blockIdx.x == 0 && blockIdx.y == 0) {
+            rec[0] = (double)(gridDim.x * gridDim.y);
+            rec[1] = (double)loss_scale;
+        }
+    }
+}
+
 // bias[c] = - sum_k D[k][c] * mean[k]   (the centering term of gf = D (F - mean 1^T)).  D is symmetric, so row c is
 // read instead of column c: one wave per output, coalesced loads, fixed-order wave reduction.
 __global__ void __launch_bounds__(256) center_bias_kernel(const float* __restrict__ d, const float* __restrict__ mean,
@@ -559,8 +605,15 @@ size_t maua_gram_workspace_bytes(int c, int64_t hw) {
     return need > bwd_split ? need : bwd_split;
 }
 
-int maua_gram_fwd(const float* f, float* gram, float* row_mean_out, int c, int64_t hw, float scale, int center,
-                  void* workspace, size_t workspace_bytes, maua_stream_t stream) {
+struct GramMse {  // the fused tail of maua_gram_fwd_mse_ledger (null target: plain maua_gram_fwd)
+    const float* target;
+    float* dmat;
+    float loss_scale, grad_scale;
+    double* rec;
+};
+
+static int gram_fwd_impl(const float* f, float* gram, float* row_mean_out, int c, int64_t hw, float scale, int center,
+                         void* workspace, size_t workspace_bytes, maua_stream_t stream, const GramMse& mse) {
     MAUA_REQUIRE(f && gram && workspace && c > 0 && hw > 0 && c <= (1 << 16) && hw < (1ll << 30), MAUA_E_INVAL, "gram_fwd: bad args");
     MAUA_REQUIRE(!center || row_mean_out, MAUA_E_INVAL, "gram_fwd: center needs row_mean_out");
     MAUA_REQUIRE(workspace_bytes >= maua_gram_workspace_bytes(c, hw), MAUA_E_WORKSPACE, "gram_fwd: workspace %zu < %zu",
@@ -608,9 +661,35 @@ int maua_gram_fwd(const float* f, float* gram, float* row_mean_out, int c, int64
         if (rc) return rc;
         kstride = GF_FOLD;
     }
+    if (mse.target) {
+        hipLaunchKernelGGL(gram_finish_mse_kernel, dim3(npairs, GT * GT / 256), dim3(256), 0, s, (const float*)workspace, gram, c,
+                           ksplit, kstride, scale, mse.target, mse.dmat, mse.grad_scale, mse.loss_scale, mse.rec);
+        return check_launch("gram_finish_mse_kernel");
+    }
     hipLaunchKernelGGL(gram_finish_kernel, dim3(npairs, GT * GT / 256), dim3(256), 0, s, (const float*)workspace, gram, c, ksplit,
                        kstride, scale);
     return check_launch("gram_finish_kernel");
+}
+
+int maua_gram_fwd(const float* f, float* gram, float* row_mean_out, int c, int64_t hw, float scale, int center,
+                  void* workspace, size_t workspace_bytes, maua_stream_t stream) {
+    return gram_fwd_impl(f, gram, row_mean_out, c, hw, scale, center, workspace, workspace_bytes, stream, GramMse{});
+}
+
+int maua_gram_mse_ledger_supported(int c) {
+    if (c <= 0 || c > (1 << 16)) return 0;
+    const int64_t nt = (c + GT - 1) / GT;
+    return nt * (nt + 1) / 2 * (GT * GT / 256) <= LEDGER_MAX ? 1 : 0;
+}
+
+int maua_gram_fwd_mse_ledger(const float* f, float* gram, float* row_mean_out, int c, int64_t hw, float scale, int center,
+                             const float* target, float* dmat, float loss_scale, float grad_scale, double* ledger, int slot,
+                             void* workspace, size_t workspace_bytes, maua_stream_t stream) {
+    MAUA_REQUIRE(target && dmat && ledger && slot >= 0 && slot < (1 << 28), MAUA_E_INVAL, "gram_fwd_mse_ledger: bad args");
+    MAUA_REQUIRE(maua_gram_mse_ledger_supported(c), MAUA_E_UNSUPPORTED, "gram_fwd_mse_ledger: %d channels need more than %d partial sums",
+                 c, LEDGER_MAX);
+    GramMse m{target, dmat, loss_scale, grad_scale, ledger + (int64_t)slot * LEDGER_STRIDE};
+    return gram_fwd_impl(f, gram, row_mean_out, c, hw, scale, center, workspace, workspace_bytes, stream, m);
 }
 
 int maua_gram_bwd(const float* d_sym, const float* f, const float* row_mean, const float* relu_mask, float* gf, int c,

@@ -24,6 +24,32 @@ __global__ void finish_sum_kernel(const double* __restrict__ partial, int n, flo
     if (threadIdx.x == 0) out[0] = (float)(v * (double)scale);
 }
 
+// One workgroup per frame: every slot with a filled ledger record gets its loss (the record's partial sums added in
+// finish_sum_kernel's order, times the record's scale) and the record is marked empty again; slots without a record keep the
+// value an immediate-mode entry point left there.  Then total = sum of the slots, left to right (`total_loss += mod.loss`).
+__global__ void __launch_bounds__(256)
+loss_ledger_sum_kernel(double* __restrict__ ledger, int slots, float* __restrict__ losses, float* __restrict__ total) {
+    __shared__ double scratch[16];
+    double* led = ledger + (int64_t)blockIdx.x * slots * LEDGER_STRIDE;
+    float* out = losses + (int64_t)blockIdx.x * slots;
+    float tot = 0.f;
+    for (int s = 0; s < slots; ++s) {
+        double* rec = led + (int64_t)s * LEDGER_STRIDE;
+        const int n = (int)rec[0];
+        if (n > 0) {
+            double v = 0.0;
+            for (int i = threadIdx.x; i < n; i += blockDim.x) v += rec[2 + i];
+            v = block_sum(v, scratch);  // (two barriers: every thread has read rec[0] before thread 0 clears it)
+            if (threadIdx.x == 0) {
+                out[s] = (float)(v * rec[1]);
+                rec[0] = 0.0;
+            }
+        }
+        if (threadIdx.x == 0) tot += out[s];
+    }
+    if (threadIdx.x == 0) total[blockIdx.x] = tot;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 __global__ void pack_filters_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wb, int cout,
                                     int cin, int kh, int kw) {
@@ -279,8 +305,12 @@ pool2x2_bwd_codes_kernel(const float* __restrict__ gy, const unsigned char* __re
 // MSE: partial[b] = sum over the block's elements of (x-t)^2 (double); grad (+)= gs * (x - t).
 __global__ void __launch_bounds__(256)
 mse_kernel(const float* __restrict__ x, const float* __restrict__ t, float* __restrict__ grad, int64_t n, float gs,
-           int accumulate, int mask_by_x, double* __restrict__ partial) {
+           int accumulate, int mask_by_x, double* __restrict__ partial, double* __restrict__ rec, float rec_scale) {
     __shared__ double scratch[16];
+    if (rec && blockIdx.x == 0 && threadIdx.x == 0) {  // ledger record header: number of partial sums, scale
+        rec[0] = (double)gridDim.x;
+        rec[1] = (double)rec_scale;
+    }
     double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float d = x[i] - t[i];
@@ -318,8 +348,12 @@ mse_weighted_kernel(const float* __restrict__ x, const float* __restrict__ w, co
 // TV: loss = strength * (sum |x[y+1]-x[y]| + sum |x[x+1]-x[x]|); d/dx via sign() of the four neighbours' differences.
 __global__ void __launch_bounds__(256)
 tv_kernel(const float* __restrict__ x, float* __restrict__ grad, int64_t planes, int H, int W, float strength,
-          int accumulate, double* __restrict__ partial) {
+          int accumulate, double* __restrict__ partial, double* __restrict__ rec) {
     __shared__ double scratch[16];
+    if (rec && blockIdx.x == 0 && threadIdx.x == 0) {
+        rec[0] = (double)gridDim.x;
+        rec[1] = (double)strength;
+    }
     const int64_t total = planes * H * W;
     double acc = 0.0;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -477,7 +511,7 @@ int maua_mse_fwd_bwd(const float* x, const float* target, float* grad, int64_t c
     MAUA_REQUIRE(workspace_bytes >= nb * sizeof(double), MAUA_E_WORKSPACE, "mse_fwd_bwd: workspace %zu < %zu",
                  workspace_bytes, nb * sizeof(double));
     hipLaunchKernelGGL(mse_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, target, grad, count, grad_scale,
-                       accumulate, mask_grad_by_x, (double*)workspace);
+                       accumulate, mask_grad_by_x, (double*)workspace, (double*)nullptr, 0.f);
     int rc = check_launch("mse_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, nb,
@@ -511,12 +545,45 @@ int maua_tv_fwd_bwd(const float* x, float* grad, int n, int c, int h, int w, flo
     const int nb = reduce_blocks(count, 1024);
     MAUA_REQUIRE(workspace_bytes >= nb * sizeof(double), MAUA_E_WORKSPACE, "tv_fwd_bwd: workspace too small");
     hipLaunchKernelGGL(tv_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, grad, (int64_t)n * c, h, w, strength,
-                       accumulate, (double*)workspace);
+                       accumulate, (double*)workspace, (double*)nullptr);
     int rc = check_launch("tv_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, nb, strength,
                        loss_out);
     return check_launch("finish_sum_kernel");
+}
+
+size_t maua_loss_ledger_bytes(int frames, int slots) {
+    if (frames <= 0 || slots <= 0 || frames > (1 << 16) || slots > (1 << 12)) return 0;
+    return (size_t)frames * slots * LEDGER_STRIDE * sizeof(double);
+}
+
+int maua_mse_fwd_bwd_ledger(const float* x, const float* target, float* grad, int64_t count, float loss_scale, float grad_scale,
+                            int accumulate, int mask_grad_by_x, double* ledger, int slot, maua_stream_t stream) {
+    MAUA_REQUIRE(x && target && ledger && slot >= 0 && slot < (1 << 28) && count > 0, MAUA_E_INVAL, "mse_fwd_bwd_ledger: bad args");
+    const int nb = reduce_blocks(count, 1024);
+    double* rec = ledger + (int64_t)slot * LEDGER_STRIDE;
+    hipLaunchKernelGGL(mse_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, target, grad, count, grad_scale, accumulate,
+                       mask_grad_by_x, rec + 2, rec, loss_scale);
+    return check_launch("mse_kernel");
+}
+
+int maua_tv_fwd_bwd_ledger(const float* x, float* grad, int n, int c, int h, int w, float strength, int accumulate,
+                           double* ledger, int slot, maua_stream_t stream) {
+    MAUA_REQUIRE(x && ledger && slot >= 0 && slot < (1 << 28) && conv_dims_ok(n, c, h, w, 1, 0), MAUA_E_INVAL, "tv_fwd_bwd_ledger: bad args");
+    const int64_t count = (int64_t)n * c * h * w;
+    const int nb = reduce_blocks(count, 1024);
+    double* rec = ledger + (int64_t)slot * LEDGER_STRIDE;
+    hipLaunchKernelGGL(tv_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, grad, (int64_t)n * c, h, w, strength, accumulate,
+                       rec + 2, rec);
+    return check_launch("tv_kernel");
+}
+
+int maua_loss_ledger_sum(double* ledger, int frames, int slots, float* losses, float* totals, maua_stream_t stream) {
+    MAUA_REQUIRE(ledger && losses && totals && frames > 0 && frames <= (1 << 16) && slots > 0 && slots <= (1 << 12), MAUA_E_INVAL,
+                 "loss_ledger_sum: bad args");
+    hipLaunchKernelGGL(loss_ledger_sum_kernel, dim3(frames), dim3(256), 0, (hipStream_t)stream, ledger, slots, losses, totals);
+    return check_launch("loss_ledger_sum_kernel");
 }
 
 int maua_fill(float* x, int64_t count, float value, maua_stream_t stream) {

@@ -159,6 +159,11 @@ class StyleEngine:
             self.slots_all = torch.zeros(n_slots, device=dev)
             self.slots = self.slots_all[:max(len(self.losses), 1)]
             self.total = torch.zeros(1, device=dev)
+        # Single images and independent frames: the losses leave their partial sums in a ledger (one record per frame and slot)
+        # and ONE launch at the end of the evaluation forms every loss value and the totals (hip.loss_ledger_sum)
+        self.ledger = None
+        if (B == 1 or self.independent) and os.environ.get("MAUA_LOSS_LEDGER", "1") != "0":
+            self.ledger = hip.loss_ledger(B, n_slots, dev)
         self.gram, self.dmat, self.mean = {}, {}, {}
         self.gram_d, self.dmat_d, self.mean_d = {}, {}, {}
         ws = hip.reduce_workspace_bytes(max(t.numel() for t in self.gbuf.values()))
@@ -366,6 +371,11 @@ class StyleEngine:
                     mean_b = self.mean[id(s)][b] if s.mod.use_covariance else None
                     ctx, wsb = self.frame_stream(b)
                     with ctx:
+                        if self.ledger is not None and hip.gram_mse_ledger_supported(c):
+                            self._timed("gram_fwd", 2 * c * c * (n // c), n * 4 + c * c * 4, lambda: hip.gram_fwd_mse_ledger(
+                                f[b:b + 1], 1.0 / n, s.mod.use_covariance, self.gram[id(s)][b], mean_b, s.mod.target,
+                                self.dmat[id(s)][b], lw / (c * c), gw * 4.0 / (c * c) / n, self.ledger[b], s.slot, workspace=wsb))
+                            continue
                         self._timed("gram_fwd", 2 * c * c * (n // c), n * 4 + c * c * 4, lambda: hip.gram_fwd(
                             f[b:b + 1], 1.0 / n, s.mod.use_covariance, out=self.gram[id(s)][b], mean_out=mean_b, workspace=wsb))
                         hip.mse_fwd_bwd(self.gram[id(s)][b], s.mod.target, self.dmat[id(s)][b], lw / (c * c),
@@ -405,9 +415,14 @@ class StyleEngine:
                 f = a[s.src]
                 c, n = f.shape[1], f[0].nelement()
                 lw, gw = self._coefficients(s)
+                # loss = lw * mean((G-T)^2); D = gw * (2/C^2) * (2/n) * (G - T)   (dG/dF = (D + D^T) F / n, D symmetric)
+                if self.ledger is not None and hip.gram_mse_ledger_supported(c):
+                    self._timed("gram_fwd", 2 * c * c * (n // c), n * 4 + c * c * 4, lambda: hip.gram_fwd_mse_ledger(
+                        f, 1.0 / n, s.mod.use_covariance, self.gram[id(s)], self.mean[id(s)], s.mod.target, self.dmat[id(s)],
+                        lw / (c * c), gw * 4.0 / (c * c) / n, self.ledger[0], s.slot, workspace=self.ws))
+                    continue
                 self._timed("gram_fwd", 2 * c * c * (n // c), n * 4 + c * c * 4, lambda: hip.gram_fwd(
                     f, 1.0 / n, s.mod.use_covariance, out=self.gram[id(s)], mean_out=self.mean[id(s)], workspace=self.ws))
-                # loss = lw * mean((G-T)^2); D = gw * (2/C^2) * (2/n) * (G - T)   (dG/dF = (D + D^T) F / n, D symmetric)
                 hip.mse_fwd_bwd(self.gram[id(s)], s.mod.target, self.dmat[id(s)], lw / (c * c), gw * 4.0 / (c * c) / n,
                                 False, self.slots[s.slot:s.slot + 1], workspace=self.ws)
         # ---------------- backward
@@ -447,8 +462,14 @@ class StyleEngine:
                         elif s.kind == "content":
                             lw, gw = self._coefficients(s)
                             n = f[0].nelement()
-                            hip.mse_fwd_bwd(f[b], s.mod.target[b], g[s.src][b], lw / n, gw * 2.0 / n, acc, slot, workspace=wsb,
-                                            mask_grad_by_x=premask(s))
+                            if self.ledger is not None:
+                                hip.mse_fwd_bwd_ledger(f[b], s.mod.target[b], g[s.src][b], lw / n, gw * 2.0 / n, acc, self.ledger[b],
+                                                       s.slot, mask_grad_by_x=premask(s))
+                            else:
+                                hip.mse_fwd_bwd(f[b], s.mod.target[b], g[s.src][b], lw / n, gw * 2.0 / n, acc, slot, workspace=wsb,
+                                                mask_grad_by_x=premask(s))
+                        elif self.ledger is not None:
+                            hip.tv_fwd_bwd_ledger(f[b:b + 1], g[0][b:b + 1], s.mod.strength, acc, self.ledger[b], s.slot)
                         else:
                             hip.tv_fwd_bwd(f[b:b + 1], g[0][b:b + 1], s.mod.strength, acc, slot, workspace=wsb)
                 self.join()
@@ -501,12 +522,18 @@ class StyleEngine:
                     if s.mod.weights is not None:  # temporal loss on the pixels: MSE(x * w, target), loss.py:52-56
                         hip.mse_weighted_fwd_bwd(a[s.src], s.mod.weights, s.mod.target, g[s.src], lw / n, gw * 2.0 / n,
                                                  cur == s.src, self.slots[s.slot:s.slot + 1], workspace=self.ws)
+                    elif self.ledger is not None:
+                        hip.mse_fwd_bwd_ledger(a[s.src], s.mod.target, g[s.src], lw / n, gw * 2.0 / n, cur == s.src, self.ledger[0],
+                                               s.slot, mask_grad_by_x=premask(s))
                     else:
                         hip.mse_fwd_bwd(a[s.src], s.mod.target, g[s.src], lw / n, gw * 2.0 / n, cur == s.src,
                                         self.slots[s.slot:s.slot + 1], workspace=self.ws, mask_grad_by_x=premask(s))
                     cur = s.src
             elif s.kind == "tv":
-                hip.tv_fwd_bwd(a[0], g[0], s.mod.strength, cur == 0, self.slots[s.slot:s.slot + 1], workspace=self.ws)
+                if self.ledger is not None:
+                    hip.tv_fwd_bwd_ledger(a[0], g[0], s.mod.strength, cur == 0, self.ledger[0], s.slot)
+                else:
+                    hip.tv_fwd_bwd(a[0], g[0], s.mod.strength, cur == 0, self.slots[s.slot:s.slot + 1], workspace=self.ws)
                 cur = 0
             elif cur is None:
                 continue  # nothing flows through layers behind the last loss
@@ -541,6 +568,9 @@ class StyleEngine:
                 cur = s.src
         if cur != 0:
             hip.fill_(g[0], 0.0)
+        if self.ledger is not None:  # (B == 1 or independent frames: no per-module terms to fold afterwards)
+            hip.loss_ledger_sum(self.ledger, self.slots_all, self.total)
+            return
         if indep:
             for b in range(x.shape[0]):
                 hip.sum_small(self.slots_all[b], self.total[b:b + 1])

@@ -73,6 +73,12 @@ SIGNATURES = {
     "maua_deprocess_u8": (c_i, [c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_p]),
     "maua_set_split_batch_hint": (None, [c_i]),
     "maua_get_split_batch_hint": (c_i, []),
+    "maua_loss_ledger_bytes": (c_sz, [c_i, c_i]),
+    "maua_mse_fwd_bwd_ledger": (c_i, [c_p, c_p, c_p, c_i64, c_f, c_f, c_i, c_i, c_p, c_i, c_p]),
+    "maua_tv_fwd_bwd_ledger": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_i, c_p]),
+    "maua_gram_mse_ledger_supported": (c_i, [c_i]),
+    "maua_gram_fwd_mse_ledger": (c_i, [c_p, c_p, c_p, c_i, c_i64, c_f, c_i, c_p, c_p, c_f, c_f, c_p, c_i, c_p, c_sz, c_p]),
+    "maua_loss_ledger_sum": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p]),
     "maua_lbfgs_state_bytes": (c_sz, [c_i64, c_i]),
     "maua_lbfgs_init": (c_i, [c_p, c_sz, c_i64, c_i, c_p]),
     "maua_lbfgs_iterate": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_f, c_f, c_f, c_p]),
@@ -427,6 +433,47 @@ def gram_fwd(f, scale, center=False, out=None, mean_out=None, workspace=None):
                                int(center), workspace.data_ptr(), workspace.numel() * workspace.element_size(),
                                _stream()), "maua_gram_fwd")
     return out, (mean_out if center else None)
+
+
+def loss_ledger(frames, slots, device):
+    """Zero-filled ledger of frames x slots records for the *_ledger entry points (float64 tensor, frames x slots x stride)."""
+    n = lib().maua_loss_ledger_bytes(int(frames), int(slots)) // 8
+    return torch.zeros(frames, slots, n // (frames * slots), dtype=torch.float64, device=device)
+
+
+def gram_mse_ledger_supported(c):
+    return bool(lib().maua_gram_mse_ledger_supported(int(c)))
+
+
+def gram_fwd_mse_ledger(f, scale, center, out, mean_out, target, dmat, loss_scale, grad_scale, ledger, slot, workspace=None):
+    """gram_fwd + mse_fwd_bwd(gram, target -> dmat) with the loss left in record `slot` of `ledger` (one frame's records)."""
+    c = f.shape[1] if f.dim() == 4 else f.shape[0]
+    hw = f.numel() // c
+    workspace = _ws(workspace, gram_workspace_bytes(c, hw), f.device)
+    _check(lib().maua_gram_fwd_mse_ledger(_ptr(_f32(f, "f")), _ptr(out), _ptr(mean_out) if center else None, c, hw, float(scale),
+                                          int(center), _ptr(_f32(target, "target")), _ptr(dmat), float(loss_scale),
+                                          float(grad_scale), ledger.data_ptr(), int(slot), workspace.data_ptr(),
+                                          workspace.numel() * workspace.element_size(), _stream()), "maua_gram_fwd_mse_ledger")
+    return out
+
+
+def mse_fwd_bwd_ledger(x, target, grad, loss_scale, grad_scale, accumulate, ledger, slot, mask_grad_by_x=False):
+    _check(lib().maua_mse_fwd_bwd_ledger(_ptr(_f32(x, "x")), _ptr(_f32(target, "target")), _ptr(grad), x.numel(), float(loss_scale),
+                                         float(grad_scale), int(accumulate), int(mask_grad_by_x), ledger.data_ptr(), int(slot),
+                                         _stream()), "maua_mse_fwd_bwd_ledger")
+
+
+def tv_fwd_bwd_ledger(x, grad, strength, accumulate, ledger, slot):
+    n, c, h, w = x.shape
+    _check(lib().maua_tv_fwd_bwd_ledger(_ptr(_f32(x, "x")), _ptr(grad), n, c, h, w, float(strength), int(accumulate),
+                                        ledger.data_ptr(), int(slot), _stream()), "maua_tv_fwd_bwd_ledger")
+
+
+def loss_ledger_sum(ledger, losses, totals):
+    """losses: (frames, slots) or (slots,) float32; totals: (frames,) float32."""
+    frames, slots = ledger.shape[0], ledger.shape[1]
+    _check(lib().maua_loss_ledger_sum(ledger.data_ptr(), frames, slots, _ptr(losses), _ptr(totals), _stream()),
+           "maua_loss_ledger_sum")
 
 
 def gram_bwd(d_sym, f, row_mean, gf, accumulate, workspace=None, relu_mask=None):

@@ -945,3 +945,55 @@ def test_pool2x2_with_kept_decisions_equals_the_recomputing_pair(hip, shape):
         assert torch.equal(torch.nan_to_num(g0, nan=7.0), torch.nan_to_num(g1, nan=7.0))
     assert torch.equal(torch.nan_to_num(y0, nan=7.0), torch.nan_to_num(y1, nan=7.0))
     assert int(codes.max()) <= 7
+
+
+@pytest.mark.parametrize("C,HW,center", [(64, 4096, False), (96, 1000, True), (512, 256, False), (1024, 100, False)])
+def test_loss_ledger_equals_the_immediate_entry_points(hip, C, HW, center):
+    """Deferred loss finishing (maua_*_ledger + maua_loss_ledger_sum) against the entry points that finish every loss with a
+    launch of their own: Gram matrix, gradient matrices and pixel gradients bit-identical; MSE / TV losses bit-identical; the
+    fused Gram + MSE loss to fp32 rounding (its partial sums are cut along tiles, not along rows); empty records leave
+    the slot alone; the total is the left-to-right sum."""
+    f = torch.relu(rnd(1, C, HW, 1, seed=61))
+    tgt_g = rnd(C, C, seed=62) * 0.01
+    tgt_g = dev((tgt_g + tgt_g.t()).contiguous())
+    x, t = rnd(1, 8, 33, 47, seed=63), rnd(1, 8, 33, 47, seed=64)
+    fd, xd, td = dev(f), dev(x), dev(t)
+    n = f.numel()
+    # immediate
+    g0, m0 = hip.gram_fwd(fd, 1.0 / n, center)
+    d0, l0 = torch.empty_like(g0), torch.zeros(4, device="cuda")
+    hip.mse_fwd_bwd(g0, tgt_g, d0, 3.0 / (C * C), 0.7, False, l0[1:2])
+    gm0 = torch.zeros_like(xd)
+    hip.mse_fwd_bwd(xd, td, gm0, 0.25, 1.5, False, l0[2:3], mask_grad_by_x=True)
+    gt0 = torch.zeros_like(xd)
+    hip.tv_fwd_bwd(xd, gt0, 1e-3, False, l0[3:4])
+    # ledger: slot 0 stays empty and keeps the value found there
+    led = hip.loss_ledger(1, 4, "cuda")
+    l1 = torch.zeros(1, 4, device="cuda")
+    l1[0, 0] = 42.0
+    g1, d1 = torch.empty_like(g0), torch.empty_like(g0)
+    m1 = torch.empty(C, device="cuda") if center else None
+    assert hip.gram_mse_ledger_supported(C)
+    hip.gram_fwd_mse_ledger(fd, 1.0 / n, center, g1, m1, tgt_g, d1, 3.0 / (C * C), 0.7, led[0], 1)
+    gm1, gt1 = torch.zeros_like(xd), torch.zeros_like(xd)
+    hip.mse_fwd_bwd_ledger(xd, td, gm1, 0.25, 1.5, False, led[0], 2, mask_grad_by_x=True)
+    hip.tv_fwd_bwd_ledger(xd, gt1, 1e-3, False, led[0], 3)
+    tot = torch.zeros(1, device="cuda")
+    hip.loss_ledger_sum(led, l1, tot)
+    torch.cuda.synchronize()
+    assert torch.equal(g0, g1) and torch.equal(d0, d1) and torch.equal(gm0, gm1) and torch.equal(gt0, gt1)
+    if center:
+        assert torch.equal(m0, m1)
+    assert float(l1[0, 0]) == 42.0
+    assert float(l1[0, 2]) == float(l0[2]) and float(l1[0, 3]) == float(l0[3])
+    assert abs(float(l1[0, 1]) - float(l0[1])) <= 2e-7 * abs(float(l0[1]))
+    want = torch.tensor(42.0) + l1[0, 1].cpu()
+    want = (want + l1[0, 2].cpu()) + l1[0, 3].cpu()
+    assert float(tot[0]) == float(want)
+    assert float(led[:, :, 0].abs().max()) == 0.0  # records are empty again
+    # a second evaluation through the same ledger gives the same values
+    hip.mse_fwd_bwd_ledger(xd, td, gm1, 0.25, 1.5, False, led[0], 2, mask_grad_by_x=True)
+    hip.loss_ledger_sum(led, l1, tot)
+    torch.cuda.synchronize()
+    assert float(l1[0, 2]) == float(l0[2])
+    assert hip.gram_mse_ledger_supported(1408) and not hip.gram_mse_ledger_supported(1409)

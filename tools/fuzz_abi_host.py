@@ -47,7 +47,7 @@ def main():
                  L.maua_conv_x6_bank_bytes(cout, cin), L.maua_conv_x3_bank_bytes(cout, cin), L.maua_conv_x3w_bank_bytes(cout, cin),
                  L.maua_conv_kxk_x3_bank_bytes(cout, cin, k), L.maua_gram_workspace_bytes(cin, h * w if abs(h * w) < 1 << 40 else 1),
                  L.maua_reduce_workspace_bytes(h * w), L.maua_lbfgs_state_bytes(h * w, rng.choice([1, 5, 100, 254, 255, 0, -1])),
-                 L.maua_channel_stats_workspace_bytes(h, w)]
+                 L.maua_channel_stats_workspace_bytes(h, w), L.maua_loss_ledger_bytes(n, cin)]
         assert all(s >= 0 for s in sizes)
         if min(n, cin, cout, h, w) <= 0:
             assert sizes[1] == 0 and sizes[2] == 0 and sizes[3] == 0, (n, cin, cout, h, w, sizes)
@@ -75,6 +75,12 @@ def main():
             L.maua_gram_fwd(ptr, ptr, None, cin, h * w if abs(h * w) < 1 << 40 else 1, 1.0, 0, ptr, ws_bytes, None),
             L.maua_gram_bwd(ptr, ptr, None, None, ptr, cin, h * w if abs(h * w) < 1 << 40 else 1, 0, ptr, ws_bytes, None),
             L.maua_mse_fwd_bwd(ptr, ptr, ptr, h * w, 1.0, 1.0, 0, 0, ptr, ptr, ws_bytes, None),
+            L.maua_mse_fwd_bwd_ledger(ptr, ptr, ptr, h * w, 1.0, 1.0, 0, 0, ptr, rng.choice([0, 3, -1]), None),
+            L.maua_tv_fwd_bwd_ledger(ptr, ptr, n, cin, h, w, 1.0, 0, ptr, rng.choice([0, 3, -1]), None),
+            L.maua_gram_fwd_mse_ledger(ptr, ptr, None, cin, h * w if abs(h * w) < 1 << 40 else 1, 1.0, 0, ptr, ptr, 1.0, 1.0, ptr,
+                                       rng.choice([0, 3, -1]), ptr, ws_bytes, None),
+            L.maua_loss_ledger_sum(ptr, n, cin, ptr, ptr, None),
+            L.maua_gram_mse_ledger_supported(cin),
             L.maua_tv_fwd_bwd(ptr, ptr, n, cin, h, w, 1.0, 0, ptr, ptr, ws_bytes, None),
             L.maua_resize_bilinear(ptr, ptr, n, h, w, cout, cin, 0.5, 0.5, None),
             L.maua_channel_stats(ptr, None, 1e-3, n, rng.randint(-1, 3), h, w, ptr, ptr, ws_bytes, None),
