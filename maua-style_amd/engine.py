@@ -17,6 +17,7 @@ Gradient weights follow the reference's ScaleGradients quirk (loss.py:10-20, SUR
 Activations and gradient buffers are allocated once per image size and reused by every iteration, so an
 iteration allocates nothing and can be captured into a hipGraph (`capture=True`).
 """
+import contextlib
 import os
 
 import torch
@@ -211,9 +212,14 @@ class StyleEngine:
         # nothing, and most of them are too small to fill the chip or are latency-bound chains - they run on a few side
         # streams so that the GPU overlaps them (fork after the kernel that produced their input, join before the next
         # kernel that reads their output).  Every stream has its own reduction / split-K workspace.
+        # A single image: the Gram / loss chain of a style layer only has to be done when the backward pass starts, so it
+        # runs on ONE side stream next to the following convolutions (large images; MAUA_STYLE_STREAM=0 / 1 forces it off / on).
         self.side, self.side_ws, self.ev_main, self.ev_side = [], [], None, []
-        if B > 1 and self.independent and int(os.environ.get("MAUA_SIDE_STREAMS", "4")) > 0:
-            ns = min(B, int(os.environ.get("MAUA_SIDE_STREAMS", "4")))
+        aside = os.environ.get("MAUA_STYLE_STREAM", "auto")  # measured: +1 % at 1024x1024, -3 % at 256x256 (graph edges cost there)
+        self.style_aside = B == 1 and self.ledger is not None and \
+            (aside == "1" or (aside == "auto" and x.shape[2] * x.shape[3] >= 768 * 768))
+        if (B > 1 and self.independent and int(os.environ.get("MAUA_SIDE_STREAMS", "4")) > 0) or self.style_aside:
+            ns = min(B, int(os.environ.get("MAUA_SIDE_STREAMS", "4"))) if B > 1 else 1
             small = hip.reduce_workspace_bytes(max(t.numel() for t in self.gbuf.values()) // B)
             for s in self.steps:
                 if s.kind == "style":
@@ -338,6 +344,7 @@ class StyleEngine:
         a, g = self.act, self.gbuf
         a[0] = x
         hip.fill_(self.slots_all, 0.0)
+        forked = False
         # ---------------- forward
         for s in self.steps:
             if s.kind == "conv":
@@ -417,9 +424,16 @@ class StyleEngine:
                 lw, gw = self._coefficients(s)
                 # loss = lw * mean((G-T)^2); D = gw * (2/C^2) * (2/n) * (G - T)   (dG/dF = (D + D^T) F / n, D symmetric)
                 if self.ledger is not None and hip.gram_mse_ledger_supported(c):
-                    self._timed("gram_fwd", 2 * c * c * (n // c), n * 4 + c * c * 4, lambda: hip.gram_fwd_mse_ledger(
-                        f, 1.0 / n, s.mod.use_covariance, self.gram[id(s)], self.mean[id(s)], s.mod.target, self.dmat[id(s)],
-                        lw / (c * c), gw * 4.0 / (c * c) / n, self.ledger[0], s.slot, workspace=self.ws))
+                    if self.style_aside and self.timer is None:
+                        self.fork()  # (a later fork only adds the dependency on the layers in between)
+                        forked = True
+                        ctx, wsb = self.frame_stream(0)
+                    else:
+                        ctx, wsb = contextlib.nullcontext(), self.ws
+                    with ctx:
+                        self._timed("gram_fwd", 2 * c * c * (n // c), n * 4 + c * c * 4, lambda: hip.gram_fwd_mse_ledger(
+                            f, 1.0 / n, s.mod.use_covariance, self.gram[id(s)], self.mean[id(s)], s.mod.target, self.dmat[id(s)],
+                            lw / (c * c), gw * 4.0 / (c * c) / n, self.ledger[0], s.slot, workspace=wsb))
                     continue
                 self._timed("gram_fwd", 2 * c * c * (n // c), n * 4 + c * c * 4, lambda: hip.gram_fwd(
                     f, 1.0 / n, s.mod.use_covariance, out=self.gram[id(s)], mean_out=self.mean[id(s)], workspace=self.ws))
@@ -440,7 +454,7 @@ class StyleEngine:
 
         cur = None  # activation index whose gradient buffer currently holds d loss / d act
         indep = self.independent and x.shape[0] > 1
-        if indep:
+        if indep or forked:
             self.join()  # the per-frame Gram / loss kernels of the forward pass
         for s in reversed(self.steps):
             if indep and s.kind in ("style", "content", "tv"):
