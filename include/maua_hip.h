@@ -117,6 +117,20 @@ int maua_conv3x3_x3w(const float* x, const void* bank, float w_scale, const floa
                      int n, int cin, int h, int w, int cout, int pad, int relu, int accumulate, void* workspace,
                      size_t workspace_bytes, maua_stream_t stream);
 
+/* The backward-data pass of a 3x3 layer fused with the Gram backward of the style loss that sits on the layer's INPUT
+ * activation F (reference: autograd of `torch.mm(x, y.T)` in GramMatrix.forward, loss.py:91, summed by autograd with the
+ * convolution's input gradient): y = [F > 0] * (conv3x3(x; backward bank) + D . F), D = the symmetric cout x cout matrix
+ * grad_scale (G - T) of maua_mse_fwd_bwd / maua_gram_fwd_mse_ledger, packed by maua_conv_pack_dmat_x3w into `dmat_bank`
+ * (maua_conv_x3w_dmat_bank_bytes(cout) bytes; dmat_inv_scale = one device float the packer writes; with n > 1 images every
+ * image has its own matrix: n consecutive banks, n consecutive scales).  Saves the separate
+ * maua_gram_bwd pass (read F, read-modify-write y).  Needs cout % 16 == 0, pad = 1 geometry (output plane = input plane),
+ * no covariance centring; `feature_map` is both the ReLU mask and the operand of D . F. */
+size_t maua_conv_x3w_dmat_bank_bytes(int c);
+int maua_conv_pack_dmat_x3w(const float* dmat, int c, void* bank, float* inv_scale_out, maua_stream_t stream);
+int maua_conv3x3_x3w_gram(const float* x, const void* bank, float w_scale, const float* feature_map, const void* dmat_bank,
+                          const float* dmat_inv_scale, float* y, int n, int cin, int h, int w, int cout, int pad, int accumulate,
+                          void* workspace, size_t workspace_bytes, maua_stream_t stream);
+
 /* ---- KS x KS stride-1 convolution in the same fp16x3 arithmetic (conv_kxk_x3.hip; KS = 5: NIN's conv2, models.py:86).
  *      Banks as for maua_conv_pack_filters_x3 with KS*KS taps; backward-data of a pad-p conv: bank_bwd, cin/cout exchanged,
  *      pad KS-1-p.  workspace (nullable) as for maua_conv3x3_x6: lets small output grids split the channel loop. ---- */

@@ -85,6 +85,49 @@ __global__ void pack_x3w_kernel(const float* __restrict__ w, unsigned short* __r
     }
 }
 
+// The symmetric C x C matrix D of a style loss (grad_scale (G - T)) as ONE-tap filter bank for the fused Gram-backward term of
+// conv_x3w_kernel: bank[chunk16][cotile][part][octet][co][ch] = D[co][ch] scaled by a power of two that brings max |D| into
+// [32, 64) like the 3x3 banks; inv[0] = 1 / scale.  One workgroup: maximum first, then the split (C <= 512: 262 k values).
+__global__ void __launch_bounds__(1024) pack_dmat_x3w_kernel(const float* __restrict__ d, int C, unsigned short* __restrict__ bank,
+                                                             float* __restrict__ inv) {
+    __shared__ float wmax[16];
+    const int tid = threadIdx.x;
+    const int64_t total = (int64_t)C * C;
+    float m = 0.f;
+    for (int64_t e = tid; e < total; e += 1024) m = fmaxf(m, fabsf(d[e]));
+    m = wave_max_nonneg(m);
+    if ((tid & 63) == 0) wmax[tid >> 6] = m;
+    __syncthreads();
+    m = 0.f;
+    for (int i = 0; i < 16; ++i) m = fmaxf(m, wmax[i]);
+    float scale = 1.f;
+    if (m > 0.f && m < 3.0e38f) {
+        const int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu) - 127;
+        scale = __builtin_bit_cast(float, (unsigned)(127 + 5 - max(e, -100)) << 23);
+    }
+    if (tid == 0) inv[0] = 1.f / scale;
+    const int nchunk = C / 16, ntile = (C + XW_COT - 1) / XW_COT;
+    const int64_t elems = (int64_t)nchunk * ntile * 2 * XW_COT * 8;  // (chunk, tile, octet, co, ch): both parts per element
+    for (int64_t e = tid; e < elems; e += 1024) {
+        int64_t r = e;
+        const int ch = (int)(r % 8);
+        r /= 8;
+        const int co = (int)(r % XW_COT);
+        r /= XW_COT;
+        const int oct = (int)(r % 2);
+        r /= 2;
+        const int tile = (int)(r % ntile);
+        const int chunk = (int)(r / ntile);
+        const int o = tile * XW_COT + co, i = chunk * 16 + oct * 8 + ch;
+        float v = o < C ? d[(int64_t)o * C + i] * scale : 0.f;
+        const _Float16 h = (_Float16)v;
+        const _Float16 l = (_Float16)(v - (float)h);
+        const int64_t base = ((int64_t)chunk * ntile + tile) * (4 * XW_COT * 8);  // [part][octet][co][ch]
+        bank[base + ((int64_t)(0 * 2 + oct) * XW_COT + co) * 8 + ch] = __builtin_bit_cast(unsigned short, h);
+        bank[base + ((int64_t)(1 * 2 + oct) * XW_COT + co) * 8 + ch] = __builtin_bit_cast(unsigned short, l);
+    }
+}
+
 // Diagnostic build only (-DXW_STAMP, tools/x3w_clock.py): shader-clock stamps at the phase boundaries of every chunk go to a
 // buffer of their own (passed in p.mask, which this kernel does not use otherwise); no output value depends on them.
 #ifdef XW_STAMP
@@ -144,14 +187,50 @@ __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_in
     const unsigned range = (unsigned)in_plane * 64u;
     float rp[3][8];
     u32x4 hl[3][2];  // the split chunk waiting for its LDS write: [item][part]
-    auto load_patch = [&](int c0) {
-        asm volatile("" : "+s"(c0));
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin + (int64_t)c0 * in_plane), 0, range, 0x00020000);
+    // The chunk list of a workgroup: the layer's input in 16-channel chunks, then (fused Gram backward) the 16-channel chunks
+    // of the layer's OUTPUT-side feature map F = omask, which meet the one-tap bank of D.
+    const int nmain = p.Cin / 16;
+    const int n2 = p.dbank ? p.Cout / 16 : 0;
+    const float* __restrict__ fin = p.dbank ? p.omask + (int64_t)n * p.Cout * in_plane : nullptr;  // (same plane size: checked on the host)
+    auto load_patch = [&](int ch) {
+        asm volatile("" : "+s"(ch));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin + (int64_t)ch * 16 * in_plane), 0, range, 0x00020000);
 #pragma unroll
         for (int c = 0; c < 8; ++c)
 #pragma unroll
             for (int k = 0; k < 3; ++k)
                 rp[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[k], c * in_plane * 4, 0));
+    };
+    // F chunks need the tile's own 8 x 32 positions only: item k = (octet k, position tid), two per thread and chunk
+    unsigned voff_f[2], lds_f[2];
+    {
+        const int r = tid >> 5, c = tid & 31;
+        const bool ok = y0 + r < p.H && x0 + c < p.W;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            voff_f[k] = ok ? (unsigned)(k * 8 * in_plane + (y0 + r) * p.W + x0 + c) * 4u : 0x80000000u;
+            lds_f[k] = (unsigned)(k * XW_PLANE + ((r + p.pad) * XW_PC + c + p.pad) * 16);
+        }
+    }
+    float (&ra)[2][8] = reinterpret_cast<float (&)[2][8]>(rp);  // buffer A shares the registers of the 3x3 staging
+    float rb[2][8];
+    auto load_f = [&](float (&r)[2][8], int c2) {
+        asm volatile("" : "+s"(c2));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fin + (int64_t)c2 * 16 * in_plane), 0, range, 0x00020000);
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                r[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff_f[k], c * in_plane * 4, 0));
+    };
+    auto publish_max_f = [&](float (&r)[2][8]) {
+        float m = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) m = fmaxf(m, fabsf(r[k][c]));
+        m = wave_max_nonneg(m);
+        if (lane == 0) Ml[wave] = m;
     };
     auto publish_max = [&]() {
         float m = 0.f;
@@ -191,6 +270,22 @@ __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_in
         }
     };
 
+    auto split_store_f = [&](float (&r)[2][8]) {  // uses the scale `sx` chunk_scale() has just set
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            u32x4 Hh, Ll;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v0 = r[k][2 * q] * sx, v1 = r[k][2 * q + 1] * sx;
+                const unsigned H = xw_cvt_pk_f16(v0, v1);
+                Hh[q] = H;
+                Ll[q] = xw_cvt_pk_f16(v0 - xw_f16_lo(H), v1 - xw_f16_hi(H));
+            }
+            *reinterpret_cast<u32x4*>(Pl + lds_f[k]) = Hh;
+            *reinterpret_cast<u32x4*>(Pl + 2 * XW_PLANE + lds_f[k]) = Ll;
+        }
+    };
+
     const unsigned char* __restrict__ bank = reinterpret_cast<const unsigned char*>(p.w6);
     // Filter slice of a chunk = 36 planes of 1 KiB in LDS order; wave w streams planes w, w + 4, ... (9 LDS-DMA instructions)
     const int wv = __builtin_amdgcn_readfirstlane(wave);
@@ -210,6 +305,19 @@ __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_in
                          : "memory");
         }
     };
+
+    // the four planes [part][octet] of D chunk c2 go where the centre tap's planes live (one per wave)
+    const unsigned char* __restrict__ dbank = reinterpret_cast<const unsigned char*>(p.dbank);
+    auto dma_d = [&](int c2) {
+        const unsigned char* g = dbank + (((int64_t)n * n2 + c2) * ntile + cotile) * 4096 + wv * 1024;  // image n's own bank
+        const unsigned lds_dst = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(Wl + (16 + wv) * 1024);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(lane16), "s"(__builtin_amdgcn_readfirstlane(lds_dst)), "s"(g)
+                     : "memory");
+    };
+    const float d_inv_scale = p.dbank ? p.dinv[n] : 0.f;
 
     // fragment byte offsets of this lane: patch (row 2 wave + row + ky, col j + kx, octet = lane half), filters (co = j)
     const int b_base = half * XW_PLANE + ((2 * wave) * XW_PC + j) * 16;
@@ -282,22 +390,25 @@ __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_in
     // chunk c:  [buffer loads of patch(c+1)]  taps 0-4, max(c+1) -> LDS | XM | DMA filter planes of taps 0-4 (c+1), scale(c+1),
     //           taps 5-8 with the split of patch(c+1) between them | X1 | DMA planes of taps 5-8, write patch(c+1), fold acc x inv(c),
     //           wait | X2 | next chunk
-    const int nchunks_all = p.Cin / 16;
+    const int nchunks_all = nmain + n2;
     const int cps = (nchunks_all + ksplit - 1) / ksplit;
     const int ch_begin = split * cps;
     const int nchunks = min(nchunks_all, ch_begin + cps);
-    dma_filters(ch_begin, 0, 9);
-    load_patch(ch_begin * 16);
-    publish_max();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    float inv_cur = chunk_scale() * w_inv_scale;  // un-scaling factor of the chunk whose products are accumulating
-    float inv_next = inv_cur;
+    float inv_cur = 0.f, inv_next = 0.f;  // un-scaling factor of the chunk whose products are accumulating / of the next one
+    if (ch_begin < min(nchunks, nmain)) {  // (a split that starts inside F, or past the end of the list, skips the 3x3 part)
+        dma_filters(ch_begin, 0, 9);
+        load_patch(ch_begin);
+        publish_max();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        inv_cur = chunk_scale() * w_inv_scale;
+        inv_next = inv_cur;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) split_item(k);
-    store_patch();
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+        for (int k = 0; k < 3; ++k) split_item(k);
+        store_patch();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
 
     // Two workgroups share a CU (one wave each per SIMD).  Launched together they run in lockstep - both in their matrix
     // phases (each at half rate), then both staging (the pipe idle): measured 2 x 3456 + 4400 cycles per chunk.  The
@@ -318,12 +429,15 @@ __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_in
         d_[2] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_s_memrealtime());
     }
 #endif
-    for (int ch = ch_begin; ch < nchunks; ++ch) {
-        const bool more = ch + 1 < nchunks;
+    const int main_end = min(nchunks, nmain);
+    const int d_begin = max(ch_begin, nmain);  // first chunk of F (if any: d_begin < nchunks)
+    for (int ch = ch_begin; ch < main_end; ++ch) {
+        const bool more = ch + 1 < main_end;
         XW_MARK(0);
         load_b(bx, 0);
         load_a(a0, 0, 0);
-        if (more) load_patch((ch + 1) * 16);
+        if (more) load_patch(ch + 1);
+        else if (d_begin < nchunks) load_f(ra, d_begin - nmain);  // the first chunk of F rides on the last chunk's products
         XW_FENCE();
         XW_TAP(0, bx, by, true, (void)0, (void)0);
         XW_TAP(1, by, bx, true, (void)0, (void)0);
@@ -367,6 +481,48 @@ __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_in
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             XW_MARK(7);
             __builtin_amdgcn_s_barrier();  // X2: patch and filters of the next chunk are in LDS
+        }
+    }
+
+    // Fused Gram backward: chunks of F against the centre-tap planes of D - one tap (12 MFMAs) per chunk, so a chunk costs
+    // what its staging costs and the loads are what to hide: two register buffers, the loads of chunk c + 2 leave when chunk
+    // c has been split (the first chunk was requested during the last 3x3 chunk).  Two barriers per chunk.
+    if (d_begin < nchunks) {
+        auto d_chunk = [&](float (&r)[2][8], int ch, bool refill) {
+            publish_max_f(r);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // the previous chunk's fragments are read; the maxima of this one are visible
+            dma_d(ch - nmain);
+            const float inv = chunk_scale() * d_inv_scale;
+            split_store_f(r);
+            if (refill) {
+                load_f(r, ch + 2 - nmain);
+                asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");  // (the planes of D are older than the 16 new loads)
+            } else {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            load_b(bx, 4);
+            load_a(a0, 4, 0);
+            load_a(a1, 4, 1);
+            XW_FENCE();
+            mfma_half(a0, bx, 0);
+            mfma_half(a1, bx, 1);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int row = 0; row < 2; ++row)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        master[t][row][q] = fmaf(acc[t][row][q], inv, master[t][row][q]);
+                        acc[t][row][q] = 0.f;
+                    }
+        };
+        if (ch_begin >= nmain) load_f(ra, d_begin - nmain);  // (a split that starts inside F: nothing was requested yet)
+        if (d_begin + 1 < nchunks) load_f(rb, d_begin + 1 - nmain);
+        for (int ch = d_begin; ch < nchunks; ch += 2) {
+            d_chunk(ra, ch, ch + 2 < nchunks);
+            if (ch + 1 < nchunks) d_chunk(rb, ch + 1, ch + 3 < nchunks);
         }
     }
 
@@ -527,6 +683,19 @@ int maua_conv_pack_filters_x3w(const float* w_oihw, void* bank_fwd, void* bank_b
     return MAUA_OK;
 }
 
+size_t maua_conv_x3w_dmat_bank_bytes(int c) {
+    if (c <= 0 || c % 16 != 0 || c > (1 << 14)) return 0;
+    return (size_t)(c / 16) * ((c + XW_COT - 1) / XW_COT) * 4096;
+}
+
+int maua_conv_pack_dmat_x3w(const float* dmat, int c, void* bank, float* inv_scale_out, maua_stream_t stream) {
+    MAUA_REQUIRE(dmat && bank && inv_scale_out && c > 0 && c % 16 == 0 && c <= (1 << 14), MAUA_E_INVAL,
+                 "conv_pack_dmat_x3w: needs a C x C matrix with C %% 16 == 0");
+    hipLaunchKernelGGL(pack_dmat_x3w_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dmat, c, (unsigned short*)bank,
+                       inv_scale_out);
+    return check_launch("pack_dmat_x3w_kernel");
+}
+
 int maua_conv_x3w_supported(int cin, int h, int w, int pad) {
     ConvArgs a{};
     a.Cin = cin;
@@ -548,9 +717,9 @@ size_t maua_conv_x3w_workspace_bytes(int n, int cin, int h, int w, int cout, int
     return ks > 1 ? (size_t)n * ks * cout * a.OH * a.OW * sizeof(float) : 0;
 }
 
-int maua_conv3x3_x3w(const float* x, const void* bank, float w_scale, const float* bias, const float* out_relu_mask, float* y,
-                     int n, int cin, int h, int w, int cout, int pad, int relu, int accumulate, void* workspace,
-                     size_t workspace_bytes, maua_stream_t stream) {
+static int conv3x3_x3w_entry(const float* x, const void* bank, float w_scale, const float* bias, const float* out_relu_mask, float* y,
+                             int n, int cin, int h, int w, int cout, int pad, int relu, int accumulate, const void* dbank,
+                             const float* dinv, void* workspace, size_t workspace_bytes, maua_stream_t stream) {
     MAUA_REQUIRE(x && bank && y && w_scale > 0.f, MAUA_E_INVAL, "conv3x3_x3w: bad args");
     MAUA_REQUIRE(conv_dims_ok(n, cin, h, w, cout, pad) && pad <= 2, MAUA_E_INVAL, "conv3x3_x3w: bad dims");
     MAUA_REQUIRE(h + 2 * pad >= 3 && w + 2 * pad >= 3, MAUA_E_UNSUPPORTED, "conv3x3_x3w: input smaller than the filter");
@@ -570,8 +739,30 @@ int maua_conv3x3_x3w(const float* x, const void* bank, float w_scale, const floa
     a.relu = relu;
     a.accumulate = accumulate;
     MAUA_REQUIRE(conv_x3w_supports(a), MAUA_E_UNSUPPORTED, "conv3x3_x3w: needs cin %% 16 == 0 and a plane of at most 2^25 pixels");
+    if (dbank) {
+        MAUA_REQUIRE(dinv && out_relu_mask, MAUA_E_INVAL, "conv3x3_x3w_gram: needs the feature map and the bank's inverse scale");
+        MAUA_REQUIRE(cout % 16 == 0 && a.OH == h && a.OW == w, MAUA_E_UNSUPPORTED,
+                     "conv3x3_x3w_gram: needs cout %% 16 == 0 and an output plane of the input's size");
+        a.dbank = dbank;
+        a.dinv = dinv;
+    }
     a.ws = (workspace && workspace_bytes >= maua_conv_x3w_workspace_bytes(n, cin, h, w, cout, pad)) ? (float*)workspace : nullptr;
     return conv_x3w_launch(a, n, w_scale, (hipStream_t)stream);
+}
+
+int maua_conv3x3_x3w(const float* x, const void* bank, float w_scale, const float* bias, const float* out_relu_mask, float* y,
+                     int n, int cin, int h, int w, int cout, int pad, int relu, int accumulate, void* workspace,
+                     size_t workspace_bytes, maua_stream_t stream) {
+    return conv3x3_x3w_entry(x, bank, w_scale, bias, out_relu_mask, y, n, cin, h, w, cout, pad, relu, accumulate, nullptr, nullptr,
+                             workspace, workspace_bytes, stream);
+}
+
+int maua_conv3x3_x3w_gram(const float* x, const void* bank, float w_scale, const float* feature_map, const void* dmat_bank,
+                          const float* dmat_inv_scale, float* y, int n, int cin, int h, int w, int cout, int pad, int accumulate,
+                          void* workspace, size_t workspace_bytes, maua_stream_t stream) {
+    MAUA_REQUIRE(dmat_bank, MAUA_E_INVAL, "conv3x3_x3w_gram: null bank");
+    return conv3x3_x3w_entry(x, bank, w_scale, nullptr, feature_map, y, n, cin, h, w, cout, pad, 0, accumulate, dmat_bank,
+                             dmat_inv_scale, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

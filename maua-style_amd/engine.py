@@ -165,6 +165,24 @@ class StyleEngine:
         self.ledger = None
         if (B == 1 or self.independent) and os.environ.get("MAUA_LOSS_LEDGER", "1") != "0":
             self.ledger = hip.loss_ledger(B, n_slots, dev)
+        # Single images: where a style loss is the only loss on the input activation of a 3x3 layer whose backward-data pass runs
+        # on conv_x3w.hip, that pass takes the Gram backward along (D . F as extra one-tap chunks of its K loop) instead of a
+        # separate read-modify-write pass over the gradient map: fused_gram[conv step] = (style step, bank of D, 1 / scale).
+        self.fused_gram = {}
+        max_c = int(os.environ.get("MAUA_FUSE_GRAM_MAX_C", "128"))  # pays on the shallow, bandwidth-bound layers
+        if (B == 1 or self.independent) and self.x6_bwd and max_c > 0:
+            relu_out = {s.dst for s in self.steps if s.kind == "conv" and s.relu}
+            for s in self.steps:
+                if s.kind != "conv" or s.k != 3 or s.stride != 1 or s.pad != 1 or s.src not in relu_out:
+                    continue
+                on_src = [t for t in self.steps if t.kind in ("style", "content") and t.src == s.src]
+                c, h, w = shapes[s.src][1:]
+                if len(on_src) == 1 and on_src[0].kind == "style" and not on_src[0].mod.use_covariance and c % 16 == 0 and \
+                        c <= max_c and self._x6_ok(s, s.mod.in_channels) and models_mod.conv3x3_bwd_is_x3w(s.mod, *shapes[s.dst][2:]):
+                    bank = hip.conv_x3w_dmat_bank(c, dev, B)
+                    if bank is not None:
+                        self.fused_gram[id(s)] = (on_src[0], bank[0], bank[1])
+        self.fused_style = {id(v[0]): v for v in self.fused_gram.values()}
         self.gram, self.dmat, self.mean = {}, {}, {}
         self.gram_d, self.dmat_d, self.mean_d = {}, {}, {}
         ws = hip.reduce_workspace_bytes(max(t.numel() for t in self.gbuf.values()))
@@ -373,6 +391,7 @@ class StyleEngine:
                 f = a[s.src]
                 c, n = f.shape[1], f[0].nelement()
                 lw, gw = self._coefficients(s)  # the single-frame weights: static + dynamic term of the same Gram
+                fs = self.fused_style.get(id(s))
                 self.fork()  # joined before the backward pass starts: nothing in the rest of the forward pass needs these
                 for b in range(f.shape[0]):
                     mean_b = self.mean[id(s)][b] if s.mod.use_covariance else None
@@ -382,11 +401,15 @@ class StyleEngine:
                             self._timed("gram_fwd", 2 * c * c * (n // c), n * 4 + c * c * 4, lambda: hip.gram_fwd_mse_ledger(
                                 f[b:b + 1], 1.0 / n, s.mod.use_covariance, self.gram[id(s)][b], mean_b, s.mod.target,
                                 self.dmat[id(s)][b], lw / (c * c), gw * 4.0 / (c * c) / n, self.ledger[b], s.slot, workspace=wsb))
+                            if fs is not None:
+                                hip.conv_pack_dmat_x3w(self.dmat[id(s)][b], fs[1][b], fs[2][b:b + 1])
                             continue
                         self._timed("gram_fwd", 2 * c * c * (n // c), n * 4 + c * c * 4, lambda: hip.gram_fwd(
                             f[b:b + 1], 1.0 / n, s.mod.use_covariance, out=self.gram[id(s)][b], mean_out=mean_b, workspace=wsb))
                         hip.mse_fwd_bwd(self.gram[id(s)][b], s.mod.target, self.dmat[id(s)][b], lw / (c * c),
                                         gw * 4.0 / (c * c) / n, False, self.slots_all[b, s.slot:s.slot + 1], workspace=wsb)
+                        if fs is not None:
+                            hip.conv_pack_dmat_x3w(self.dmat[id(s)][b], fs[1][b], fs[2][b:b + 1])
             elif s.kind == "style" and self._active(s, a[s.src].shape) and a[s.src].shape[0] > 1:
                 f = a[s.src]
                 B, c, n = f.shape[0], f.shape[1], f[0].nelement()
@@ -434,11 +457,15 @@ class StyleEngine:
                         self._timed("gram_fwd", 2 * c * c * (n // c), n * 4 + c * c * 4, lambda: hip.gram_fwd_mse_ledger(
                             f, 1.0 / n, s.mod.use_covariance, self.gram[id(s)], self.mean[id(s)], s.mod.target, self.dmat[id(s)],
                             lw / (c * c), gw * 4.0 / (c * c) / n, self.ledger[0], s.slot, workspace=wsb))
+                        if id(s) in self.fused_style:
+                            hip.conv_pack_dmat_x3w(self.dmat[id(s)], self.fused_style[id(s)][1][0], self.fused_style[id(s)][2])
                     continue
                 self._timed("gram_fwd", 2 * c * c * (n // c), n * 4 + c * c * 4, lambda: hip.gram_fwd(
                     f, 1.0 / n, s.mod.use_covariance, out=self.gram[id(s)], mean_out=self.mean[id(s)], workspace=self.ws))
                 hip.mse_fwd_bwd(self.gram[id(s)], s.mod.target, self.dmat[id(s)], lw / (c * c), gw * 4.0 / (c * c) / n,
                                 False, self.slots[s.slot:s.slot + 1], workspace=self.ws)
+                if id(s) in self.fused_style:
+                    hip.conv_pack_dmat_x3w(self.dmat[id(s)], self.fused_style[id(s)][1][0], self.fused_style[id(s)][2])
         # ---------------- backward
         # Gradient buffers of fused conv+ReLU activations are kept PRE-MASKED: the last kernel that writes g[k] (the
         # backward of the consumer, or the last loss term attached to k) zeroes it where a[k] <= 0, so no backward-data
@@ -452,6 +479,7 @@ class StyleEngine:
         def premask(s):
             return final_writer.get(s.src) is s and s.src in relu_acts
 
+        fused_done = set()
         cur = None  # activation index whose gradient buffer currently holds d loss / d act
         indep = self.independent and x.shape[0] > 1
         if indep or forked:
@@ -460,6 +488,8 @@ class StyleEngine:
             if indep and s.kind in ("style", "content", "tv"):
                 if s.kind != "tv" and not self._active(s, a[s.src].shape):
                     continue
+                if id(s) in fused_done:
+                    continue  # its Gram backward went along with the convolution's backward pass
                 f = a[s.src]
                 acc = cur == s.src
                 last_step = s.kind == "tv"  # module 0: the totals can be formed on the frame's stream right behind it
@@ -521,6 +551,8 @@ class StyleEngine:
                                         self.slots_all[slots[b]:slots[b] + 1], workspace=self.ws, mask_grad_by_x=premask(s))
                     cur = s.src
             elif s.kind == "style":
+                if id(s) in fused_done:
+                    continue  # its Gram backward went along with the convolution's backward pass
                 if self._active(s, a[s.src].shape):
                     f = a[s.src]
                     c, n = f.shape[1], f[0].nelement()
@@ -555,7 +587,13 @@ class StyleEngine:
                 assert cur == s.dst
                 fl, nb = self._conv_work(s, a[s.src].shape, a[s.dst].shape, True)
                 im = a[s.src] if premask(s) else None
-                if self.x6_bwd and self._x6_ok(s, s.mod.in_channels):
+                fg = self.fused_gram.get(id(s))
+                if fg is not None and self._active(fg[0], a[s.src].shape) and premask(fg[0]):
+                    c, n = a[s.src].shape[1], a[s.src][0].nelement()
+                    self._timed("conv3x3_split_bwd", fl + 2 * c * c * (n // c), nb, lambda: models_mod.conv3x3_bwd_with_gram(
+                        g[s.dst], s.mod, a[s.src], fg[1], fg[2], out=g[s.src], workspace=self.ws))
+                    fused_done.add(id(fg[0]))
+                elif self.x6_bwd and self._x6_ok(s, s.mod.in_channels):
                     self._timed("conv3x3_split_bwd", fl, nb, lambda: models_mod.conv3x3_mfma(
                         g[s.dst], s.mod, True, out=g[s.src], out_relu_mask=im, workspace=self.ws))
                 elif self.x6_bwd and models_mod.conv1x1_is_mfma(s.mod, True):

@@ -73,6 +73,9 @@ SIGNATURES = {
     "maua_deprocess_u8": (c_i, [c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_p]),
     "maua_set_split_batch_hint": (None, [c_i]),
     "maua_get_split_batch_hint": (c_i, []),
+    "maua_conv_x3w_dmat_bank_bytes": (c_sz, [c_i]),
+    "maua_conv_pack_dmat_x3w": (c_i, [c_p, c_i, c_p, c_p, c_p]),
+    "maua_conv3x3_x3w_gram": (c_i, [c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "maua_loss_ledger_bytes": (c_sz, [c_i, c_i]),
     "maua_mse_fwd_bwd_ledger": (c_i, [c_p, c_p, c_p, c_i64, c_f, c_f, c_i, c_i, c_p, c_i, c_p]),
     "maua_tv_fwd_bwd_ledger": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_i, c_p]),
@@ -280,6 +283,34 @@ def conv3x3_x3w(x, bank, w_scale, bias, cout, pad, relu, out=None, out_relu_mask
     wp, wn = _ws_args(workspace, conv_x3w_workspace_bytes(n, cin, h, w, cout, pad) if workspace is None else 0, x.device)
     _check(lib().maua_conv3x3_x3w(_ptr(_f32(x, "x")), bank.data_ptr(), float(w_scale), _ptr(bias), _ptr(out_relu_mask), _ptr(out), n,
                                   cin, h, w, cout, pad, int(relu), int(accumulate), wp, wn, _stream()), "maua_conv3x3_x3w")
+    return out
+
+
+def conv_x3w_dmat_bank(c, device, frames=1):
+    """(banks (frames, bytes), inverse scales (frames,)) for conv_pack_dmat_x3w / conv3x3_x3w_gram; None when c is not a multiple
+    of 16."""
+    nbytes = lib().maua_conv_x3w_dmat_bank_bytes(int(c))
+    if nbytes == 0:
+        return None
+    return torch.empty(frames, nbytes, dtype=torch.uint8, device=device), torch.ones(frames, dtype=torch.float32, device=device)
+
+
+def conv_pack_dmat_x3w(dmat, bank, inv_scale):
+    c = dmat.shape[0]
+    _check(lib().maua_conv_pack_dmat_x3w(_ptr(_f32(dmat, "dmat")), c, bank.data_ptr(), _ptr(inv_scale), _stream()),
+           "maua_conv_pack_dmat_x3w")
+
+
+def conv3x3_x3w_gram(x, bank, w_scale, feature_map, dmat_bank, dmat_inv_scale, cout, pad, out=None, accumulate=False,
+                     workspace=None):
+    """Backward-data pass + Gram backward in one launch: out = [F > 0] * (conv(x) + D . F)."""
+    n, cin, h, w = x.shape
+    if out is None:
+        out = torch.empty(n, cout, h + 2 * pad - 2, w + 2 * pad - 2, device=x.device, dtype=torch.float32)
+    wp, wn = _ws_args(workspace, conv_x3w_workspace_bytes(n, cin, h, w, cout, pad) if workspace is None else 0, x.device)
+    _check(lib().maua_conv3x3_x3w_gram(_ptr(_f32(x, "x")), bank.data_ptr(), float(w_scale), _ptr(_f32(feature_map, "feature_map")),
+                                       dmat_bank.data_ptr(), _ptr(dmat_inv_scale), _ptr(out), n, cin, h, w, cout, pad,
+                                       int(accumulate), wp, wn, _stream()), "maua_conv3x3_x3w_gram")
     return out
 
 

@@ -91,6 +91,22 @@ def conv3x3_mfma(x, mod, backward, out=None, out_relu_mask=None, relu=False, acc
                           accumulate=accumulate, workspace=workspace)
 
 
+def conv3x3_bwd_is_x3w(mod, h, w):
+    """Whether the backward-data pass of a 3x3 layer on an h x w plane runs on conv_x3w.hip (the kernel that can take the Gram
+    backward of a style loss along, hip.conv3x3_x3w_gram)."""
+    pad = mod.padding[0]
+    return _x3_enabled() and _x3w_enabled() and h * w >= _x3w_min_pixels() and mod.kernel_size[0] == 3 and mod.stride[0] == 1 and \
+        hip.conv_x3w_supported(mod.out_channels, h, w, 2 - pad)
+
+
+def conv3x3_bwd_with_gram(gy, mod, feature_map, dmat_bank, dmat_inv_scale, out, workspace=None):
+    """out = [F > 0] * (backward-data of the layer + D . F): the layer's input gradient and the Gram backward of the style loss on
+    its input activation F in one launch."""
+    _, bb, wsc = mod.banks3w()
+    return hip.conv3x3_x3w_gram(gy, bb, wsc, feature_map, dmat_bank, dmat_inv_scale, mod.in_channels, 2 - mod.padding[0], out=out,
+                                workspace=workspace)
+
+
 def conv1x1_is_mfma(mod, backward):
     """Whether a layer's pass runs on the fp16x3 1x1 kernel (conv1x1_x3.hip): 1x1, stride 1, no padding (NIN's cccp layers,
     reference models.py:84-110), the split-precision path enabled for that pass and fp16x3 selected."""

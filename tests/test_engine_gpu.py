@@ -673,3 +673,24 @@ def test_engine_reads_no_uninitialised_memory(weight_files, monkeypatch):
         res[poison] = (slots.clone().cpu(), grad.clone().cpu(), batch)
     for a, b in zip(res["0"], res["1"]):
         assert torch.isfinite(b).all() and torch.equal(a, b)
+
+
+def test_gram_backward_fused_into_the_convolution_equals_the_separate_pass(weight_files, monkeypatch):
+    """Single images above 64 x 64-pixel planes: the backward passes of conv1_2 / conv2_2 take the Gram backward of relu1_1 /
+    relu2_1 along (conv_x3w.hip).  Same losses bit for bit, pixel gradient equal to the separate passes to fp32 rounding and as
+    close to the fp64 oracle."""
+    import engine
+    res = {}
+    for max_c in ("0", "128", "512"):
+        monkeypatch.setenv("MAUA_FUSE_GRAM_MAX_C", max_c)
+        args = product_args(weight_files, S=128)
+        content, style, init = synth.images(128)
+        net, losses = build(args, content, [style], 128)
+        eng = engine.StyleEngine(net, losses)
+        slots, total, grad = eng.feval(init.cuda())
+        torch.cuda.synchronize()
+        res[max_c] = (slots.clone().cpu(), float(total), grad.clone().cpu(), len(eng.fused_gram))
+    assert res["0"][3] == 0 and res["128"][3] == 2 and res["512"][3] >= 2
+    for k in ("128", "512"):
+        assert torch.equal(res[k][0], res["0"][0]) and res[k][1] == res["0"][1]
+        assert rel_l2(res[k][2], res["0"][2].double()) <= 2e-6

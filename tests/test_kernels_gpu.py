@@ -997,3 +997,30 @@ def test_loss_ledger_equals_the_immediate_entry_points(hip, C, HW, center):
     torch.cuda.synchronize()
     assert float(l1[0, 2]) == float(l0[2])
     assert hip.gram_mse_ledger_supported(1408) and not hip.gram_mse_ledger_supported(1409)
+
+
+@pytest.mark.parametrize("cin,c,H,W", [(64, 64, 64, 96), (128, 128, 40, 72), (128, 64, 33, 50), (64, 128, 16, 520)])
+def test_backward_pass_with_the_gram_backward_along(hip, cin, c, H, W):
+    """maua_conv3x3_x3w_gram (backward-data pass + D . F of the style loss on the layer's input activation, masked by that
+    activation) against fp64 and against the two separate passes it replaces (maua_conv3x3_x3w backward + maua_gram_bwd)."""
+    gy = rnd(1, cin, H, W, seed=71) * (rnd(1, cin, H, W, seed=72) > 0)     # a ReLU-masked gradient
+    w = rnd(cin, c, 3, 3, seed=73) * (2.0 / (9 * c)) ** 0.5               # layer c -> cin channels; backward-data: cin -> c
+    f = torch.relu(rnd(1, c, H, W, seed=74))
+    d = rnd(c, c, seed=75) * 1e-3
+    d = (d + d.t()).contiguous()
+    _, bb, wsc = hip.conv_pack_filters_x3w(dev(w))
+    dbank, dinv = hip.conv_x3w_dmat_bank(c, "cuda")
+    hip.conv_pack_dmat_x3w(dev(d), dbank, dinv)
+    fused = hip.conv3x3_x3w_gram(dev(gy), bb, wsc, dev(f), dbank, dinv, c, 1)
+    two = hip.conv3x3_x3w(dev(gy), bb, wsc, None, c, 1, False)
+    hip.gram_bwd(dev(d), dev(f), None, two, True, relu_mask=dev(f))
+    torch.cuda.synchronize()
+    ref = F.conv_transpose2d(gy.double(), w.double(), padding=1) + torch.einsum("kc,bkhw->bchw", d.double(), f.double())
+    ref = ref * (f > 0)
+    e_fused, e_two = rel_l2(fused.cpu(), ref), rel_l2(two.cpu(), ref)
+    assert e_fused <= 3e-7 and e_fused <= 1.5 * e_two + 1e-8, (e_fused, e_two)
+    assert torch.equal(fused == 0, two == 0) or float(((fused == 0) != (two == 0)).sum()) < 1e-5 * fused.numel()
+    again = hip.conv3x3_x3w_gram(dev(gy), bb, wsc, dev(f), dbank, dinv, c, 1)
+    assert torch.equal(fused, again)
+    # the bank's scale: max |D| lands in [32, 64)
+    assert 32.0 <= float(d.abs().max()) / float(dinv[0]) < 64.0
