@@ -131,6 +131,9 @@ lbfgs_pair_kernel(const LbfgsHeader* __restrict__ hdr, const float* __restrict__
 // Small vectors (a 256 x 256 image is 48 blocks) leave most of the chip idle, so the pair loop is also cut into gridDim.y
 // groups: workgroup (block, group) handles the pairs [group * per, (group + 1) * per) of its block.  Every (block, id) entry is
 // still computed by exactly one workgroup with the same arithmetic, whatever the number of groups: bit-identical results.
+// VEC: the thread's 16 elements are four float4 (count % 4 == 0, 16-byte aligned vectors) instead of 16 strided floats: a quarter
+// of the memory requests for the same bytes.
+template <bool VEC>
 __global__ void __launch_bounds__(256)
 lbfgs_pair_dots_kernel(LbfgsHeader* __restrict__ hdr, const float* __restrict__ g, const float* __restrict__ S,
                        const float* __restrict__ Y, float* __restrict__ partial, int64_t n, int m1) {
@@ -155,7 +158,7 @@ lbfgs_pair_dots_kernel(LbfgsHeader* __restrict__ hdr, const float* __restrict__ 
         const float* yB = Y + (int64_t)cand * n + blk;
 #pragma unroll
         for (int k = 0; k < LB_EPT; ++k) {
-            const int e = tid + 256 * k;
+            const int e = VEC ? 4 * (tid + 256 * (k >> 2)) + (k & 3) : tid + 256 * k;
             const bool ok = e < rem;
             off[k] = ok ? e : 0;  // lanes past the end re-read element 0 and multiply it by zero columns
             gv[k] = ok ? gB[off[k]] : 0.f;
@@ -169,10 +172,20 @@ lbfgs_pair_dots_kernel(LbfgsHeader* __restrict__ hdr, const float* __restrict__ 
         const float* sp = S + (int64_t)p * n + blk;
         const float* yp = Y + (int64_t)p * n + blk;
         float ls[LB_EPT], ly[LB_EPT];
+        if constexpr (VEC) {
 #pragma unroll
-        for (int k = 0; k < LB_EPT; ++k) {
-            ls[k] = sp[off[k]];
-            ly[k] = yp[off[k]];
+            for (int k = 0; k < LB_EPT; k += 4) {  // (off[k] is a multiple of 4: rem % 4 == 0)
+                const float4 a = *reinterpret_cast<const float4*>(sp + off[k]);
+                const float4 b = *reinterpret_cast<const float4*>(yp + off[k]);
+                ls[k] = a.x, ls[k + 1] = a.y, ls[k + 2] = a.z, ls[k + 3] = a.w;
+                ly[k] = b.x, ly[k + 1] = b.y, ly[k + 2] = b.z, ly[k + 3] = b.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < LB_EPT; ++k) {
+                ls[k] = sp[off[k]];
+                ly[k] = yp[off[k]];
+            }
         }
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
 #pragma unroll
@@ -716,13 +729,13 @@ lbfgs_combine_kernel(const LbfgsHeader* __restrict__ hdr, const float* __restric
 
 // Sweep 2 for small vectors (count % 4 == 0): one float4 per thread, 64-thread workgroups - wide loads AND enough waves to
 // cover the chip; per element the same sum in the same order as above.
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 lbfgs_combine_v4_kernel(const LbfgsHeader* __restrict__ hdr, const float* __restrict__ coef, const float* __restrict__ g,
                         const float* __restrict__ S, const float* __restrict__ Y, float* __restrict__ d, float* __restrict__ x,
                         int64_t n, int m1, unsigned* __restrict__ dmax_bits) {
     const int len = hdr->len, head = hdr->head, stopped = hdr->stopped;
     const float t = hdr->t;
-    const int64_t e = ((int64_t)blockIdx.x * 64 + threadIdx.x) * 4;
+    const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const bool ok = e < n;
     const int64_t ec = ok ? e : 0;
     const float cg = coef[2 * m1];
@@ -753,7 +766,7 @@ lbfgs_combine_v4_kernel(const LbfgsHeader* __restrict__ hdr, const float* __rest
         }
     }
     dm = wave_max_nonneg(dm);
-    if (threadIdx.x == 0 && !stopped) atomicMax(dmax_bits, __float_as_uint(dm));
+    if ((threadIdx.x & 63) == 0 && !stopped) atomicMax(dmax_bits, __float_as_uint(dm));
 }
 
 __global__ void lbfgs_status_kernel(const LbfgsHeader* __restrict__ hdr, float* __restrict__ out) {
@@ -813,7 +826,15 @@ int maua_lbfgs_iterate(void* state, float* x, const float* grad, const float* lo
     if (rc) return rc;
     int groups = (1024 + L.nwg - 1) / L.nwg;  // pair-loop groups: aim at ~4 workgroups per CU
     if (groups > L.m1) groups = L.m1;
-    hipLaunchKernelGGL(lbfgs_pair_dots_kernel, dim3(L.nwg, groups), dim3(256), lds1, s, hdr, grad, S, Y, partial, count, L.m1);
+    const bool aligned = count % 4 == 0 && (((uintptr_t)x | (uintptr_t)grad) & 15) == 0;
+    static const bool vec_on = [] {
+        const char* e = getenv("MAUA_LBFGS_VEC");
+        return !e || atoi(e) != 0;
+    }();
+    if (aligned && vec_on)
+        hipLaunchKernelGGL(lbfgs_pair_dots_kernel<true>, dim3(L.nwg, groups), dim3(256), lds1, s, hdr, grad, S, Y, partial, count, L.m1);
+    else
+        hipLaunchKernelGGL(lbfgs_pair_dots_kernel<false>, dim3(L.nwg, groups), dim3(256), lds1, s, hdr, grad, S, Y, partial, count, L.m1);
     rc = check_launch("lbfgs_pair_dots_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(lbfgs_finish_dots_kernel, dim3(L.nb_ids), dim3(256), 0, s, hdr, partial, dots, L.nwg, L.nb_ids, L.m1);
@@ -846,11 +867,10 @@ int maua_lbfgs_iterate(void* state, float* x, const float* grad, const float* lo
         hipLaunchKernelGGL(kernel, dim3((unsigned)((count + 256 * ept - 1) / (256 * ept))), dim3(256), 0, s, hdr, coef, grad, S, Y, d,
                            x, count, L.m1, &hdr->dmax_bits);
     };
-    const bool aligned = count % 4 == 0 && (((uintptr_t)x | (uintptr_t)grad) & 15) == 0;
-    if (count >= 256 * 16 * 512) combine(lbfgs_combine_kernel<16>, 16);
-    else if (aligned)
-        hipLaunchKernelGGL(lbfgs_combine_v4_kernel, dim3((unsigned)((count / 4 + 63) / 64)), dim3(64), 0, s, hdr, coef, grad, S, Y, d, x,
-                           count, L.m1, &hdr->dmax_bits);
+    if (count >= 256 * 16 * 512) combine(lbfgs_combine_kernel<16>, 16);  // (large vectors: both forms run at the HBM rate)
+    else if (aligned && vec_on)      // small ones: one float4 per thread, 64-thread workgroups - wide loads and enough waves
+        hipLaunchKernelGGL(lbfgs_combine_v4_kernel, dim3((unsigned)((count / 4 + 63) / 64)), dim3(64), 0, s, hdr, coef, grad, S, Y, d,
+                           x, count, L.m1, &hdr->dmax_bits);
     else if (count >= 256 * 4 * 512) combine(lbfgs_combine_kernel<4>, 4);
     else combine(lbfgs_combine_kernel<1>, 1);
     return check_launch("lbfgs_combine_kernel");

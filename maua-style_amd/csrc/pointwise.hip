@@ -30,22 +30,51 @@ __global__ void finish_sum_kernel(const double* __restrict__ partial, int n, flo
 __global__ void __launch_bounds__(256)
 loss_ledger_sum_kernel(double* __restrict__ ledger, int slots, float* __restrict__ losses, float* __restrict__ total) {
     __shared__ double scratch[16];
+    __shared__ int cnt[64];
+    __shared__ double scl[64];
+    __shared__ float kept[64];
     double* led = ledger + (int64_t)blockIdx.x * slots * LEDGER_STRIDE;
     float* out = losses + (int64_t)blockIdx.x * slots;
     float tot = 0.f;
-    for (int s = 0; s < slots; ++s) {
-        double* rec = led + (int64_t)s * LEDGER_STRIDE;
-        const int n = (int)rec[0];
-        if (n > 0) {
-            double v = 0.0;
-            for (int i = threadIdx.x; i < n; i += blockDim.x) v += rec[2 + i];
-            v = block_sum(v, scratch);  // (two barriers: every thread has read rec[0] before thread 0 clears it)
-            if (threadIdx.x == 0) {
-                out[s] = (float)(v * rec[1]);
-                rec[0] = 0.0;
-            }
+    constexpr int PER = LEDGER_MAX / 256;  // partial sums per thread
+    for (int s0 = 0; s0 < slots; s0 += 64) {
+        const int ns = min(64, slots - s0);
+        __syncthreads();
+        if ((int)threadIdx.x < ns) {  // all record headers of the group at once: a dependent load apiece would cost its latency ns times
+            const double* rec = led + (int64_t)(s0 + threadIdx.x) * LEDGER_STRIDE;
+            cnt[threadIdx.x] = min((int)rec[0], LEDGER_MAX);
+            scl[threadIdx.x] = rec[1];
+            kept[threadIdx.x] = out[s0 + threadIdx.x];
         }
-        if (threadIdx.x == 0) tot += out[s];
+        __syncthreads();
+        // the partial sums of record s + 1 are requested before record s is reduced
+        double nxt[PER];
+        auto fetch = [&](int s) {
+            const double* rec = led + (int64_t)(s0 + s) * LEDGER_STRIDE + 2;
+            const int n = s < ns ? cnt[s] : 0;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int idx = threadIdx.x + 256 * i;
+                nxt[i] = idx < n ? rec[idx] : 0.0;
+            }
+        };
+        fetch(0);
+        for (int s = 0; s < ns; ++s) {
+            double v = 0.0;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) v += nxt[i];  // finish_sum_kernel's order (absent entries add +0)
+            const int n = cnt[s];
+            fetch(s + 1);
+            if (n > 0) {  // (uniform)
+                v = block_sum(v, scratch);
+                if (threadIdx.x == 0) {
+                    kept[s] = (float)(v * scl[s]);
+                    out[s0 + s] = kept[s];
+                    led[(int64_t)(s0 + s) * LEDGER_STRIDE] = 0.0;
+                }
+            }
+            if (threadIdx.x == 0) tot += kept[s];
+        }
     }
     if (threadIdx.x == 0) total[blockIdx.x] = tot;
 }
