@@ -246,7 +246,7 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--hip_graph", action="store_true", help="(default) replay each iteration from a captured hipGraph")
     ap.add_argument("--no_hip_graph", action="store_true", help="launch every kernel eagerly in the timed region too")
-    ap.add_argument("--no_extra_sizes", action="store_true", help="skip the 512x512 figure in `extra`")
+    ap.add_argument("--no_extra_sizes", action="store_true", help="skip the 512x512 / 256x256 figures in `extra`")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a.gpus, sys.argv[1:]))  # before anything in this process touches the GPU
@@ -411,7 +411,7 @@ def main():
     }
     if world == 1 and not a.no_extra_sizes and S == 1024:
         del opt  # frees the 2.5 GB history slab before the next job allocates its own
-        out["extra"] = {"other_sizes": [steady_rate(512, max(a.steps, 100), a.optimizer, a.history)]}
+        out["extra"] = {"other_sizes": [steady_rate(sz, max(a.steps, 100), a.optimizer, a.history) for sz in (512, 256)]}
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(S, a.optimizer)
     print(json.dumps(out), flush=True)

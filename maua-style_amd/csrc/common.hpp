@@ -104,6 +104,8 @@ struct ConvArgs {
     int ksplit;          // conv_x6 split-K: > 1 -> blockIdx.z = n*ksplit + split, raw partial sums go to `ws`
     float* ws;           // [n][ksplit][Cout][OH][OW] partial sums (split-K only)
     int stagger;         // conv_x3w: start delay (units of 512 cycles) of the first-round workgroups in odd CU slots
+    unsigned char* pool_codes;  // conv_x3w forward, nullable: the epilogue applies ReLU and the 2x2 / 2 max pool that follows,
+                                // `y` is the POOLED map and these are its decision bytes (pool2x2_fwd_codes_kernel's)
     const void* dbank;   // conv_x3w, nullable: packed Cout x Cout matrix D (maua_conv_pack_dmat_x3w); the kernel adds D . omask
     const float* dinv;   //   (the Gram backward of the style loss on this layer's output) to its sums; dinv[0] = 1 / scale of the bank
 };

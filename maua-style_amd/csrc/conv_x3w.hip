@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(1024) pack_dmat_x3w_kernel(const float* __rest
 #define XW_MARK(k) do {} while (0)
 #endif
 
-template <bool ACC, bool OM>
+template <bool ACC, bool OM, bool POOL = false>
 __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_inv_scale) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[XW_PATCH_BYTES + XW_W_BYTES + 16];
     unsigned char* Pl = smem;                    // [part][octet][pos][16 B]
@@ -534,6 +534,39 @@ __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_in
     }
 #endif
     // epilogue: lane holds pixel column j of rows y0 + 2 wave + {0, 1}; register r is output channel (r&3)+8*(r>>2)+4*half
+    if constexpr (POOL) {
+        // ReLU + the 2x2 / 2 max pool behind it: a wave's two rows and neighbouring lanes are exactly the windows, so the
+        // full-size activation never goes to memory - only the pooled map and one decision byte per window (what
+        // pool2x2_fwd_codes_kernel leaves: position of the first maximum in scan order, bit 2 = the maximum is <= 0).
+        const int PW = p.OW >> 1;
+        const int64_t pplane = (int64_t)(p.OH >> 1) * PW;
+        float* __restrict__ py = p.y + (int64_t)n * p.Cout * pplane;
+        unsigned char* __restrict__ pc = p.pool_codes + (int64_t)n * p.Cout * pplane;
+        const int oy = y0 + 2 * wave, oxx = x0 + j;
+        const bool store = (lane & 1) == 0 && oy + 1 < p.OH && oxx + 1 < p.OW;  // (even extents: a window is inside or outside)
+        const int64_t ppix = (int64_t)(oy >> 1) * PW + (oxx >> 1);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float a = master[t][0][r], c = master[t][1][r];
+                a = a > 0.f ? a : 0.f;
+                c = c > 0.f ? c : 0.f;
+                const float b = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x101, 0xf, 0xf, false));  // row_shl:1
+                const float d = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c), 0x101, 0xf, 0xf, false));
+                float m = a;
+                int arg = 0;
+                if (b > m) { m = b; arg = 1; }
+                if (c > m) { m = c; arg = 2; }
+                if (d > m) { m = d; arg = 3; }
+                if (store && co < p.Cout) {
+                    py[(int64_t)co * pplane + ppix] = m;
+                    pc[(int64_t)co * pplane + ppix] = (unsigned char)(arg | (m > 0.f ? 0 : 4));
+                }
+            }
+        return;
+    }
     float* __restrict__ yout = p.y + (int64_t)n * p.Cout * out_plane;
     const float* __restrict__ om = p.omask ? p.omask + (int64_t)n * p.Cout * out_plane : nullptr;
     const int ox = x0 + j;
@@ -599,6 +632,11 @@ static int x3w_choose_split(const ConvArgs& a, int n) {
               // launch (maua_set_split_batch_hint, 1 by default): vid_img's frames are then computed with the same summation
               // order whether they run one at a time or sixteen together - bit-identical results whatever the grouping.
     const int nchunks = a.Cin / 16;
+    static const int forced = [] {  // experiments: MAUA_X3W_KS=k splits every launch k ways (when the layer has the chunks)
+        const char* e = getenv("MAUA_X3W_KS");
+        return e ? atoi(e) : 0;
+    }();
+    if (forced > 0) return forced <= nchunks / 2 ? forced : (nchunks >= 4 ? nchunks / 2 : 1);
     if (wgs >= 2048 || nchunks < 4) return 1;
     const double out_mb = (double)split_batch_hint() * a.Cout * a.OH * a.OW * 4.0 / 1e6;
     int best = 1;
@@ -644,7 +682,8 @@ int conv_x3w_launch(const ConvArgs& a, int n, float w_scale, hipStream_t stream)
         }();
         p.stagger = stagger;
     }
-    if (acc && om) hipLaunchKernelGGL((conv_x3w_kernel<true, true>), grid, dim3(256), 0, stream, p, w_inv);
+    if (a.pool_codes) hipLaunchKernelGGL((conv_x3w_kernel<false, false, true>), grid, dim3(256), 0, stream, p, w_inv);
+    else if (acc && om) hipLaunchKernelGGL((conv_x3w_kernel<true, true>), grid, dim3(256), 0, stream, p, w_inv);
     else if (acc) hipLaunchKernelGGL((conv_x3w_kernel<true, false>), grid, dim3(256), 0, stream, p, w_inv);
     else if (om) hipLaunchKernelGGL((conv_x3w_kernel<false, true>), grid, dim3(256), 0, stream, p, w_inv);
     else hipLaunchKernelGGL((conv_x3w_kernel<false, false>), grid, dim3(256), 0, stream, p, w_inv);
@@ -755,6 +794,41 @@ int maua_conv3x3_x3w(const float* x, const void* bank, float w_scale, const floa
                      size_t workspace_bytes, maua_stream_t stream) {
     return conv3x3_x3w_entry(x, bank, w_scale, bias, out_relu_mask, y, n, cin, h, w, cout, pad, relu, accumulate, nullptr, nullptr,
                              workspace, workspace_bytes, stream);
+}
+
+int maua_conv_x3w_split(int n, int cin, int h, int w, int cout, int pad) {
+    if (!conv_dims_ok(n, cin, h, w, cout, pad)) return 0;
+    ConvArgs a{};
+    a.Cin = cin;
+    a.Cout = cout;
+    a.OH = h + 2 * pad - 2;
+    a.OW = w + 2 * pad - 2;
+    if (a.OH <= 0 || a.OW <= 0) return 0;
+    return x3w_choose_split(a, n);
+}
+
+int maua_conv3x3_x3w_relu_pool(const float* x, const void* bank, float w_scale, const float* bias, float* pooled,
+                               unsigned char* codes, int n, int cin, int h, int w, int cout, int pad, maua_stream_t stream) {
+    MAUA_REQUIRE(x && bank && pooled && codes && w_scale > 0.f, MAUA_E_INVAL, "conv3x3_x3w_relu_pool: bad args");
+    MAUA_REQUIRE(conv_dims_ok(n, cin, h, w, cout, pad) && pad <= 2, MAUA_E_INVAL, "conv3x3_x3w_relu_pool: bad dims");
+    ConvArgs a{};
+    a.x = x;
+    a.w6 = bank;
+    a.bias = bias;
+    a.y = pooled;
+    a.pool_codes = codes;
+    a.Cin = cin;
+    a.H = h;
+    a.W = w;
+    a.Cout = cout;
+    a.OH = h + 2 * pad - 2;
+    a.OW = w + 2 * pad - 2;
+    a.pad = pad;
+    a.relu = 1;
+    MAUA_REQUIRE(a.OH >= 2 && a.OW >= 2 && a.OH % 2 == 0 && a.OW % 2 == 0 && conv_x3w_supports(a), MAUA_E_UNSUPPORTED,
+                 "conv3x3_x3w_relu_pool: needs an even output plane, cin %% 16 == 0");
+    a.ws = nullptr;  // one pass over the channels: the epilogue holds complete sums
+    return conv_x3w_launch(a, n, w_scale, (hipStream_t)stream);
 }
 
 int maua_conv3x3_x3w_gram(const float* x, const void* bank, float w_scale, const float* feature_map, const void* dmat_bank,

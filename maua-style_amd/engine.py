@@ -165,6 +165,20 @@ class StyleEngine:
         self.ledger = None
         if (B == 1 or self.independent) and os.environ.get("MAUA_LOSS_LEDGER", "1") != "0":
             self.ledger = hip.loss_ledger(B, n_slots, dev)
+        # conv + ReLU whose only consumer is a 2x2 / 2 max pool with kept decisions, on conv_x3w.hip in one pass over the
+        # channels: the pool runs in the convolution's epilogue and the full-size activation is never written (nothing reads
+        # it: the backward pass routes by the decision bytes).  fused_pool[conv step] = pool step.
+        self.fused_pool = {}
+        if self.x6_fwd and os.environ.get("MAUA_FUSE_POOL", "1") != "0":
+            for s in self.steps:
+                if s.kind != "conv" or not s.relu or s.k != 3 or s.stride != 1:
+                    continue
+                users = [t for t in self.steps if t.src == s.dst and t is not s]
+                if len(users) == 1 and users[0].kind == "pool" and id(users[0]) in self.pool_codes and \
+                        self._x6_ok(s, s.mod.out_channels) and models_mod.conv3x3_fwd_is_x3w(s.mod, *shapes[s.src][2:]) and \
+                        hip.conv_x3w_split(B, shapes[s.src][1], shapes[s.src][2], shapes[s.src][3], s.mod.out_channels, s.pad) == 1:
+                    self.fused_pool[id(s)] = users[0]
+        self.pooled_by_conv = {id(v) for v in self.fused_pool.values()}
         # Single images: where a style loss is the only loss on the input activation of a 3x3 layer whose backward-data pass runs
         # on conv_x3w.hip, that pass takes the Gram backward along (D . F as extra one-tap chunks of its K loop) instead of a
         # separate read-modify-write pass over the gradient map: fused_gram[conv step] = (style step, bank of D, 1 / scale).
@@ -367,7 +381,11 @@ class StyleEngine:
         for s in self.steps:
             if s.kind == "conv":
                 fl, nb = self._conv_work(s, a[s.src].shape, a[s.dst].shape, False)
-                if self.x6_fwd and self._x6_ok(s, s.mod.out_channels):
+                if id(s) in self.fused_pool:
+                    ps = self.fused_pool[id(s)]
+                    self._timed("conv3x3_split_fwd", fl, nb, lambda: models_mod.conv3x3_relu_pool(
+                        a[s.src], s.mod, a[ps.dst], self.pool_codes[id(ps)]))
+                elif self.x6_fwd and self._x6_ok(s, s.mod.out_channels):
                     self._timed("conv3x3_split_fwd", fl, nb, lambda: models_mod.conv3x3_mfma(
                         a[s.src], s.mod, False, out=a[s.dst], relu=s.relu, workspace=self.ws))
                 elif self.x6_fwd and models_mod.conv1x1_is_mfma(s.mod, False):
@@ -383,7 +401,9 @@ class StyleEngine:
             elif s.kind == "relu":
                 hip.relu_(a[s.src])
             elif s.kind == "pool":
-                if id(s) in self.pool_codes:
+                if id(s) in self.pooled_by_conv:
+                    pass  # done in the epilogue of the convolution in front of it
+                elif id(s) in self.pool_codes:
                     hip.pool2x2_fwd_codes(a[s.src], a[s.dst], self.pool_codes[id(s)])
                 else:
                     hip.pool2d_fwd(a[s.src], s.k, s.stride, s.ceil, s.mode, out=a[s.dst])

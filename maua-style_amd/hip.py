@@ -73,6 +73,8 @@ SIGNATURES = {
     "maua_deprocess_u8": (c_i, [c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_p]),
     "maua_set_split_batch_hint": (None, [c_i]),
     "maua_get_split_batch_hint": (c_i, []),
+    "maua_conv_x3w_split": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    "maua_conv3x3_x3w_relu_pool": (c_i, [c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "maua_conv_x3w_dmat_bank_bytes": (c_sz, [c_i]),
     "maua_conv_pack_dmat_x3w": (c_i, [c_p, c_i, c_p, c_p, c_p]),
     "maua_conv3x3_x3w_gram": (c_i, [c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
@@ -284,6 +286,19 @@ def conv3x3_x3w(x, bank, w_scale, bias, cout, pad, relu, out=None, out_relu_mask
     _check(lib().maua_conv3x3_x3w(_ptr(_f32(x, "x")), bank.data_ptr(), float(w_scale), _ptr(bias), _ptr(out_relu_mask), _ptr(out), n,
                                   cin, h, w, cout, pad, int(relu), int(accumulate), wp, wn, _stream()), "maua_conv3x3_x3w")
     return out
+
+
+def conv_x3w_split(n, cin, h, w, cout, pad):
+    """Channel-loop splits conv3x3_x3w would use for this geometry under the current batch hint (1 = one pass)."""
+    return int(lib().maua_conv_x3w_split(int(n), int(cin), int(h), int(w), int(cout), int(pad)))
+
+
+def conv3x3_x3w_relu_pool(x, bank, w_scale, bias, cout, pad, pooled, codes):
+    """conv + bias + ReLU + 2x2 / 2 max pool in one launch: writes `pooled` and the pool's decision bytes only."""
+    n, cin, h, w = x.shape
+    _check(lib().maua_conv3x3_x3w_relu_pool(_ptr(_f32(x, "x")), bank.data_ptr(), float(w_scale), _ptr(bias), _ptr(pooled),
+                                            codes.data_ptr(), n, cin, h, w, cout, pad, _stream()), "maua_conv3x3_x3w_relu_pool")
+    return pooled
 
 
 def conv_x3w_dmat_bank(c, device, frames=1):

@@ -91,6 +91,18 @@ def conv3x3_mfma(x, mod, backward, out=None, out_relu_mask=None, relu=False, acc
                           accumulate=accumulate, workspace=workspace)
 
 
+def conv3x3_fwd_is_x3w(mod, h, w):
+    """Whether the forward pass of a 3x3 layer on an h x w input plane runs on conv_x3w.hip."""
+    return _x3_enabled() and _x3w_enabled() and h * w >= _x3w_min_pixels() and mod.kernel_size[0] == 3 and mod.stride[0] == 1 and \
+        hip.conv_x3w_supported(mod.in_channels, h, w, mod.padding[0])
+
+
+def conv3x3_relu_pool(x, mod, pooled, codes):
+    """conv + bias + ReLU + the 2x2 / 2 max pool behind it in one launch (hip.conv3x3_x3w_relu_pool)."""
+    bf, _, wsc = mod.banks3w()
+    return hip.conv3x3_x3w_relu_pool(x, bf, wsc, mod.bias_device(), mod.out_channels, mod.padding[0], pooled, codes)
+
+
 def conv3x3_bwd_is_x3w(mod, h, w):
     """Whether the backward-data pass of a 3x3 layer on an h x w plane runs on conv_x3w.hip (the kernel that can take the Gram
     backward of a style loss along, hip.conv3x3_x3w_gram)."""

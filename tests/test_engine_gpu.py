@@ -694,3 +694,23 @@ def test_gram_backward_fused_into_the_convolution_equals_the_separate_pass(weigh
     for k in ("128", "512"):
         assert torch.equal(res[k][0], res["0"][0]) and res[k][1] == res["0"][1]
         assert rel_l2(res[k][2], res["0"][2].double()) <= 2e-6
+
+
+def test_pool_in_the_convolution_epilogue_changes_no_bit(weight_files, monkeypatch):
+    """Where a conv + ReLU feeds nothing but a 2x2 max pool and runs in one pass over its channels, the pool happens in the
+    convolution's epilogue and the full-size activation is never written: same losses, same gradient, bit for bit."""
+    import engine
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MAUA_FUSE_POOL", flag)
+        monkeypatch.setenv("MAUA_DEBUG_POISON", "1")
+        args = product_args(weight_files, S=512)
+        content, style, init = synth.images(512)
+        net, losses = build(args, content, [style], 512)
+        eng = engine.StyleEngine(net, losses)
+        slots, total, grad = eng.feval(init.cuda())
+        torch.cuda.synchronize()
+        res[flag] = (slots.clone().cpu(), grad.clone().cpu(), len(eng.fused_pool))
+    assert res["0"][2] == 0 and res["1"][2] >= 2, (res["0"][2], res["1"][2])
+    assert torch.isfinite(res["1"][1]).all()
+    assert torch.equal(res["0"][0], res["1"][0]) and torch.equal(res["0"][1], res["1"][1])

@@ -1024,3 +1024,25 @@ def test_backward_pass_with_the_gram_backward_along(hip, cin, c, H, W):
     assert torch.equal(fused, again)
     # the bank's scale: max |D| lands in [32, 64)
     assert 32.0 <= float(d.abs().max()) / float(dinv[0]) < 64.0
+
+
+@pytest.mark.parametrize("n,cin,cout,H,W", [(1, 64, 64, 64, 96), (2, 128, 128, 40, 72), (1, 64, 128, 34, 62), (1, 16, 200, 18, 260)])
+def test_conv_relu_pool_in_one_launch_equals_the_three_steps(hip, n, cin, cout, H, W):
+    """maua_conv3x3_x3w_relu_pool against maua_conv3x3_x3w (+ ReLU) followed by maua_pool2x2_fwd_codes: the same pooled map
+    and the same decision bytes, bit for bit (zero windows, ties and all), and the backward routing from those bytes."""
+    x = torch.relu(rnd(n, cin, H, W, seed=81))
+    x[:, :, :4, :4] = 0.0                                  # windows that are zero after ReLU whatever the filters
+    w = rnd(cout, cin, 3, 3, seed=82) * (2.0 / (9 * cin)) ** 0.5
+    b = rnd(cout, seed=83) * 0.1
+    b[:4] = -100.0                                         # whole channels at zero: every window a four-way tie
+    bf, _, wsc = hip.conv_pack_filters_x3w(dev(w))
+    one_pass = torch.empty(16, dtype=torch.uint8, device="cuda")  # no room for split-K slabs: one pass over the channels
+    y = hip.conv3x3_x3w(dev(x), bf, wsc, dev(b), cout, 1, True, workspace=one_pass)
+    p0 = torch.empty(n, cout, H // 2, W // 2, device="cuda")
+    c0 = torch.empty(n, cout, H // 2, W // 2, dtype=torch.uint8, device="cuda")
+    hip.pool2x2_fwd_codes(y, p0, c0)
+    p1, c1 = torch.full_like(p0, float("nan")), torch.full_like(c0, 255)
+    hip.conv3x3_x3w_relu_pool(dev(x), bf, wsc, dev(b), cout, 1, p1, c1)
+    torch.cuda.synchronize()
+    assert torch.equal(p0, p1) and torch.equal(c0, c1)
+    assert int((c1[:, :4] == 4).all()) == 1              # zero channels: first position, "not positive"

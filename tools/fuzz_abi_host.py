@@ -55,6 +55,8 @@ def main():
             assert sizes[6] == 0 and sizes[7] == 0 and sizes[8] == 0, (cin, cout, sizes)
         L.maua_pool_out_size(h, rng.choice([2, 3, 0, -1]), rng.choice([2, 1, 0]), rng.randint(0, 1))
         L.maua_conv_x3w_supported(cin, h, w, pad)
+        assert L.maua_conv_x3w_split(n, cin, h, w, cout, pad) >= 0 and L.maua_conv_x3w_dmat_bank_bytes(cin) >= 0
+        L.maua_conv_pack_dmat_x3w(None, cin, None, None, None)
         # compute entry points: null pointers and bad dims must be refused with a negative code before any launch; good
         # arguments reach the launch (a HIP error on this GPU-less box, or 0 on a GPU box where P would fault - so only
         # argument sets that fail validation use P there)
@@ -63,6 +65,8 @@ def main():
         ptr = P if no_gpu else None
         rcs = [
             L.maua_conv3x3_x3w(ptr, ptr, 1.0, ptr, None, ptr, n, cin, h, w, cout, pad, 1, 0, ptr, ws_bytes, None),
+            L.maua_conv3x3_x3w_relu_pool(ptr, ptr, 1.0, ptr, ptr, ptr, n, cin, h, w, cout, pad, None),
+            L.maua_conv3x3_x3w_gram(ptr, ptr, 1.0, ptr, ptr, ptr, ptr, n, cin, h, w, cout, pad, 0, ptr, ws_bytes, None),
             L.maua_conv3x3_x3(ptr, ptr, 1.0, ptr, None, ptr, n, cin, h, w, cout, pad, 1, 0, ptr, ws_bytes, None),
             L.maua_conv3x3_x6(ptr, ptr, ptr, None, ptr, n, cin, h, w, cout, pad, 1, 0, ptr, ws_bytes, None),
             L.maua_conv2d_fwd(ptr, None, ptr, ptr, ptr, n, cin, h, w, cout, k, k, stride, pad, 1, 0, ptr, ws_bytes, None),
@@ -87,7 +91,7 @@ def main():
             L.maua_lbfgs_iterate(ptr, ptr, ptr, None, h * w, rng.choice([1, 100, 254, 255]), 1.0, -1.0, -1.0, None),
         ]
         if min(n, cin, cout, h, w) <= 0:  # (the 1x1 entry takes the product h * w, which two negative extents make positive)
-            assert all(rc < 0 for rc in rcs[:6]), (n, cin, cout, h, w, rcs)
+            assert all(rc < 0 for rc in rcs[:8]), (n, cin, cout, h, w, rcs)
         checked += len(rcs) + len(sizes)
     L.maua_set_split_batch_hint(1)
     print(f"fuzz_abi_host: {n_cases} cases, {checked} calls, no sanitizer report, return codes consistent")
