@@ -1046,3 +1046,12 @@ def test_conv_relu_pool_in_one_launch_equals_the_three_steps(hip, n, cin, cout, 
     torch.cuda.synchronize()
     assert torch.equal(p0, p1) and torch.equal(c0, c1)
     assert int((c1[:, :4] == 4).all()) == 1              # zero channels: first position, "not positive"
+
+
+def test_fused_launches_give_the_same_bits_every_time():
+    """tools/stress_fused.py: the fused convolution launches (Gram backward in the K loop, ReLU + pool in the epilogue) repeated
+    while a GEMM on another stream keeps the chip busy, and two L-BFGS states fed the same gradients: not one differing bit."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "stress_fused.py"), "40"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "TOTAL MISMATCHES 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
