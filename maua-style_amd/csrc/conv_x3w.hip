@@ -87,14 +87,18 @@ __global__ void pack_x3w_kernel(const float* __restrict__ w, unsigned short* __r
 
 // The symmetric C x C matrix D of a style loss (grad_scale (G - T)) as ONE-tap filter bank for the fused Gram-backward term of
 // conv_x3w_kernel: bank[chunk16][cotile][part][octet][co][ch] = D[co][ch] scaled by a power of two that brings max |D| into
-// [32, 64) like the 3x3 banks; inv[0] = 1 / scale.  One workgroup: maximum first, then the split (C <= 512: 262 k values).
+// [32, 64) like the 3x3 banks; inv[0] = 1 / scale.  Every workgroup finds the maximum itself (C <= 512: 1 MB out of L2), then
+// packs its share: a thread takes the 8 consecutive values of one (chunk, tile, octet, co) and writes their two 16-byte halves.
 __global__ void __launch_bounds__(1024) pack_dmat_x3w_kernel(const float* __restrict__ d, int C, unsigned short* __restrict__ bank,
                                                              float* __restrict__ inv) {
     __shared__ float wmax[16];
     const int tid = threadIdx.x;
-    const int64_t total = (int64_t)C * C;
+    const int64_t total4 = (int64_t)C * C / 4;  // (C % 16 == 0)
     float m = 0.f;
-    for (int64_t e = tid; e < total; e += 1024) m = fmaxf(m, fabsf(d[e]));
+    for (int64_t e = tid; e < total4; e += 1024) {
+        const float4 v = reinterpret_cast<const float4*>(d)[e];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
     m = wave_max_nonneg(m);
     if ((tid & 63) == 0) wmax[tid >> 6] = m;
     __syncthreads();
@@ -105,26 +109,33 @@ __global__ void __launch_bounds__(1024) pack_dmat_x3w_kernel(const float* __rest
         const int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu) - 127;
         scale = __builtin_bit_cast(float, (unsigned)(127 + 5 - max(e, -100)) << 23);
     }
-    if (tid == 0) inv[0] = 1.f / scale;
+    if (tid == 0 && blockIdx.x == 0) inv[0] = 1.f / scale;
     const int nchunk = C / 16, ntile = (C + XW_COT - 1) / XW_COT;
-    const int64_t elems = (int64_t)nchunk * ntile * 2 * XW_COT * 8;  // (chunk, tile, octet, co, ch): both parts per element
-    for (int64_t e = tid; e < elems; e += 1024) {
+    const int64_t groups = (int64_t)nchunk * ntile * 2 * XW_COT;  // (chunk, tile, octet, co)
+    for (int64_t e = (int64_t)blockIdx.x * 1024 + tid; e < groups; e += (int64_t)gridDim.x * 1024) {
         int64_t r = e;
-        const int ch = (int)(r % 8);
-        r /= 8;
         const int co = (int)(r % XW_COT);
         r /= XW_COT;
         const int oct = (int)(r % 2);
         r /= 2;
         const int tile = (int)(r % ntile);
         const int chunk = (int)(r / ntile);
-        const int o = tile * XW_COT + co, i = chunk * 16 + oct * 8 + ch;
-        float v = o < C ? d[(int64_t)o * C + i] * scale : 0.f;
-        const _Float16 h = (_Float16)v;
-        const _Float16 l = (_Float16)(v - (float)h);
-        const int64_t base = ((int64_t)chunk * ntile + tile) * (4 * XW_COT * 8);  // [part][octet][co][ch]
-        bank[base + ((int64_t)(0 * 2 + oct) * XW_COT + co) * 8 + ch] = __builtin_bit_cast(unsigned short, h);
-        bank[base + ((int64_t)(1 * 2 + oct) * XW_COT + co) * 8 + ch] = __builtin_bit_cast(unsigned short, l);
+        const int o = tile * XW_COT + co, i = chunk * 16 + oct * 8;
+        u32x4 Hh = {0u, 0u, 0u, 0u}, Ll = {0u, 0u, 0u, 0u};
+        if (o < C) {
+            const float4 v0 = *reinterpret_cast<const float4*>(d + (int64_t)o * C + i);
+            const float4 v1 = *reinterpret_cast<const float4*>(d + (int64_t)o * C + i + 4);
+            const float v[8] = {v0.x * scale, v0.y * scale, v0.z * scale, v0.w * scale, v1.x * scale, v1.y * scale, v1.z * scale, v1.w * scale};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned H = xw_cvt_pk_f16(v[2 * q], v[2 * q + 1]);
+                Hh[q] = H;
+                Ll[q] = xw_cvt_pk_f16(v[2 * q] - xw_f16_lo(H), v[2 * q + 1] - xw_f16_hi(H));
+            }
+        }
+        unsigned char* base = reinterpret_cast<unsigned char*>(bank) + ((int64_t)chunk * ntile + tile) * 4096 + co * 16;  // [part][octet][co][16 B]
+        *reinterpret_cast<u32x4*>(base + (0 * 2 + oct) * 1024) = Hh;
+        *reinterpret_cast<u32x4*>(base + (1 * 2 + oct) * 1024) = Ll;
     }
 }
 
@@ -201,37 +212,6 @@ __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_in
             for (int k = 0; k < 3; ++k)
                 rp[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[k], c * in_plane * 4, 0));
     };
-    // F chunks need the tile's own 8 x 32 positions only: item k = (octet k, position tid), two per thread and chunk
-    unsigned voff_f[2], lds_f[2];
-    {
-        const int r = tid >> 5, c = tid & 31;
-        const bool ok = y0 + r < p.H && x0 + c < p.W;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            voff_f[k] = ok ? (unsigned)(k * 8 * in_plane + (y0 + r) * p.W + x0 + c) * 4u : 0x80000000u;
-            lds_f[k] = (unsigned)(k * XW_PLANE + ((r + p.pad) * XW_PC + c + p.pad) * 16);
-        }
-    }
-    float (&ra)[2][8] = reinterpret_cast<float (&)[2][8]>(rp);  // buffer A shares the registers of the 3x3 staging
-    float rb[2][8];
-    auto load_f = [&](float (&r)[2][8], int c2) {
-        asm volatile("" : "+s"(c2));
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fin + (int64_t)c2 * 16 * in_plane), 0, range, 0x00020000);
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-                r[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff_f[k], c * in_plane * 4, 0));
-    };
-    auto publish_max_f = [&](float (&r)[2][8]) {
-        float m = 0.f;
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int c = 0; c < 8; ++c) m = fmaxf(m, fabsf(r[k][c]));
-        m = wave_max_nonneg(m);
-        if (lane == 0) Ml[wave] = m;
-    };
     auto publish_max = [&]() {
         float m = 0.f;
 #pragma unroll
@@ -270,22 +250,6 @@ __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_in
         }
     };
 
-    auto split_store_f = [&](float (&r)[2][8]) {  // uses the scale `sx` chunk_scale() has just set
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            u32x4 Hh, Ll;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float v0 = r[k][2 * q] * sx, v1 = r[k][2 * q + 1] * sx;
-                const unsigned H = xw_cvt_pk_f16(v0, v1);
-                Hh[q] = H;
-                Ll[q] = xw_cvt_pk_f16(v0 - xw_f16_lo(H), v1 - xw_f16_hi(H));
-            }
-            *reinterpret_cast<u32x4*>(Pl + lds_f[k]) = Hh;
-            *reinterpret_cast<u32x4*>(Pl + 2 * XW_PLANE + lds_f[k]) = Ll;
-        }
-    };
-
     const unsigned char* __restrict__ bank = reinterpret_cast<const unsigned char*>(p.w6);
     // Filter slice of a chunk = 36 planes of 1 KiB in LDS order; wave w streams planes w, w + 4, ... (9 LDS-DMA instructions)
     const int wv = __builtin_amdgcn_readfirstlane(wave);
@@ -306,17 +270,7 @@ __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_in
         }
     };
 
-    // the four planes [part][octet] of D chunk c2 go where the centre tap's planes live (one per wave)
     const unsigned char* __restrict__ dbank = reinterpret_cast<const unsigned char*>(p.dbank);
-    auto dma_d = [&](int c2) {
-        const unsigned char* g = dbank + (((int64_t)n * n2 + c2) * ntile + cotile) * 4096 + wv * 1024;  // image n's own bank
-        const unsigned lds_dst = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(Wl + (16 + wv) * 1024);
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(lane16), "s"(__builtin_amdgcn_readfirstlane(lds_dst)), "s"(g)
-                     : "memory");
-    };
     const float d_inv_scale = p.dbank ? p.dinv[n] : 0.f;
 
     // fragment byte offsets of this lane: patch (row 2 wave + row + ky, col j + kx, octet = lane half), filters (co = j)
@@ -437,7 +391,6 @@ __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_in
         load_b(bx, 0);
         load_a(a0, 0, 0);
         if (more) load_patch(ch + 1);
-        else if (d_begin < nchunks) load_f(ra, d_begin - nmain);  // the first chunk of F rides on the last chunk's products
         XW_FENCE();
         XW_TAP(0, bx, by, true, (void)0, (void)0);
         XW_TAP(1, by, bx, true, (void)0, (void)0);
@@ -484,30 +437,71 @@ __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_in
         }
     }
 
-    // Fused Gram backward: chunks of F against the centre-tap planes of D - one tap (12 MFMAs) per chunk, so a chunk costs
-    // what its staging costs and the loads are what to hide: two register buffers, the loads of chunk c + 2 leave when chunk
-    // c has been split (the first chunk was requested during the last 3x3 chunk).  Two barriers per chunk.
-    if (d_begin < nchunks) {
-        auto d_chunk = [&](float (&r)[2][8], int ch, bool refill) {
-            publish_max_f(r);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();  // the previous chunk's fragments are read; the maxima of this one are visible
-            dma_d(ch - nmain);
-            const float inv = chunk_scale() * d_inv_scale;
-            split_store_f(r);
-            if (refill) {
-                load_f(r, ch + 2 - nmain);
-                asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");  // (the planes of D are older than the 16 new loads)
-            } else {
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // Fused Gram backward: the 16-channel chunks of F against the matching columns of D - one tap, 12 MFMAs per chunk and wave.
+    // Nothing here goes through LDS: a lane's MFMA operands are exactly what it can load itself - its pixel column of its two
+    // rows for 8 channels (B operand: 16 coalesced dword loads), its output channel's 8 values of D (A operand: one 16-byte
+    // load per part and channel half from the packed bank) - and the power-of-two scale is per WAVE (its own maximum, its own
+    // accumulators).  No barrier, no cross-wave exchange: the waves drift apart and hide each other's load latency, the loads
+    // of chunk c + 1 are in flight while chunk c is multiplied.
+    if constexpr (!POOL) if (d_begin < nchunks) {
+        __builtin_amdgcn_s_barrier();  // (every wave is done with the LDS fragments of the last 3x3 chunk - nothing below needs LDS,
+                                       //  but the stamps / a later reader of this code should not have to wonder)
+        unsigned voff_f[2];
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+            const int oy = y0 + 2 * wave + row, oxx = x0 + j;
+            voff_f[row] = (oy < p.H && oxx < p.W) ? (unsigned)(half * 8 * in_plane + oy * p.W + oxx) * 4u : 0x80000000u;
+        }
+        struct DChunk {
+            float f[2][8];   // [row][channel of this lane's octet]
+            u32x4 a[2][2];   // [part][32-channel half of the tile]: 8 fp16 of D[co][c0 + 8 half ..]
+        };
+        auto request = [&](DChunk& d, int c2) {
+            asm volatile("" : "+s"(c2));
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fin + (int64_t)c2 * 16 * in_plane), 0, range, 0x00020000);
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int row = 0; row < 2; ++row)
+                    d.f[row][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff_f[row], c * in_plane * 4, 0));
+            const unsigned char* g = dbank + (((int64_t)n * n2 + c2) * ntile + cotile) * 4096 + half * 1024 + j * 16;
+#pragma unroll
+            for (int part = 0; part < 2; ++part)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) d.a[part][t] = *reinterpret_cast<const u32x4*>(g + part * 2048 + t * 512);
+        };
+        auto multiply = [&](DChunk& d) {
+            float m = 0.f;
+#pragma unroll
+            for (int row = 0; row < 2; ++row)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) m = fmaxf(m, fabsf(d.f[row][c]));
+            m = wave_max_nonneg(m);
+            int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu) - 127;
+            e = m > 0.f ? max(e, -100) : 11;
+            const float s = __builtin_bit_cast(float, (unsigned)(127 + 11 - e) << 23);
+            const float inv = __builtin_bit_cast(float, (unsigned)(127 + e - 11) << 23) * d_inv_scale;
+            BFrag b;
+#pragma unroll
+            for (int row = 0; row < 2; ++row) {
+                u32x4 Hh, Ll;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v0 = d.f[row][2 * q] * s, v1 = d.f[row][2 * q + 1] * s;
+                    const unsigned H = xw_cvt_pk_f16(v0, v1);
+                    Hh[q] = H;
+                    Ll[q] = xw_cvt_pk_f16(v0 - xw_f16_lo(H), v1 - xw_f16_hi(H));
+                }
+                b[row][0] = __builtin_bit_cast(f16x8, Hh);
+                b[row][1] = __builtin_bit_cast(f16x8, Ll);
             }
-            __builtin_amdgcn_s_barrier();
-            load_b(bx, 4);
-            load_a(a0, 4, 0);
-            load_a(a1, 4, 1);
-            XW_FENCE();
-            mfma_half(a0, bx, 0);
-            mfma_half(a1, bx, 1);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                AFrag a;
+                a[0] = __builtin_bit_cast(f16x8, d.a[0][t]);
+                a[1] = __builtin_bit_cast(f16x8, d.a[1][t]);
+                mfma_half(a, b, t);
+            }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -518,11 +512,15 @@ __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_in
                         acc[t][row][q] = 0.f;
                     }
         };
-        if (ch_begin >= nmain) load_f(ra, d_begin - nmain);  // (a split that starts inside F: nothing was requested yet)
-        if (d_begin + 1 < nchunks) load_f(rb, d_begin + 1 - nmain);
+        DChunk da, db;
+        request(da, d_begin - nmain);
         for (int ch = d_begin; ch < nchunks; ch += 2) {
-            d_chunk(ra, ch, ch + 2 < nchunks);
-            if (ch + 1 < nchunks) d_chunk(rb, ch + 1, ch + 3 < nchunks);
+            if (ch + 1 < nchunks) request(db, ch + 1 - nmain);
+            multiply(da);
+            if (ch + 1 < nchunks) {
+                if (ch + 2 < nchunks) request(da, ch + 2 - nmain);
+                multiply(db);
+            }
         }
     }
 
@@ -730,8 +728,9 @@ size_t maua_conv_x3w_dmat_bank_bytes(int c) {
 int maua_conv_pack_dmat_x3w(const float* dmat, int c, void* bank, float* inv_scale_out, maua_stream_t stream) {
     MAUA_REQUIRE(dmat && bank && inv_scale_out && c > 0 && c % 16 == 0 && c <= (1 << 14), MAUA_E_INVAL,
                  "conv_pack_dmat_x3w: needs a C x C matrix with C %% 16 == 0");
-    hipLaunchKernelGGL(pack_dmat_x3w_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dmat, c, (unsigned short*)bank,
-                       inv_scale_out);
+    const int64_t groups = (int64_t)(c / 16) * ((c + XW_COT - 1) / XW_COT) * 2 * XW_COT;
+    hipLaunchKernelGGL(pack_dmat_x3w_kernel, dim3((unsigned)((groups + 4095) / 4096)), dim3(1024), 0, (hipStream_t)stream, dmat, c,
+                       (unsigned short*)bank, inv_scale_out);
     return check_launch("pack_dmat_x3w_kernel");
 }
 

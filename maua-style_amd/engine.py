@@ -183,7 +183,7 @@ class StyleEngine:
         # on conv_x3w.hip, that pass takes the Gram backward along (D . F as extra one-tap chunks of its K loop) instead of a
         # separate read-modify-write pass over the gradient map: fused_gram[conv step] = (style step, bank of D, 1 / scale).
         self.fused_gram = {}
-        max_c = int(os.environ.get("MAUA_FUSE_GRAM_MAX_C", "128"))  # pays on the shallow, bandwidth-bound layers
+        max_c = int(os.environ.get("MAUA_FUSE_GRAM_MAX_C", "256"))  # pays on the shallow, bandwidth-bound layers (relu4_1: break-even)
         if (B == 1 or self.independent) and self.x6_bwd and max_c > 0:
             relu_out = {s.dst for s in self.steps if s.kind == "conv" and s.relu}
             for s in self.steps:

@@ -681,7 +681,7 @@ def test_gram_backward_fused_into_the_convolution_equals_the_separate_pass(weigh
     close to the fp64 oracle."""
     import engine
     res = {}
-    for max_c in ("0", "128", "512"):
+    for max_c in ("0", "64", "512"):
         monkeypatch.setenv("MAUA_FUSE_GRAM_MAX_C", max_c)
         args = product_args(weight_files, S=128)
         content, style, init = synth.images(128)
@@ -690,8 +690,8 @@ def test_gram_backward_fused_into_the_convolution_equals_the_separate_pass(weigh
         slots, total, grad = eng.feval(init.cuda())
         torch.cuda.synchronize()
         res[max_c] = (slots.clone().cpu(), float(total), grad.clone().cpu(), len(eng.fused_gram))
-    assert res["0"][3] == 0 and res["128"][3] == 2 and res["512"][3] >= 2
-    for k in ("128", "512"):
+    assert res["0"][3] == 0 and res["64"][3] == 1 and res["512"][3] >= 2
+    for k in ("64", "512"):
         assert torch.equal(res[k][0], res["0"][0]) and res[k][1] == res["0"][1]
         assert rel_l2(res[k][2], res["0"][2].double()) <= 2e-6
 
