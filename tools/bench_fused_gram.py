@@ -42,5 +42,7 @@ for name, c, div in (("relu1_1 / conv1_2", 64, 1), ("relu2_1 / conv2_2", 128, 2)
     t_gram = timed(lambda: hip.gram_bwd(d, f, None, out, True, workspace=ws, relu_mask=f))
     t_fused = timed(lambda: hip.conv3x3_x3w_gram(gy, bb, wsc, f, dbank, dinv, c, 1, out=out, workspace=ws))
     t_pack = timed(lambda: hip.conv_pack_dmat_x3w(d, dbank, dinv))
+    t_mask = timed(lambda: hip.conv3x3_x3w(gy, bb, wsc, None, c, 1, False, out=out, out_relu_mask=f, workspace=ws))
     print(f"{name} C = {c:3d} @ {H:4d}: conv {t_conv:6.1f} us + Gram backward {t_gram:6.1f} us = {t_conv + t_gram:6.1f} | fused {t_fused:6.1f} us "
-          f"(+ pack {t_pack:4.1f} us) | saves {t_conv + t_gram - t_fused - t_pack:6.1f} us")
+          f"(+ pack {t_pack:4.1f} us) | saves {t_conv + t_gram - t_fused - t_pack:6.1f} us | conv with the mask in its epilogue {t_mask:6.1f} us: "
+          f"the chunks of F cost {t_fused - t_mask:5.1f} us")
