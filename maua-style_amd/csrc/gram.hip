@@ -236,9 +236,6 @@ gram_x3_partial_kernel(const float* __restrict__ f, const float* __restrict__ me
             mrow[t][r] = (mean && row < C) ? mean[row] : 0.f;
         }
     auto load_stage = [&](int slot, int64_t p0) {
-#if defined(GX_ABL) && GX_ABL == 3
-        return;  // ablation: no global loads
-#endif
         if (slot == 0) {
             load_unit(ra[0], ti, p0);
             if (!diag) load_unit(rb[0], tj, p0);
@@ -279,10 +276,6 @@ gram_x3_partial_kernel(const float* __restrict__ f, const float* __restrict__ me
         }
     };
     auto store_stage = [&](int slot, int64_t p0, unsigned char* buf) {
-#if defined(GX_ABL) && GX_ABL == 2
-        asm volatile("" ::"v"(ra[0][0][0]), "v"(ra[1][0][0]));  // ablation: loads stay live, no split, no LDS writes
-        return;
-#endif
         if (slot == 0) {
             store_unit(ra[0], 0, p0, buf);
             if (!diag) store_unit(rb[0], 1, p0, buf);
@@ -295,11 +288,7 @@ gram_x3_partial_kernel(const float* __restrict__ f, const float* __restrict__ me
     f32x16 master, acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) master[r] = acc0[r] = acc1[r] = 0.f;
-#if defined(GX_ABL) && GX_ABL == 1
-    const bool skip = true;  // ablation: no LDS fragment reads, no MFMAs
-#else
     const bool skip = diag && wi == 1 && wj == 0;  // wave-uniform: the mirrored block of a diagonal tile
-#endif
     const int bslot = diag ? 0 : 1;                 // the column operand comes from tile tj's planes
     const int a_off = (wi * 32 + i32) * GXROW + half * 16;
     const int b_off = (bslot * 2) * GXPLANE + (wj * 32 + i32) * GXROW + half * 16;
