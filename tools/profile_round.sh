@@ -3,7 +3,10 @@ R=$PWD; O=$R/gpurun_out/r2fin; mkdir -p $O
 python bench.py --steps 200 > $O/bench_graph.json 2> $O/bench_graph.err
 python bench.py --steps 100 --no_hip_graph --no_cpu_baseline --no_extra_sizes > $O/bench_eager.json 2>/dev/null
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- python3 $R/bench.py --steps 20 --warmup 2 --no_cpu_baseline --no_extra_sizes --no_hip_graph > $O/bench_under_rocprof.json 2>/dev/null
+# kernel durations in stream order (what bench.py's per-launch events measure); the default overlaps the Gram chains with the convolutions
+MAUA_STYLE_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- python3 $R/bench.py --steps 20 --warmup 2 --no_cpu_baseline --no_extra_sizes --no_hip_graph > $O/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_overlap -o p -- python3 $R/bench.py --steps 20 --warmup 2 --no_cpu_baseline --no_extra_sizes --no_hip_graph > $O/bench_under_rocprof_overlap.json 2>/dev/null
+rm -f $O/stats/*kernel_trace.csv $O/stats_overlap/*kernel_trace.csv
 B="python3 $R/bench.py --steps 4 --warmup 1 --no_prefill --no_cpu_baseline --no_hip_graph --no_extra_sizes"
 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d $O/pmc_a -o p -- $B > /dev/null 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/pmc_b -o p -- $B > /dev/null 2>&1
@@ -18,4 +21,7 @@ python tools/run_configs.py --configs 2,3,4,5,6 --out gpurun_out/r2fin/configs.j
 python tools/x3w_clock.py 512 512 128 > $O/clock_conv4_2.txt 2>&1
 python tools/x3w_clock.py 64 64 1024 > $O/clock_conv1_2.txt 2>&1
 python tools/bench_x3w.py 1024 5 10 > $O/x3_vs_x3w.txt 2>&1
+python tools/lbfgs_clock.py 196608 100 > $O/clock_lbfgs.txt 2>&1
+python tools/bench_fused_gram.py 1024 20 > $O/fused_gram.txt 2>&1
+python tools/stress_fused.py 100 > $O/stress_fused.txt 2>&1
 ls -la $O; tail -c 600 $O/bench_graph.json
