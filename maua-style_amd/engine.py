@@ -179,6 +179,9 @@ class StyleEngine:
                         hip.conv_x3w_split(B, shapes[s.src][1], shapes[s.src][2], shapes[s.src][3], s.mod.out_channels, s.pad) == 1:
                     self.fused_pool[id(s)] = users[0]
         self.pooled_by_conv = {id(v) for v in self.fused_pool.values()}
+        for s in self.steps:  # (those activations exist as shapes only: 0.5 GB less at 1024x1024)
+            if id(s) in self.fused_pool:
+                self.act[s.dst] = torch.empty(shapes[s.dst], device="meta")
         # Single images: where a style loss is the only loss on the input activation of a 3x3 layer whose backward-data pass runs
         # on conv_x3w.hip, that pass takes the Gram backward along (D . F as extra one-tap chunks of its K loop) instead of a
         # separate read-modify-write pass over the gradient map: fused_gram[conv step] = (style step, bank of D, 1 / scale).
@@ -237,7 +240,7 @@ class StyleEngine:
         if os.environ.get("MAUA_DEBUG_POISON") == "1":  # tests: every buffer starts as NaN, so a read-before-write shows up
             for t in list(self.act.values()) + list(self.gbuf.values()) + list(self.gram.values()) + list(self.dmat.values()) + \
                     list(self.gram_d.values()) + list(self.dmat_d.values()):
-                if t is not None:
+                if t is not None and not t.is_meta:
                     t.fill_(float("nan"))
             self.ws.view(torch.float32)[:] = float("nan") if self.ws.numel() % 4 == 0 else 0
         # Independent frames: the per-frame kernels (Gram, losses, Gram backward, optimiser) of different frames share
@@ -664,7 +667,10 @@ class StyleEngine:
         last = max((self.steps.index(s) for s in want), default=-1)
         for s in self.steps[:last + 1]:
             if s.kind == "conv":
-                if self.x6_fwd and self._x6_ok(s, s.mod.out_channels):
+                if id(s) in self.fused_pool:
+                    ps = self.fused_pool[id(s)]
+                    models_mod.conv3x3_relu_pool(a[s.src], s.mod, a[ps.dst], self.pool_codes[id(ps)])
+                elif self.x6_fwd and self._x6_ok(s, s.mod.out_channels):
                     models_mod.conv3x3_mfma(a[s.src], s.mod, False, out=a[s.dst], relu=s.relu, workspace=self.ws)
                 elif self.x6_fwd and models_mod.conv1x1_is_mfma(s.mod, False):
                     models_mod.conv1x1_mfma(a[s.src], s.mod, False, out=a[s.dst], relu=s.relu, workspace=self.ws)
@@ -677,7 +683,8 @@ class StyleEngine:
             elif s.kind == "relu":
                 hip.relu_(a[s.src])
             elif s.kind == "pool":
-                hip.pool2d_fwd(a[s.src], s.k, s.stride, s.ceil, s.mode, out=a[s.dst])
+                if id(s) not in self.pooled_by_conv:
+                    hip.pool2d_fwd(a[s.src], s.k, s.stride, s.ceil, s.mode, out=a[s.dst])
         for s in want:
             s.mod.target = a[s.src].detach().clone()
 
@@ -725,6 +732,6 @@ class StyleEngine:
         tot = 0
         for d in (self.act, self.gbuf):
             for t in d.values():
-                if t is not None:
+                if t is not None and not t.is_meta:
                     tot += t.numel() * 4
         return tot
