@@ -164,36 +164,116 @@ def _visible_gpus():
         return 0
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, allow_fewer=False):
     """`python bench.py --gpus N` outside torchrun: start N fresh rank processes (one per GPU) with torchrun's environment
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) and wait for them.  This parent never touches the GPU and
     never re-execs itself; rank 0's JSON line is relayed on stdout.  Fewer than N visible devices is an error unless
-    MAUA_DIST_BACKEND=gloo asks for several ranks per GPU (the 1-GPU test box)."""
+    `--allow_fewer` (run min(N, visible) ranks and say so in the line: `n_gpus` is what ran, `requested_gpus` what was asked)
+    or MAUA_DIST_BACKEND=gloo (several ranks per GPU, the 1-GPU test box).  All children are polled: when one exits non-zero
+    (a GPU fault, a failed rendezvous) the others are terminated and the launcher returns non-zero instead of waiting in a
+    collective."""
     import socket
     import subprocess
     have = _visible_gpus()
     if have < n and os.environ.get("MAUA_DIST_BACKEND") != "gloo":
-        sys.stderr.write(f"bench.py: --gpus {n} but only {have} device(s) visible (set MAUA_DIST_BACKEND=gloo to share GPUs)\n")
-        return 2
+        if allow_fewer and have >= 1:
+            sys.stderr.write(f"bench.py: --gpus {n} requested, {have} device(s) visible: running {have} rank(s) (--allow_fewer)\n")
+            argv = _with_flag_value(argv, "--gpus", str(have)) + ["--requested_gpus", str(n)]
+            n = have
+        else:
+            sys.stderr.write(f"bench.py: --gpus {n} but only {have} device(s) visible (--allow_fewer runs on what is there; "
+                             "MAUA_DIST_BACKEND=gloo shares GPUs between ranks)\n")
+            return 2
+    if n == 1:  # one rank: no process group needed, but still a fresh child (this parent must stay off the GPU)
+        return subprocess.call([sys.executable, os.path.abspath(__file__)] + argv + ["--_launched"])
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
     procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
                        "HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0 or "")
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, text=True))
+    rcs = [None] * n
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+        if any(rc not in (None, 0) for rc in rcs):
+            for r, p in enumerate(procs):  # a rank failed: the others would sit in rendezvous or a collective holding their GPUs
+                if rcs[r] is None:
+                    p.terminate()
+            deadline = time.time() + 20
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    try:
+                        rcs[r] = p.wait(timeout=max(0.1, deadline - time.time()))
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        rcs[r] = p.wait()
+            break
+        time.sleep(0.2)
+    out0.seek(0)
+    sys.stdout.write(out0.read())
     sys.stdout.flush()
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
-        sys.stderr.write(f"bench.py: ranks failed (rank, exit code): {bad}\n")
+        sys.stderr.write(f"bench.py: ranks failed or were stopped (rank, exit code): {bad}\n")
         return 1
     return 0
+
+
+def _with_flag_value(argv, flag, value):
+    """argv with `flag value` / `flag=value` replaced (appended when absent)."""
+    out, i, seen = [], 0, False
+    while i < len(argv):
+        if argv[i] == flag and i + 1 < len(argv):
+            out += [flag, value]
+            i += 2
+            seen = True
+        elif argv[i].startswith(flag + "="):
+            out.append(f"{flag}={value}")
+            i += 1
+            seen = True
+        else:
+            out.append(argv[i])
+            i += 1
+    return out if seen else out + [flag, value]
+
+
+def start_exact_split_child(argv_size, steps, warmup, history, optimizer):
+    """The same workload on the EXACT three-way bf16 split (MAUA_CONV_X3=0: bf16x6, 24-bit operands) in a fresh child process.
+    It is started here - before this process makes its first GPU call - and then waits on its stdin until the parent has
+    finished its own measurement (two jobs timing each other would measure neither)."""
+    import subprocess
+    env = dict(os.environ, MAUA_CONV_X3="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.Popen([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--size", str(argv_size), "--steps", str(steps),
+                             "--warmup", str(warmup), "--history", str(history), "--optimizer", optimizer, "--no_cpu_baseline",
+                             "--no_extra_sizes", "--no_exact_split", "--no_repeats", "--_wait_for_go"], env=env, stdin=subprocess.PIPE,
+                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+
+
+def finish_exact_split_child(proc):
+    try:
+        out, _ = proc.communicate("go\n", timeout=900)
+    except Exception as e:  # noqa: BLE001 - the headline must not die with its side figure
+        proc.kill()
+        return {"error": repr(e)}
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    if proc.returncode != 0 or not lines:
+        return {"error": f"child exit code {proc.returncode}"}
+    d = json.loads(lines[-1])
+    r = d.get("roofline") or {}
+    return {"env": "MAUA_CONV_X3=0", "dtype": d["dtype"], "iterations_per_s": d["value"], "ms_per_step": d["ms_per_step"],
+            "steps": d["steps"], "roofline_kernel": r.get("kernel"), "roofline_achieved_tflops": r.get("achieved"),
+            "roofline_peak_tflops": r.get("peak"), "roofline_frac": r.get("frac"),
+            "note": "same workload, same process layout, every 3x3 convolution on exact bf16x6 products (three bf16 parts per operand = 24 "
+                    "significand bits, six MFMAs per product block); measured in a fresh child process after the headline"}
 
 
 def steady_rate(size, steps, optimizer="lbfgs", history=100, warmup=5):
@@ -223,15 +303,44 @@ def steady_rate(size, steps, optimizer="lbfgs", history=100, warmup=5):
     opt = optim.PixelOptimizer(net, losses, init, args)
     for _ in range((history if optimizer == "lbfgs" else 0) + warmup):
         opt.step()
+    import dist as _dist
+    _dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         opt.step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    _dist.barrier()
     work = algorithmic_work(size, history)
-    return {"image_size": size, "optimizer": optimizer, "steps": steps, "iterations_per_s": round(steps / dt, 2),
-            "ms_per_step": round(dt / steps * 1e3, 4), "model_tflops": round(work["flops"] / (dt / steps) / 1e12, 2)}
+    import dist
+    world = dist.group_size()
+    dt_all = dist.max_over_ranks(dt)  # whole job: every rank ran `steps` iterations on its own image; the slowest rank's time
+    res = {"image_size": size, "optimizer": optimizer, "steps": steps, "n_gpus": world,
+           "iterations_per_s": round(world * steps / dt_all, 2), "ms_per_step": round(dt_all / steps * 1e3, 4),
+           "model_tflops": round(world * work["flops"] / (dt_all / steps) / 1e12, 2)}
+    conv = opt.engine is not None and _conv_roofline_of(opt, steps)
+    if conv:
+        res["conv_roofline_frac"] = conv
+    return res
+
+
+def _conv_roofline_of(opt, steps):
+    """roofline.frac of the split-precision 3x3 launches at this size: a short eager pass with HIP events around every launch."""
+    import models
+    timer = []
+    opt.engine.timer = timer
+    try:
+        for _ in range(min(steps, 20)):
+            opt.step()
+        torch.cuda.synchronize()
+    finally:
+        opt.engine.timer = None
+    conv = [(fl, e0.elapsed_time(e1)) for tag, fl, nb, e0, e1 in timer if tag.startswith("conv3x3_split")]
+    if not conv:
+        return None
+    per_product = 3 if models._x3_enabled() else X6_MFMAS_PER_PRODUCT
+    return round(sum(c[0] for c in conv) / (sum(c[1] for c in conv) * 1e-3) / 1e12 / (BF16_MFMA_PEAK_TFLOPS / per_product), 4)
 
 
 def main():
@@ -247,9 +356,21 @@ def main():
     ap.add_argument("--hip_graph", action="store_true", help="(default) replay each iteration from a captured hipGraph")
     ap.add_argument("--no_hip_graph", action="store_true", help="launch every kernel eagerly in the timed region too")
     ap.add_argument("--no_extra_sizes", action="store_true", help="skip the 512x512 / 256x256 figures in `extra`")
+    ap.add_argument("--no_exact_split", action="store_true", help="skip the bf16x6 (MAUA_CONV_X3=0) figure in `extra`")
+    ap.add_argument("--no_repeats", action="store_true", help="skip the repeated timed regions in `extra.repeats`")
+    ap.add_argument("--repeats", type=int, default=5, help="further K-step regions timed after the headline one")
+    ap.add_argument("--allow_fewer", action="store_true", help="with fewer than --gpus devices visible: run on those and report it")
+    ap.add_argument("--requested_gpus", type=int, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--_launched", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--_wait_for_go", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))  # before anything in this process touches the GPU
+        sys.exit(launch_ranks(a.gpus, [v for v in sys.argv[1:] if v != "--allow_fewer"], a.allow_fewer))  # before anything here touches the GPU
+    if a._wait_for_go and sys.stdin.readline().strip() != "go":  # exact-split child: the parent says when the GPU is free
+        sys.exit(3)  # (the parent went away without asking)
+    exact_child = None
+    if a.gpus == 1 and "WORLD_SIZE" not in os.environ and a.size == 1024 and not a.no_exact_split:
+        exact_child = start_exact_split_child(a.size, a.steps, a.warmup, a.history, a.optimizer)  # before the first GPU call
 
     import config
     import dist
@@ -316,6 +437,18 @@ def main():
     mine = time.perf_counter() - t0
     elapsed = dist.max_over_ranks(mine)
     per_rank = dist.gather_floats(a.steps / mine)  # iterations/s of every rank (rank order)
+    # The same K-step region again, `--repeats` times (each bracketed like the headline one): its spread inside THIS run.
+    repeats = []
+    if not a.no_repeats:
+        for _ in range(max(0, a.repeats)):
+            dist.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                opt.step()
+            torch.cuda.synchronize()
+            dist.barrier()
+            repeats.append(dist.max_over_ranks(time.perf_counter() - t1))
     eager_ms = None
     if opt.engine is not None and a.hip_graph and rank == 0:
         opt.engine.timer = timer
@@ -328,7 +461,12 @@ def main():
     if opt.engine is not None:
         opt.engine.timer = None
 
+    want_sizes = not a.no_extra_sizes and S == 1024
     if rank != 0:
+        if want_sizes:  # every rank runs the other sizes on its own GPU (north_star: 512x512 at 1, 2, 4 and 8 GPUs too)
+            del opt
+            for sz in (512, 256):
+                steady_rate(sz, max(a.steps, 100), a.optimizer, a.history)
         return
     status = opt.state.status() if a.optimizer == "lbfgs" else {}
     work = algorithmic_work(S, a.history)
@@ -409,9 +547,29 @@ def main():
                        "frac_hbm_peak": round((work["bytes_feval"] + (work["bytes_lbfgs"] if a.optimizer == "lbfgs" else 0)) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         "roofline": roofline,
     }
-    if world == 1 and not a.no_extra_sizes and S == 1024:
+    extra = {}
+    if repeats:
+        import statistics
+        rates = sorted(a.steps * world / t for t in repeats)
+        extra["repeats"] = {"regions": len(repeats), "steps_each": a.steps,
+                            "iterations_per_s": {"median": round(statistics.median(rates), 3), "min": round(rates[0], 3),
+                                                 "max": round(rates[-1], 3)},
+                            "ms_per_step": {"median": round(statistics.median(repeats) / a.steps * 1e3, 4),
+                                            "min": round(min(repeats) / a.steps * 1e3, 4),
+                                            "max": round(max(repeats) / a.steps * 1e3, 4)},
+                            "note": "the K-step timed region repeated after the headline region (which stays `value`), each "
+                                    "bracketed by barrier + synchronize, max over ranks"}
+    if a.requested_gpus:
+        out["requested_gpus"] = a.requested_gpus
+        out["note_gpus"] = f"{a.requested_gpus} GPUs requested, {world} visible: ran on {world} (--allow_fewer)"
+    if want_sizes:
         del opt  # frees the 2.5 GB history slab before the next job allocates its own
-        out["extra"] = {"other_sizes": [steady_rate(sz, max(a.steps, 100), a.optimizer, a.history) for sz in (512, 256)]}
+        extra["other_sizes"] = [steady_rate(sz, max(a.steps, 100), a.optimizer, a.history) for sz in (512, 256)]
+    if exact_child is not None:
+        torch.cuda.empty_cache()
+        extra["exact_split"] = finish_exact_split_child(exact_child)
+    if extra:
+        out["extra"] = extra
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(S, a.optimizer)
     print(json.dumps(out), flush=True)

@@ -244,6 +244,11 @@ int maua_gram_fwd_mse_ledger(const float* f, float* gram, float* row_mean_out, i
                              const float* target, float* dmat, float loss_scale, float grad_scale, double* ledger, int slot,
                              void* workspace, size_t workspace_bytes, maua_stream_t stream);
 int maua_loss_ledger_sum(double* ledger, int frames, int slots, float* losses, float* totals, maua_stream_t stream);
+/* The same launch, which also leaves every filled record's loss BEFORE its rounding to fp32 in losses_f64[frames][slots]
+ * (`mod.loss` of optim.py:207-211 as a double; slots whose record is empty are not written): full-size derivative tests
+ * difference loss values that agree in their first five digits. */
+int maua_loss_ledger_sum_f64(double* ledger, int frames, int slots, float* losses, float* totals, double* losses_f64,
+                             maua_stream_t stream);
 
 /* ---- small vector helpers used by the host engine -------------------------------------------------- */
 int maua_fill(float* x, int64_t count, float value, maua_stream_t stream);

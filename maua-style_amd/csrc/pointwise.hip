@@ -28,7 +28,8 @@ __global__ void finish_sum_kernel(const double* __restrict__ partial, int n, flo
 // finish_sum_kernel's order, times the record's scale) and the record is marked empty again; slots without a record keep the
 // value an immediate-mode entry point left there.  Then total = sum of the slots, left to right (`total_loss += mod.loss`).
 __global__ void __launch_bounds__(256)
-loss_ledger_sum_kernel(double* __restrict__ ledger, int slots, float* __restrict__ losses, float* __restrict__ total) {
+loss_ledger_sum_kernel(double* __restrict__ ledger, int slots, float* __restrict__ losses, float* __restrict__ total,
+                       double* __restrict__ exact) {
     __shared__ double scratch[16];
     __shared__ int cnt[64];
     __shared__ double scl[64];
@@ -70,6 +71,7 @@ loss_ledger_sum_kernel(double* __restrict__ ledger, int slots, float* __restrict
                 if (threadIdx.x == 0) {
                     kept[s] = (float)(v * scl[s]);
                     out[s0 + s] = kept[s];
+                    if (exact) exact[(int64_t)blockIdx.x * slots + s0 + s] = v * scl[s];  // (tests: the loss before its fp32 rounding)
                     led[(int64_t)(s0 + s) * LEDGER_STRIDE] = 0.0;
                 }
             }
@@ -611,7 +613,17 @@ int maua_tv_fwd_bwd_ledger(const float* x, float* grad, int n, int c, int h, int
 int maua_loss_ledger_sum(double* ledger, int frames, int slots, float* losses, float* totals, maua_stream_t stream) {
     MAUA_REQUIRE(ledger && losses && totals && frames > 0 && frames <= (1 << 16) && slots > 0 && slots <= (1 << 12), MAUA_E_INVAL,
                  "loss_ledger_sum: bad args");
-    hipLaunchKernelGGL(loss_ledger_sum_kernel, dim3(frames), dim3(256), 0, (hipStream_t)stream, ledger, slots, losses, totals);
+    hipLaunchKernelGGL(loss_ledger_sum_kernel, dim3(frames), dim3(256), 0, (hipStream_t)stream, ledger, slots, losses, totals,
+                       (double*)nullptr);
+    return check_launch("loss_ledger_sum_kernel");
+}
+
+int maua_loss_ledger_sum_f64(double* ledger, int frames, int slots, float* losses, float* totals, double* losses_f64,
+                             maua_stream_t stream) {
+    MAUA_REQUIRE(ledger && losses && totals && losses_f64 && frames > 0 && frames <= (1 << 16) && slots > 0 && slots <= (1 << 12),
+                 MAUA_E_INVAL, "loss_ledger_sum_f64: bad args");
+    hipLaunchKernelGGL(loss_ledger_sum_kernel, dim3(frames), dim3(256), 0, (hipStream_t)stream, ledger, slots, losses, totals,
+                       losses_f64);
     return check_launch("loss_ledger_sum_kernel");
 }
 

@@ -18,26 +18,51 @@ def env_rank():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+_LONG_GROUP = None  # a second communicator over the same ranks whose collectives may wait for hours (end_of_job_barrier)
+
+
 def init(backend=None):
     """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun's env).
-    Returns (rank, local_rank, world).  One process per GPU; the device is chosen before any collective."""
+    Returns (rank, local_rank, world).  One process per GPU; the device is chosen before any collective.
+
+    Two timeouts.  The default group - rendezvous, the start-up broadcast, the benchmark's barriers - gives up after
+    MAUA_DIST_TIMEOUT_S (default 600 s): a rank that died at start-up must not leave the others holding their GPUs.  Ranks
+    that finish uneven shards of a long job meet in `end_of_job_barrier`, on a second group with MAUA_DIST_JOB_TIMEOUT_S
+    (default one week)."""
+    global _LONG_GROUP
     rank, local_rank, world = env_rank()
     if world > 1 and not td.is_initialized():
         if backend is None:  # MAUA_DIST_BACKEND=gloo: several ranks sharing one GPU (testing the N > 1 paths on a 1-GPU box)
             backend = os.environ.get("MAUA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
+            if local_rank >= torch.cuda.device_count():
+                raise RuntimeError(f"rank {rank}: LOCAL_RANK {local_rank} but {torch.cuda.device_count()} device(s) visible; RCCL "
+                                   "needs one GPU per rank (MAUA_DIST_BACKEND=gloo shares GPUs between ranks)")
             torch.cuda.set_device(local_rank)
         elif torch.cuda.is_available():
             torch.cuda.set_device(local_rank % torch.cuda.device_count())
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # Ranks meet only at start-up (one broadcast) and at the very end of a job that can run for hours with uneven
-        # shards: the default 10-minute collective timeout would abort the waiting ranks.  MAUA_DIST_TIMEOUT_S overrides.
         import datetime
-        timeout = datetime.timedelta(seconds=float(os.environ.get("MAUA_DIST_TIMEOUT_S", 7 * 24 * 3600)))
-        td.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
+        short = datetime.timedelta(seconds=float(os.environ.get("MAUA_DIST_TIMEOUT_S", 600)))
+        td.init_process_group(backend=backend, rank=rank, world_size=world, timeout=short)
+        long = datetime.timedelta(seconds=float(os.environ.get("MAUA_DIST_JOB_TIMEOUT_S", 7 * 24 * 3600)))
+        _LONG_GROUP = td.new_group(ranks=list(range(world)), timeout=long, backend=backend)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank if local_rank < torch.cuda.device_count() else 0)
     return rank, local_rank, world
+
+
+def end_of_job_barrier():
+    """Where the ranks of a sharded job wait for each other after their (uneven, possibly hours-long) shards: a barrier on the
+    long-timeout group.  Everything before it uses the default group's short timeout."""
+    if td.is_available() and td.is_initialized() and td.get_world_size() > 1:
+        if _LONG_GROUP is not None:
+            t = torch.zeros(1, device=_coll_device())
+            td.all_reduce(t, group=_LONG_GROUP)
+            if t.is_cuda:
+                torch.cuda.synchronize()
+        else:
+            td.barrier()
 
 
 def shard_range(n_items, rank, world):
@@ -57,8 +82,8 @@ def shard_owner(index, n_items, world):
 
 def broadcast_tensors(tensors, src=0):
     """Broadcast a list of same-dtype tensors as ONE flat buffer (one collective instead of one per layer)."""
-    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
-        return
+    if not (td.is_available() and td.is_initialized()):
+        return  # (a one-rank group still runs the collective: the code path of the 8-GPU job on a 1-GPU box)
     tensors = [t for t in tensors if t is not None and t.numel() > 0]
     if not tensors:
         return
@@ -81,8 +106,7 @@ def broadcast_style_targets(net, src=0):
     """Style Gram targets captured on rank `src` -> every rank (2.4 MB for the default five layers), so the style
     forward passes run once per job instead of once per rank (and once per frame, as the reference does:
     style.py:178 keeps the hoisting commented out)."""
-    world = td.get_world_size() if (td.is_available() and td.is_initialized()) else 1
-    if world == 1:
+    if not (td.is_available() and td.is_initialized()):
         return
     for mod in net.style_losses:
         for name in ("target", "video_target"):
@@ -143,7 +167,7 @@ def gather_frames(local, n_items):
     if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
         return local
     out = [None] * td.get_world_size()
-    td.all_gather_object(out, local)
+    td.all_gather_object(out, local, group=_LONG_GROUP)  # the ranks arrive here after their whole shards: long timeout
     merged = {}
     for d in out:
         merged.update(d)

@@ -163,6 +163,7 @@ class StyleEngine:
         # Single images and independent frames: the losses leave their partial sums in a ledger (one record per frame and slot)
         # and ONE launch at the end of the evaluation forms every loss value and the totals (hip.loss_ledger_sum)
         self.ledger = None
+        self.slots_f64 = None  # tests set this (zeros_like(slots_all, dtype=float64)): the losses before their rounding to fp32
         if (B == 1 or self.independent) and os.environ.get("MAUA_LOSS_LEDGER", "1") != "0":
             self.ledger = hip.loss_ledger(B, n_slots, dev)
         # conv + ReLU whose only consumer is a 2x2 / 2 max pool with kept decisions, on conv_x3w.hip in one pass over the
@@ -242,7 +243,7 @@ class StyleEngine:
                     list(self.gram_d.values()) + list(self.dmat_d.values()):
                 if t is not None and not t.is_meta:
                     t.fill_(float("nan"))
-            self.ws.view(torch.float32)[:] = float("nan") if self.ws.numel() % 4 == 0 else 0
+            self.ws[:self.ws.numel() // 4 * 4].view(torch.float32)[:] = float("nan")
         # Independent frames: the per-frame kernels (Gram, losses, Gram backward, optimiser) of different frames share
         # nothing, and most of them are too small to fill the chip or are latency-bound chains - they run on a few side
         # streams so that the GPU overlaps them (fork after the kernel that produced their input, join before the next
@@ -644,7 +645,7 @@ class StyleEngine:
         if cur != 0:
             hip.fill_(g[0], 0.0)
         if self.ledger is not None:  # (B == 1 or independent frames: no per-module terms to fold afterwards)
-            hip.loss_ledger_sum(self.ledger, self.slots_all, self.total)
+            hip.loss_ledger_sum(self.ledger, self.slots_all, self.total, self.slots_f64)
             return
         if indep:
             for b in range(x.shape[0]):

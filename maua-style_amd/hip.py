@@ -84,6 +84,7 @@ SIGNATURES = {
     "maua_gram_mse_ledger_supported": (c_i, [c_i]),
     "maua_gram_fwd_mse_ledger": (c_i, [c_p, c_p, c_p, c_i, c_i64, c_f, c_i, c_p, c_p, c_f, c_f, c_p, c_i, c_p, c_sz, c_p]),
     "maua_loss_ledger_sum": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p]),
+    "maua_loss_ledger_sum_f64": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
     "maua_lbfgs_state_bytes": (c_sz, [c_i64, c_i]),
     "maua_lbfgs_init": (c_i, [c_p, c_sz, c_i64, c_i, c_p]),
     "maua_lbfgs_iterate": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_f, c_f, c_f, c_p]),
@@ -515,9 +516,15 @@ def tv_fwd_bwd_ledger(x, grad, strength, accumulate, ledger, slot):
                                         ledger.data_ptr(), int(slot), _stream()), "maua_tv_fwd_bwd_ledger")
 
 
-def loss_ledger_sum(ledger, losses, totals):
-    """losses: (frames, slots) or (slots,) float32; totals: (frames,) float32."""
+def loss_ledger_sum(ledger, losses, totals, losses_f64=None):
+    """losses: (frames, slots) or (slots,) float32; totals: (frames,) float32; losses_f64 (optional, float64, same shape as
+    losses): every filled record's loss before its rounding to fp32."""
     frames, slots = ledger.shape[0], ledger.shape[1]
+    if losses_f64 is not None:
+        assert losses_f64.dtype == torch.float64 and losses_f64.numel() == frames * slots and losses_f64.is_contiguous()
+        _check(lib().maua_loss_ledger_sum_f64(ledger.data_ptr(), frames, slots, _ptr(losses), _ptr(totals), losses_f64.data_ptr(),
+                                              _stream()), "maua_loss_ledger_sum_f64")
+        return
     _check(lib().maua_loss_ledger_sum(ledger.data_ptr(), frames, slots, _ptr(losses), _ptr(totals), _stream()),
            "maua_loss_ledger_sum")
 

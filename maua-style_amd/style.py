@@ -269,11 +269,49 @@ def planned_frames(size):
     return max(1, min(16, (4 << 20) // max(1, int(size) * int(size))))
 
 
-def frames_per_batch(size):
+def frames_per_batch(size, args=None):
     """How many frames are actually optimised together: planned_frames, unless MAUA_FRAME_BATCH overrides it (1 = the
-    reference's frame-by-frame loop; same results bit for bit, the policy above does not change)."""
+    reference's frame-by-frame loop; same results bit for bit, the policy above does not change).  Two flags make calls
+    depend on each other or on their own file names and therefore run frame by frame: `--normalize_weights` divides the
+    strengths of the SHARED network once per optimize call and never resets them (optim.py:176-178: they compound per frame),
+    and `--save_iter` writes `<frame output>_<size>[_<iter>].png` from inside each frame's own call (optim.py:230-236)."""
+    if args is not None and (getattr(args, "normalize_weights", False) or getattr(args, "save_iter", 0) > 0):
+        return 1
     forced = int(os.environ.get("MAUA_FRAME_BATCH", "0"))
     return forced if forced > 0 else planned_frames(size)
+
+
+class _ByteBudget(dict):
+    """dict of device tensors that forgets its oldest entries once it holds more than `budget` bytes (a miss is always
+    recoverable: the frame is decoded / read from its file again).  Keeps vid_img's device memory O(1) in the clip length."""
+
+    def __init__(self, budget):
+        super().__init__()
+        self.budget, self.held = int(budget), 0
+
+    def __setitem__(self, key, t):
+        if key in self:
+            self.held -= super().__getitem__(key).numel() * super().__getitem__(key).element_size()
+        super().__setitem__(key, t)
+        self.held += t.numel() * t.element_size()
+        while self.held > self.budget and len(self) > 1:
+            oldest = next(iter(self))
+            if oldest == key:
+                break
+            self.pop(oldest)
+
+    def pop(self, key, *default):
+        if key in self:
+            t = super().pop(key)
+            self.held -= t.numel() * t.element_size()
+            return t
+        if default:
+            return default[0]
+        raise KeyError(key)
+
+    def clear(self):
+        super().clear()
+        self.held = 0
 
 
 def _optimize_group(contents, style_images, inits, num_iters, args, net, losses, planned):
@@ -319,7 +357,10 @@ def vid_img(args):
     # What the next pass reads back is what this pass wrote: the 8-bit image of every finished frame stays in memory (768 KB at
     # 512 x 512), so the PNG only has to be decoded when it comes from an earlier run (resume) or was colour-transferred on
     # the way out.  Decoded, rescaled content frames are kept per scale as well (every pass starts from them again).
-    written, content_cache = {}, {}
+    # Both are bounded (MAUA_FRAME_CACHE_MB, default 4096 MB each): a clip of thousands of frames must not grow the device
+    # footprint with its length (the reference holds one frame at a time); a miss decodes the PNG again.
+    budget = int(float(os.environ.get("MAUA_FRAME_CACHE_MB", "4096")) * (1 << 20))
+    written, content_cache = _ByteBudget(budget), _ByteBudget(budget)
     for size_n, (current_size, num_iters) in enumerate(zip(args.image_sizes, args.num_iters)):
         print("\nCurrent size {}px".format(current_size))
         os.makedirs(output_dir + "/" + str(current_size), exist_ok=True)
@@ -331,7 +372,7 @@ def vid_img(args):
         optim.set_model_args(args, current_size)
         net, losses = models.load_model(args)
         dist.broadcast_network(net, src=0)
-        batch = frames_per_batch(current_size)
+        batch = frames_per_batch(current_size, args)
 
         for pass_n in range(passes):
             out_path = lambda frame: "%s/%s/%s_%s.png" % (output_dir, current_size, pass_n + 1, name(frame))
@@ -346,9 +387,10 @@ def vid_img(args):
                 contents, inits, post_noise = [], [], []
                 for frame in group:  # host phase, frame by frame: every global-RNG draw in the reference's order
                     print("Optimizing... size: %s, pass: %s, frame: %s" % (current_size, pass_n + 1, name(frame)))
-                    if frame not in content_cache:
-                        content_cache[frame] = _resize(up(load.preprocess(frame)), scale_factor=content_scale)
-                    content = match_histogram(content_cache[frame], style_images_big[0], mode=mode)
+                    resized = content_cache.get(frame)
+                    if resized is None:
+                        resized = content_cache[frame] = _resize(up(load.preprocess(frame)), scale_factor=content_scale)
+                    content = match_histogram(resized, style_images_big[0], mode=mode)
                     if size_n == 0 and pass_n == 0:
                         pastiche = up(th.randn(content.size()).mul(0.001)) if args.init == "random" else content.clone()
                     else:  # previous result of this frame: last pass of the previous size, or previous pass of this size
@@ -374,7 +416,8 @@ def vid_img(args):
                     if on_gpu and args.original_colors != 1:
                         import hip
                         u8 = hip.deprocess_u8(out.float().contiguous(), load._MEAN_BGR)
-                        written[out_path(frame)] = u8
+                        if not (size_n == len(args.image_sizes) - 1 and pass_n == passes - 1):  # nothing reads the last pass back
+                            written[out_path(frame)] = u8
                         img = Image.fromarray(u8.cpu().numpy(), mode="RGB")
                     else:
                         img = load.deprocess(out)
@@ -387,7 +430,7 @@ def vid_img(args):
     for fut in pending.values():  # surface any error of the background writer
         fut.result()
     writer.shutdown()
-    dist.barrier()
+    dist.end_of_job_barrier()  # uneven shards of a long job: the one wait with the long timeout
 
 
 if __name__ == "__main__":

@@ -635,6 +635,28 @@ def test_frame_batch_is_bit_identical_to_frame_by_frame(weight_files, opt, S, ex
     assert rel_l2(plain[0], together[0]) <= (0.2 if opt == "lbfgs" else 1e-4)
 
 
+@pytest.mark.parametrize("opt,N", [("lbfgs", 5), ("lbfgs", 10), ("adam", 10)])
+def test_frame_batch_against_the_reference_trajectory(weight_files, opt, N):
+    """The batch path against the GOLDEN, not against itself: the problem of tests/golden/traj_vgg19_S64.npz (the unmodified
+    reference's optim.optimize run, fp32 and fp64) is frame 1 of a B = 3 optimize_frames call between two other frames; its
+    result meets the same trajectory rule as a plain optimize call (reference loop: style.py:192-290 -> optim.py:111-255)."""
+    import models
+    import optim
+    g = gold("traj_vgg19_S64")
+    ref32, ref64 = g[f"{opt}_N{N}_f32"], g[f"{opt}_N{N}_f64"]
+    content, style, init = synth.images(64)
+    contents = torch.cat([synth.images(64, seed=50)[0], content, synth.images(64, seed=51)[0]])
+    inits = torch.cat([synth.images(64, seed=60)[2], init, synth.images(64, seed=61)[2]])
+    args = product_args(weight_files, optimizer=opt, S=64, N=N)
+    optim.set_model_args(args, 64)
+    net, losses = models.load_model(args)
+    out = optim.optimize_frames(contents.cuda(), [style], inits.cuda(), N, args, net, losses).cpu()
+    floor = rel_l2(ref32, ref64)
+    err = rel_l2(out[1:2], ref64)
+    assert err <= max(1e-3, 2 * floor), (err, floor)
+    assert rel_l2(out[0:1], ref64) > 0.1          # (the neighbours really are other problems)
+
+
 def test_frame_batch_nin(weight_files):
     import models
     import optim
