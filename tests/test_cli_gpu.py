@@ -356,7 +356,8 @@ def test_vid_img_frame_batches_match_the_frame_by_frame_loop(tmp_path, weight_fi
     flags += ["--init", "random"] if variant == "hist_random_init" else ["--no_hist_match", "--init", "content"]
     # --normalize_weights divides the shared network's strengths on every optimize call (reference optim.py:176-178: they compound
     # per FRAME), --save_iter names its intermediate files after each frame's own output: both make the job run frame by frame
-    flags += {"normalize_weights": ["--normalize_weights"], "save_iter": ["--save_iter", "2"]}.get(variant, [])
+    # (with the default temporal weight the reference itself divides by max(size of an empty target) = 0: the flag needs --temporal_weight 0)
+    flags += {"normalize_weights": ["--normalize_weights", "--temporal_weight", "0"], "save_iter": ["--save_iter", "2"]}.get(variant, [])
     outs = {}
     for batch in ("1", "3"):
         out = tmp_path / f"out{batch}"

@@ -1,0 +1,120 @@
+"""CPU emulation (no GPU): what would Winograd F(2x2,3x3) on the fp16x3 split cost in accuracy?
+
+Compares, against F.conv2d in fp64, on layer-shaped data (post-ReLU activations, He-scaled filters):
+  fp32 CPU conv              - the reference's own arithmetic
+  direct fp16x3              - conv_x3w.hip's scheme: per-chunk power-of-two scale, two fp16 parts per operand, three products,
+                               one truncating fp32 accumulation per MFMA k-step (27 per 16-channel chunk), RTN fold per chunk
+  Winograd fp16x3            - input transform B^T d B in fp32 on the scaled patch, filter transform G g G^T in fp64 -> fp32 bank,
+                               both split into two fp16 parts, 16 element-wise GEMMs (3 k-steps per 16-channel chunk), RTN fold per
+                               chunk, inverse transform A^T M A in fp32
+usage: python tools/probe_winograd_numerics.py [cin cout side]
+"""
+import sys
+
+import torch
+import torch.nn.functional as F
+
+torch.manual_seed(0)
+cin, cout, side = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (128, 64, 32)
+
+
+def trunc32(v64, _rtn=__import__("os").environ.get("RTN") == "1"):
+    """fp64 -> fp32 with truncation toward zero (the MFMA adder's alignment behaviour, tools/mfma_probe/mfma_round.hip)."""
+    f = v64.float()
+    if _rtn:
+        return f.double()
+    over = f.double().abs() > v64.abs()
+    f = torch.where(over, torch.nextafter(f, torch.zeros_like(f)), f)
+    return f.double()
+
+
+def split16(v32):
+    """two fp16 parts of an fp32 tensor (round to nearest, like v_cvt_pk_f16_f32)"""
+    hi = v32.half()
+    lo = (v32 - hi.float()).half()
+    return hi.double(), lo.double()
+
+
+def pow2_scale(m, target_exp):
+    """power of two s with s * m in [2^target_exp, 2^(target_exp + 1))"""
+    e = torch.floor(torch.log2(m.clamp_min(1e-30)))
+    return torch.pow(2.0, target_exp - e)
+
+
+def direct_x3(x, w, chunk=16):
+    c, H, W = x.shape
+    co = w.shape[0]
+    wmax = w.abs().max()
+    ws = pow2_scale(wmax, 5)                       # |w s| in [32, 64)
+    wh, wl = split16((w * ws).float())
+    xp = F.pad(x, (1, 1, 1, 1))
+    master = torch.zeros(co, H, W, dtype=torch.float32)
+    for c0 in range(0, c, chunk):
+        xc = xp[c0:c0 + chunk]
+        s = pow2_scale(xc.abs().max(), 11)         # chunk maximum into [2^11, 2^12)  (one tile here)
+        xh, xl = split16((xc * s).float())
+        acc = torch.zeros(co, H, W, dtype=torch.float64)
+        for ky in range(3):
+            for kx in range(3):
+                for (a, b) in ((xh, wh), (xh, wl), (xl, wh)):
+                    blk = torch.einsum("chw,oc->ohw", a[:, ky:ky + H, kx:kx + W], b[:, c0:c0 + chunk, ky, kx])
+                    acc = trunc32(acc + blk)
+        master = (master.double() + acc / (s * ws)).float()
+    return master.double()
+
+
+BT = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float64)
+G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64)
+AT = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float64)
+
+
+def winograd_x3(x, w, chunk=16, fold=True, plain_fp32=False):
+    c, H, W = x.shape
+    co = w.shape[0]
+    U = torch.einsum("ai,ocij,bj->ocab", G, w.double(), G)          # filter transform in fp64
+    us = pow2_scale(U.abs().max(), 5)
+    U32 = (U * us).float()
+    uh, ul = split16(U32)
+    xp = F.pad(x, (1, 1, 1, 1))
+    th, tw = H // 2, W // 2
+    # 4x4 tiles, stride 2: (c, th, tw, 4, 4)
+    tiles = xp.unfold(1, 4, 2).unfold(2, 4, 2)
+    master = torch.zeros(co, th, tw, 4, 4, dtype=torch.float32)
+    for c0 in range(0, c, chunk):
+        d = tiles[c0:c0 + chunk]
+        s = pow2_scale(d.abs().max(), 9)                            # |V| <= 4 |d|: two bits of head room
+        d32 = (d * s).float()
+        # B^T d B in fp32, two 1-D passes of +-1 additions (each add rounds)
+        t = torch.stack([d32[..., 0, :] - d32[..., 2, :], d32[..., 1, :] + d32[..., 2, :], d32[..., 2, :] - d32[..., 1, :],
+                         d32[..., 1, :] - d32[..., 3, :]], dim=-2)
+        V32 = torch.stack([t[..., 0] - t[..., 2], t[..., 1] + t[..., 2], t[..., 2] - t[..., 1], t[..., 1] - t[..., 3]], dim=-1)
+        if plain_fp32:
+            acc = torch.einsum("cyxab,ocab->oyxab", V32.double(), U32[:, c0:c0 + chunk].double()).float().double()
+        else:
+            vh, vl = split16(V32)
+            acc = torch.zeros(co, th, tw, 4, 4, dtype=torch.float64)
+            for (a, b) in ((vh, uh), (vl, uh), (vh, ul)):
+                acc = trunc32(acc + torch.einsum("cyxab,ocab->oyxab", a, b[:, c0:c0 + chunk]))
+        master = (master.double() + acc / (s * us)).float()
+    M = master
+    # A^T M A in fp32
+    r = torch.stack([M[..., 0, :] + M[..., 1, :] + M[..., 2, :], M[..., 1, :] - M[..., 2, :] - M[..., 3, :]], dim=-2)
+    Y = torch.stack([r[..., 0] + r[..., 1] + r[..., 2], r[..., 1] - r[..., 2] - r[..., 3]], dim=-1)   # (co, th, tw, 2, 2)
+    return Y.permute(0, 1, 3, 2, 4).reshape(co, H, W).double()
+
+
+def rel(a, b):
+    return float((a - b).norm() / b.norm())
+
+
+for kind in ("relu(randn)", "gradient-like (masked, wide range)"):
+    x = torch.relu(torch.randn(cin, side, side)) if kind.startswith("relu") else \
+        torch.randn(cin, side, side) * torch.exp(torch.randn(cin, side, side) * 1.5) * (torch.rand(cin, side, side) > 0.5) * 1e-4
+    w = torch.randn(cout, cin, 3, 3) * (2.0 / (9 * cin)) ** 0.5
+    ref = F.conv2d(x.double()[None], w.double(), padding=1)[0]
+    e32 = rel(F.conv2d(x[None], w, padding=1)[0].double(), ref)
+    print(f"{kind}: cin {cin} cout {cout} {side}x{side}")
+    print(f"   fp32 CPU conv            {e32:.3e}")
+    print(f"   direct fp16x3            {rel(direct_x3(x, w), ref):.3e}")
+    print(f"   Winograd fp16x3          {rel(winograd_x3(x, w), ref):.3e}")
+    print(f"   Winograd plain fp32      {rel(winograd_x3(x, w, plain_fp32=True), ref):.3e}")
