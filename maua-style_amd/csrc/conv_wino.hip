@@ -164,8 +164,7 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, unsigned char* __r
 // One LDS-DMA instruction: 64 lanes x 4 bytes from a buffer resource (out-of-range lanes deliver 0) to 256 consecutive LDS bytes.
 __device__ __forceinline__ void wn_dma_row(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_dst) {
     unsigned keep;
-    // (s_nop 4: the descriptor's words come from v_readfirstlane - VALU-written SGPRs need five wait states before a VMEM read)
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(voff), "s"(lds_dst), "s"(rsrc), "s"(soff)
                  : "memory");
@@ -236,6 +235,7 @@ __global__ void __launch_bounds__(512, 2) conv_wino_kernel(ConvArgs p) {
         const uint64_t base = (uint64_t)(size_t)(xin + (int64_t)ch * 16 * in_plane);
         const unsigned b_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base);
         const unsigned b_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32)) & 0xffffu;
+        asm volatile("s_nop 4" ::: "memory");  // (SGPRs written by v_readfirstlane need five wait states before a VMEM instruction reads them)
 #pragma unroll
         for (int e = 0; e < 2; ++e)
 #pragma unroll
@@ -356,18 +356,19 @@ __global__ void __launch_bounds__(512, 2) conv_wino_kernel(ConvArgs p) {
     // statements pin the order (each "rewrites" what the next step reads)
     auto block = [&](BFrag& b, int tb, float inv) {
         f32x16 t0 = mfma3(a0, b[0], 0);
-        f32x16 t1 = mfma3(a0, b[0], 1);
-        WN_PIN2(t0, t1);
+        WN_PINB(t0, b);
         fold(acc[0][0][tb], t0, inv);
         WN_PINB(acc[0][0][tb], b);
-        t0 = mfma3(a1, b[1], 0);
-        WN_PIN2(t0, t1);
-        fold(acc[0][1][tb], t1, inv);
+        t0 = mfma3(a0, b[0], 1);
+        WN_PINB(t0, b);
+        fold(acc[0][1][tb], t0, inv);
         WN_PINB(acc[0][1][tb], b);
-        t1 = mfma3(a1, b[1], 1);
-        WN_PIN2(t0, t1);
+        t0 = mfma3(a1, b[1], 0);
+        WN_PINB(t0, b);
         fold(acc[1][0][tb], t0, inv);
-        fold(acc[1][1][tb], t1, inv);
+        WN_PINB(acc[1][0][tb], b);
+        t0 = mfma3(a1, b[1], 1);
+        fold(acc[1][1][tb], t0, inv);
     };
 
     // ---- channel loop.  Raw patches run three chunks deep in the ring (DMA of chunk c + 2 issued at the end of iteration c, after

@@ -42,8 +42,8 @@ n = min(nch, 62)
 t = raw[:, :, :n]
 valid = t[:, 0, 0, 0] != 0
 t = t[valid]
-names = ["request filters + raw patch, scale", "transform (waves 0-3)", "products (24 MFMA + folds)", "transform (waves 4-7)", "X1 wait",
-         "raw -> LDS, maxima", "X2 wait"]
+names = ["barrier wait", "operand of tile block 0", "12 MFMA + 4 folds", "20 LDS-DMA rows (raw patch, chunk + 2)", "operand of tile block 1",
+         "12 MFMA + 4 folds", "filter fragments of the next chunk"]
 for grp, sel in (("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8))):
     tt = t[:, sel]
     seg = [((tt[..., k + 1] - tt[..., k]) & 0xFFFFFFFF)[:, :, 1:n - 1].float() for k in range(7)]
