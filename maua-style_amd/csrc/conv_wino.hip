@@ -208,14 +208,15 @@ __global__ void __launch_bounds__(512, 2) conv_wino_kernel(ConvArgs p) {
     const unsigned char* __restrict__ bank = reinterpret_cast<const unsigned char*>(p.w6);
     const float u_inv = reinterpret_cast<const float*>(bank)[1];
 
-    // ---- this wave's two Winograd positions: row xi = wave / 2 of B^T d B, columns nu = (0, 1) or (3, 2)
-    //      t[c]  = d[rA][c] + sigma d[rB][c]                       (rows by xi; tau = overall sign of the row combination)
-    //      slot 0 = u0 - u2,  slot 1 = u1 + alpha u0 + beta u2     with u = t[0..2] (nu pair 0) or t[1..3] (nu pair 1)
+    // ---- this wave's two Winograd positions: row xi = wave / 2 of B^T d B, columns nu = (0, 1) or (2, 3)
+    //      t[c] = d[rA][c] + sigma d[rB][c]   (rows by xi; tau = overall sign of the row combination, carried by the scales)
+    //      A lane reads (p, q) = t[0, 1] and r = t[2]  (nu pair 0)   or   (p, q) = t[2, 3] and r = t[1]  (nu pair 1); then
+    //      slot 0 = p - r = V[xi][0] or V[xi][2],   slot 1 = q + gamma r = V[xi][1] or -V[xi][3]   (gamma = +1 / -1)
     const int xi = wave >> 1, nup = wave & 1;
     const int rA = xi == 0 ? 0 : 1, rB = xi == 3 ? 3 : 2;
     const float sigma = xi == 1 ? 1.f : -1.f, tau = xi == 2 ? -1.f : 1.f;
-    const float alpha = nup ? -1.f : 0.f, beta = nup ? 0.f : 1.f;
-    const int pos0 = xi * 4 + (nup ? 3 : 0), pos1 = xi * 4 + (nup ? 2 : 1);  // bank / exchange positions of slot 0 / 1
+    const float gamma = nup ? -1.f : 1.f, tau1 = nup ? -tau : tau;
+    const int pos0 = xi * 4 + 2 * nup, pos1 = pos0 + 1;  // bank / exchange positions of slot 0 / 1
 
     // ---- raw patch ring in LDS: [buffer][16 ch][10 rows][64 floats]; column c of patch row R sits at (c + 32 ((R >> 1) & 1)) % 64
     //      (rows two apart - the two tile rows of a 32-tile block - land 32 banks apart: the window reads are conflict-free).
@@ -251,14 +252,14 @@ __global__ void __launch_bounds__(512, 2) conv_wino_kernel(ConvArgs p) {
 
     // ---- window reads: lane (tile column n = j of a 32-tile block, channel octet = half): tile row trl = j / 16, tile column tc = j % 16
     const int trl = j >> 4, tc = j & 15;
-    int rd[2][2];  // [row A / B][column pair 0-1 / 2-3]: byte offset inside a raw buffer for block 0, channel 0 of the octet
+    int rd64[2], rd32[2];  // [row A / B]: byte offsets inside a raw buffer (tile block 0, channel 0 of the octet) of (p, q) and of r
 #pragma unroll
     for (int ab = 0; ab < 2; ++ab) {
         const int r = ab ? rB : rA;
         const int rot = 32 * ((trl + (r >> 1)) & 1);
-#pragma unroll
-        for (int cp = 0; cp < 2; ++cp)
-            rd[ab][cp] = ((half * 8) * WN_PR + 2 * trl + r) * 256 + ((2 * tc + 2 * cp + rot) & 63) * 4;
+        const int row = ((half * 8) * WN_PR + 2 * trl + r) * 256;
+        rd64[ab] = row + ((2 * tc + 2 * nup + rot) & 63) * 4;
+        rd32[ab] = row + ((2 * tc + 2 - nup + rot) & 63) * 4;
     }
 
     // ---- filter fragments straight from the bank (MFMA lane order, L2-resident): slot i -> position pos_i
@@ -295,17 +296,16 @@ __global__ void __launch_bounds__(512, 2) conv_wino_kernel(ConvArgs p) {
     typedef f16x8 BFrag[2][2];  // [slot][part]
     auto make_b = [&](BFrag& b, const unsigned char* __restrict__ Rb, int tb) {
         float V[2][8];
+        int o64a = rd64[0], o64b = rd64[1], o32a = rd32[0], o32b = rd32[1];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const int o = tb * 1024 + c * (WN_PR * 256);
-            const f32x2 dA0 = *reinterpret_cast<const f32x2*>(Rb + rd[0][0] + o), dA1 = *reinterpret_cast<const f32x2*>(Rb + rd[0][1] + o);
-            const f32x2 dB0 = *reinterpret_cast<const f32x2*>(Rb + rd[1][0] + o), dB1 = *reinterpret_cast<const f32x2*>(Rb + rd[1][1] + o);
-            const float t0 = fmaf(sigma, dB0[0], dA0[0]), t1 = fmaf(sigma, dB0[1], dA0[1]);
-            const float t2 = fmaf(sigma, dB1[0], dA1[0]), t3 = fmaf(sigma, dB1[1], dA1[1]);
-            const float u0 = nup ? t1 : t0, u1 = nup ? t2 : t1, u2 = nup ? t3 : t2;
-            V[0][c] = u0 - u2;
-            V[1][c] = fmaf(beta, u2, fmaf(alpha, u0, u1));
-            if (c & 1) asm volatile("" : "+v"(V[0][c]), "+v"(V[1][c]), "+v"(rd[0][0]), "+v"(rd[0][1]), "+v"(rd[1][0]), "+v"(rd[1][1]));
+            const f32x2 pqA = *reinterpret_cast<const f32x2*>(Rb + o64a + o), pqB = *reinterpret_cast<const f32x2*>(Rb + o64b + o);
+            const float rrA = *reinterpret_cast<const float*>(Rb + o32a + o), rrB = *reinterpret_cast<const float*>(Rb + o32b + o);
+            const float pp = fmaf(sigma, pqB[0], pqA[0]), qq = fmaf(sigma, pqB[1], pqA[1]), rr = fmaf(sigma, rrB, rrA);
+            V[0][c] = pp - rr;
+            V[1][c] = fmaf(gamma, rr, qq);
+            if (c & 1) asm volatile("" : "+v"(V[0][c]), "+v"(V[1][c]), "+v"(o64a), "+v"(o64b), "+v"(o32a), "+v"(o32b));
         }
         float m = 0.f;
 #pragma unroll
@@ -320,17 +320,23 @@ __global__ void __launch_bounds__(512, 2) conv_wino_kernel(ConvArgs p) {
         }
         unsigned eb = (__builtin_bit_cast(unsigned, m) >> 23) & 0xffu;  // biased exponent; 0 for an all-zero (or denormal) column
         eb = eb < 27u ? 27u : (eb > 227u ? 227u : eb);
-        const float s = __builtin_bit_cast(float, (unsigned)(127 + 13 + 127 - (int)eb) << 23) * tau;
-        const float inv = __builtin_bit_cast(float, (unsigned)((int)eb - 13) << 23);  // (the row sign tau rides on the scale only)
+        const float s = __builtin_bit_cast(float, (unsigned)(127 + 13 + 127 - (int)eb) << 23);
+        const float inv = __builtin_bit_cast(float, (unsigned)((int)eb - 13) << 23);  // (the signs ride on the scales only)
+        // two-part fp16 split of V s: hi = f16(V s) straight from the FMA (v_fma_mixlo / mixhi: one rounding), lo = f16(V s - hi) with
+        // the residual exact in fp32 (v_fma_mix_f32 reads the f16 half it subtracts) - 2.5 instructions per value
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            const float si = s * (i ? tau1 : tau);
             u32x4 H, L;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float v0 = V[i][2 * q] * s, v1 = V[i][2 * q + 1] * s;
-                const unsigned h2 = wn_cvt_pk_f16(v0, v1);
+                unsigned h2;
+                float r0, r1;
+                asm("v_fma_mixlo_f16 %0, %1, %3, 0\n\tv_fma_mixhi_f16 %0, %2, %3, 0" : "=&v"(h2) : "v"(V[i][2 * q]), "v"(V[i][2 * q + 1]), "v"(si));
+                asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(V[i][2 * q]), "v"(si), "v"(h2));
+                asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(V[i][2 * q + 1]), "v"(si), "v"(h2));
                 H[q] = h2;
-                L[q] = wn_cvt_pk_f16(v0 - wn_f16_lo(h2), v1 - wn_f16_hi(h2));
+                L[q] = wn_cvt_pk_f16(r0, r1);
             }
             b[i][0] = __builtin_bit_cast(f16x8, H);
             b[i][1] = __builtin_bit_cast(f16x8, L);
