@@ -138,8 +138,9 @@ def pmc_traffic(prefix):
     by tools/pmc_summary.py from separate `rocprofv3 --pmc` runs of this same command).  Reads: request counters x 64 B,
     doubled as MI355X_MICROARCH.md prescribes for gfx950 (our own calibration, profiles/pmc_r01_calibration.json: x2.0
     for 16 B/lane streams, x1.2-1.6 for 4 B/lane patterns, so this is an upper bound); writes are exact."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_r02_traffic.json")
-    if not os.path.exists(path):
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    path = next((os.path.join(here, f) for f in ("pmc_r03_traffic.json", "pmc_r02_traffic.json") if os.path.exists(os.path.join(here, f))), None)
+    if path is None:
         return None
     with open(path) as f:
         kernels = json.load(f)["kernels"]
@@ -152,7 +153,7 @@ def pmc_traffic(prefix):
     if not n:
         return None
     return {"bytes": round((2 * rd + wr) / n),
-            "note": "per launch, from profiles/pmc_r02_traffic.json (separate rocprofv3 --pmc passes of this command): "
+            "note": f"per launch, from profiles/{os.path.basename(path)} (separate rocprofv3 --pmc passes of this command): "
                     "2 x TCC_EA0_RDREQ x 64 B (gfx950 correction, upper bound for 4 B/lane loads) + write requests"}
 
 

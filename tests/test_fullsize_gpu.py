@@ -200,6 +200,49 @@ def test_full_size_fp16x3_conv_is_as_close_to_fp64_as_fp32_cpu(setup, layer, dir
         assert err <= max(1.5 * floor, 1e-7), (layer, direction, (y0, x0), err, floor)
 
 
+@pytest.mark.parametrize("layer", ["conv3_4", "conv4_3", "conv4_4", "conv5_1"])
+def test_full_size_backward_pass_gradients_against_fp64(setup, layer):
+    """The gradients the REAL 1024x1024 backward pass leaves in the engine's buffers - written by the launches the benchmark times, with
+    the ReLU mask of the produced gradient applied in the convolution's epilogue (conv_x3w_kernel<false, true, false>) - against fp64 on
+    64x64 crops: g[input of the layer] = [input > 0] * conv_transpose(g[output of the layer]) (autograd of models.py:129-130 in the
+    reference), recomputed on the CPU from the engine's own g[output] and saved activation.  Layers whose input carries no loss term
+    (conv4_3's input, relu4_2, is the content layer: its MSE gradient is added on top - checked with it).  Bar: 1.5x the error of the fp32
+    CPU arithmetic on the same data."""
+    import torch.nn.functional as F
+    _, _, _, eng, x = setup
+    eng.feval(x)
+    torch.cuda.synchronize()
+    want = {"conv3_4": (256, 256, 256, 3), "conv4_3": (512, 512, 128, 1), "conv4_4": (512, 512, 128, 2), "conv5_1": (512, 512, 64, 0)}[layer]
+    cands = [s for s in eng.steps if s.kind == "conv" and (s.mod.in_channels, s.mod.out_channels) == want[:2] and eng.act[s.src].shape[2] == want[2]]
+    step = cands[want[3]] if len(cands) > want[3] else cands[-1]
+    mod = step.mod
+    g_out = eng.gbuf[step.dst]
+    g_in = eng.gbuf[step.src]
+    a_in = eng.act[step.src]
+    assert not g_out.is_meta and not a_in.is_meta and float(g_out.abs().max()) > 0
+    w_eff = mod.weight.detach().flip(2, 3).transpose(0, 1).contiguous()  # backward-data as a correlation
+    extra = None
+    for s2 in eng.steps:  # a content loss on the layer's input adds gw * 2 / N * (F - T) (ScaleGradients quirk: strength^2, loss.py:17-20)
+        if s2.kind == "content" and s2.src == step.src and "temporal" not in getattr(s2.mod, "name", ""):
+            gw = float(eng._coefficients(s2)[1])  # (--no_grad_norm in this module's setup: the gradient weight is the strength itself)
+            assert gw == float(s2.mod.strength)
+            extra = (gw * 2.0 / a_in.nelement(), s2.mod.target)
+    side = a_in.shape[2]
+    for y0, x0 in sorted({(0, 0), (side // 2 - 32, min(side // 2 - 16, side - 64)), (side - 64, side - 64)}):
+        mask = (a_in[:, :, y0:y0 + 64, x0:x0 + 64].cpu() > 0)
+        res = {}
+        for dt in (torch.float64, torch.float32):
+            r = _crop_reference(g_out, w_eff, None, y0, x0, 64, 1, dt)
+            if extra is not None:
+                r = r + extra[0] * (a_in[:, :, y0:y0 + 64, x0:x0 + 64].cpu().to(dt) - extra[1][:, :, y0:y0 + 64, x0:x0 + 64].cpu().to(dt))
+            res[dt] = r * mask
+        mine = g_in[:, :, y0:y0 + 64, x0:x0 + 64].cpu()
+        floor = rel_l2(res[torch.float32], res[torch.float64])
+        err = rel_l2(mine, res[torch.float64])
+        assert err <= max(1.5 * floor, 1e-7), (layer, (y0, x0), err, floor)
+        assert torch.equal(mine == 0, ~mask) or float(((mine == 0) != ~mask).sum()) <= 1e-4 * mine.numel()
+
+
 # ---------------------------------------------------------------------------------------------------------
 # BASELINE config 2 (512x512 L-BFGS), config 3 (stock scaling table up to 2048x2048 Adam), config 5 (NIN + covariance 1024)
 # ---------------------------------------------------------------------------------------------------------

@@ -8,8 +8,8 @@ import subprocess
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rr = sys.argv[1] if len(sys.argv) > 1 else "02"
-src = os.path.join(REPO, sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/r2fin")
+rr = sys.argv[1] if len(sys.argv) > 1 else "03"
+src = os.path.join(REPO, sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/r3fin")
 dst = os.path.join(REPO, "profiles")
 
 

@@ -1,5 +1,5 @@
 set -x
-R=$PWD; O=$R/gpurun_out/r2fin; mkdir -p $O
+R=$PWD; O=$R/gpurun_out/${ROUND_DIR:-r3fin}; mkdir -p $O
 python bench.py --steps 200 > $O/bench_graph.json 2> $O/bench_graph.err
 python bench.py --steps 100 --no_hip_graph --no_cpu_baseline --no_extra_sizes > $O/bench_eager.json 2>/dev/null
 cd /tmp; export TMPDIR=/tmp
@@ -17,10 +17,11 @@ python tools/pmc_summary.py $O/pmc_traffic.json $O/pmc_a $O/pmc_b $O/pmc_c $O/pm
 rm -rf $O/pmc_a $O/pmc_b $O/pmc_c $O/pmc_d
 for S in 256 512 724 1024 1448 2048; do python bench.py --size $S --steps 100 --no_cpu_baseline --no_extra_sizes 2>/dev/null >> $O/sizes_lbfgs.jsonl; done
 for S in 1024 1448 2048; do python bench.py --size $S --optimizer adam --steps 100 --no_cpu_baseline --no_extra_sizes 2>/dev/null >> $O/sizes_adam.jsonl; done
-python tools/run_configs.py --configs 2,3,4,5,6 --out gpurun_out/r2fin/configs.json > $O/configs.log 2>&1
+python tools/run_configs.py --configs 2,3,4,5,6 --out $O/configs.json > $O/configs.log 2>&1
 python tools/x3w_clock.py 512 512 128 > $O/clock_conv4_2.txt 2>&1
 python tools/x3w_clock.py 64 64 1024 > $O/clock_conv1_2.txt 2>&1
 python tools/bench_x3w.py 1024 5 10 > $O/x3_vs_x3w.txt 2>&1
+python tools/bench_wino.py 1024 5 10 > $O/x3w_vs_wino.txt 2>&1
 python tools/lbfgs_clock.py 196608 100 > $O/clock_lbfgs.txt 2>&1
 python tools/bench_fused_gram.py 1024 20 > $O/fused_gram.txt 2>&1
 python tools/stress_fused.py 100 > $O/stress_fused.txt 2>&1
