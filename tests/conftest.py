@@ -28,6 +28,16 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _library_state_is_per_test():
+    """The split-K policy of the convolutions follows a process-wide hint (maua_set_split_batch_hint: frames the caller plans per
+    launch); tests that plan frame batches must not change what later tests measure."""
+    yield
+    if torch.cuda.is_available():
+        import hip
+        hip.set_split_batch_hint(1)
+
+
 def make_cfg(**over):
     """Namespace with the reference's defaults for the fields the hot path reads (config.py:15-89)."""
     d = dict(

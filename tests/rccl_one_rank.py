@@ -47,7 +47,7 @@ before = [p.detach().clone() for p in net.parameters()]
 dist.broadcast_network(net, src=0)                            # ONE flat RCCL broadcast of the replica
 torch.cuda.synchronize()
 assert all(torch.equal(a, b.detach()) for a, b in zip(before, net.parameters()))
-assert sum(p.numel() for p in net.parameters() if p.dim() == 4) == 12944960   # conv weights through conv5_1
+assert sum(p.numel() for p in net.parameters()) == 12944960   # conv weights + biases through conv5_1: the 51.8 MB of SURVEY section 5
 content, style, init = synth.images(256)
 optim.set_content_targets(net, content, args)
 optim.set_style_targets(net, [style], args)

@@ -228,8 +228,13 @@ def test_full_size_backward_pass_gradients_against_fp64(setup, layer):
             assert gw == float(s2.mod.strength)
             extra = (gw * 2.0 / a_in.nelement(), s2.mod.target)
     side = a_in.shape[2]
+    # the gradient of a conv + ReLU output is kept pre-masked by whoever writes it last; the gradient of a POOLED map is not (the pool's
+    # backward pass applies the mask of its source while routing): conv5_1's input is pool4's output
+    producer = next(s2 for s2 in eng.steps if s2.kind in ("conv", "pool") and s2.dst == step.src)
+    premasked = producer.kind == "conv" and producer.relu
+    assert premasked == (layer != "conv5_1")
     for y0, x0 in sorted({(0, 0), (side // 2 - 32, min(side // 2 - 16, side - 64)), (side - 64, side - 64)}):
-        mask = (a_in[:, :, y0:y0 + 64, x0:x0 + 64].cpu() > 0)
+        mask = (a_in[:, :, y0:y0 + 64, x0:x0 + 64].cpu() > 0) if premasked else torch.ones(1, a_in.shape[1], 64, 64, dtype=torch.bool)
         res = {}
         for dt in (torch.float64, torch.float32):
             r = _crop_reference(g_out, w_eff, None, y0, x0, 64, 1, dt)
@@ -240,7 +245,8 @@ def test_full_size_backward_pass_gradients_against_fp64(setup, layer):
         floor = rel_l2(res[torch.float32], res[torch.float64])
         err = rel_l2(mine, res[torch.float64])
         assert err <= max(1.5 * floor, 1e-7), (layer, (y0, x0), err, floor)
-        assert torch.equal(mine == 0, ~mask) or float(((mine == 0) != ~mask).sum()) <= 1e-4 * mine.numel()
+        if premasked:
+            assert torch.equal(mine == 0, ~mask) or float(((mine == 0) != ~mask).sum()) <= 1e-4 * mine.numel()
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -396,7 +402,7 @@ def test_config3_adam_2048_evaluation_and_descent(weight_files):
 # ---------------------------------------------------------------------------------------------------------
 # BASELINE config 4 at its real size: 16 frames of 512x512 per launch (what one rank of the 64-frame job evaluates at once)
 # ---------------------------------------------------------------------------------------------------------
-def test_config4_sixteen_frames_of_512_in_one_batch(weight_files, monkeypatch):
+def test_config4_sixteen_frames_of_512_in_one_batch(weight_files, monkeypatch, request):
     """optim.optimize_frames on a full batch of the video workload (reference loop: style.py:192-290 minus flow; per frame
     optim.py:111-255): 16 x 512x512 through the convolutions at once (grid z = frame, split-K policy of the planned batch, four
     side streams, one D bank per frame), L-BFGS, every engine buffer poisoned with NaN first.  The first and the last frame are
@@ -406,7 +412,9 @@ def test_config4_sixteen_frames_of_512_in_one_batch(weight_files, monkeypatch):
     import models
     import optim
     import style as style_mod
+    import hip
     monkeypatch.setenv("MAUA_DEBUG_POISON", "1")
+    request.addfinalizer(lambda: hip.set_split_batch_hint(1))  # (the plan of 16 frames per launch is process-wide state of the library)
     S, B, N = 512, 16, 20
     assert style_mod.planned_frames(S) == B and style_mod.frames_per_batch(S) == B
     frames = synth.frames(B, S)
