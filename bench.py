@@ -82,7 +82,7 @@ def _host_description():
     return os.cpu_count() or 1, model
 
 
-def cpu_baseline(S, optimizer, iters=5, repeats=3):
+def cpu_baseline(S, optimizer, iters=5, repeats=3, model="vgg19"):
     """The CPU oracle (oracle/, a restatement of the reference's arithmetic on torch CPU ops) timed on this host's cores AT
     THE BENCHMARKED SIZE, no extrapolation: `repeats` runs of `iters` L-BFGS iterations (evaluate + two-loop update) from
     the same start, median.  The intra-op thread count is the fastest of a sweep of single evaluations up to nproc
@@ -98,7 +98,9 @@ def cpu_baseline(S, optimizer, iters=5, repeats=3):
                        style_layers="relu1_1,relu2_1,relu3_1,relu4_1,relu5_1", tv_weight=1e-3, temporal_weight=50.0,
                        content_weight=5.0, style_weight=100.0, use_covariance=False, normalize_gradients=True,
                        video_style_factor=100.0)
-    net = OracleNet(build_spec(cfg), synth.vgg19_state_dict())
+    if model == "nin":  # BASELINE config 5
+        cfg.model_file, cfg.content_layers, cfg.style_layers, cfg.use_covariance = "nin", "relu8", "relu1,relu3,relu5,relu7,relu9,relu11", True
+    net = OracleNet(build_spec(cfg), synth.nin_state_dict() if model == "nin" else synth.vgg19_state_dict())
     content, style, init = synth.images(S)
     net.capture_content(content)
     net.capture_style([style], [1.0])
@@ -352,6 +354,8 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--optimizer", default="lbfgs", choices=["lbfgs", "adam"])
     ap.add_argument("--history", type=int, default=100)
+    ap.add_argument("--model", default="vgg19", choices=["vgg19", "nin"],
+                    help="nin: BASELINE config 5 (NIN + --use_covariance, reference models.py:74-113, loss.py:87-89) instead of the headline")
     ap.add_argument("--no_prefill", action="store_true", help="do not fill the L-BFGS history before timing")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--hip_graph", action="store_true", help="(default) replay each iteration from a captured hipGraph")
@@ -370,7 +374,7 @@ def main():
     if a._wait_for_go and sys.stdin.readline().strip() != "go":  # exact-split child: the parent says when the GPU is free
         sys.exit(3)  # (the parent went away without asking)
     exact_child = None
-    if a.gpus == 1 and "WORLD_SIZE" not in os.environ and a.size == 1024 and not a.no_exact_split:
+    if a.gpus == 1 and "WORLD_SIZE" not in os.environ and a.size == 1024 and not a.no_exact_split and a.model == "vgg19":
         exact_child = start_exact_split_child(a.size, a.steps, a.warmup, a.history, a.optimizer)  # before the first GPU call
 
     import config
@@ -390,15 +394,18 @@ def main():
     S = a.size
 
     tmp = tempfile.mkdtemp(prefix="maua_bench_")
-    wfile = os.path.join(tmp, "vgg19_synth.pth")
-    torch.save(synth.vgg19_state_dict(), wfile)
+    nin = a.model == "nin"
+    wfile = os.path.join(tmp, "nin_synth.pth" if nin else "vgg19_synth.pth")
+    torch.save(synth.nin_state_dict() if nin else synth.vgg19_state_dict(), wfile)
     scaling = os.path.join(tmp, "scaling.json")
     with open(scaling, "w") as f:
         json.dump({"100000": {"gpu": "0", "multidevice": False}}, f)
     args = config.get_args(["--content", "c.png", "--style", "s.png", "--model_file", wfile, "--disable_check",
                             "--scaling_args", scaling, "--optimizer", a.optimizer, "--image_sizes", str(S),
                             "--num_iters", str(a.steps), "--seed", "0", "--no_hist_match", "--lbfgs_num_correction",
-                            str(a.history)])
+                            str(a.history)] +
+                           (["--use_covariance", "--style_layers", "relu1,relu3,relu5,relu7,relu9,relu11", "--content_layers", "relu8"]
+                            if nin else []))
     a.hip_graph = not a.no_hip_graph
     args.hip_graph = a.hip_graph
     optim.set_model_args(args, S)
@@ -451,18 +458,32 @@ def main():
             dist.barrier()
             repeats.append(dist.max_over_ranks(time.perf_counter() - t1))
     eager_ms = None
+    lbfgs_events = []
     if opt.engine is not None and a.hip_graph and rank == 0:
         opt.engine.timer = timer
+        if a.optimizer == "lbfgs":  # the five launches of one maua_lbfgs_iterate call, bracketed together (HIP events, launch stream)
+            real_iterate = opt.state.iterate
+
+            def timed_iterate(*args_, **kw):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out_ = real_iterate(*args_, **kw)
+                e1.record()
+                lbfgs_events.append((e0, e1))
+                return out_
+            opt.state.iterate = timed_iterate
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(a.steps):
             opt.step()
         torch.cuda.synchronize()
         eager_ms = (time.perf_counter() - t1) / a.steps * 1e3
+        if a.optimizer == "lbfgs":
+            opt.state.iterate = real_iterate
     if opt.engine is not None:
         opt.engine.timer = None
 
-    want_sizes = not a.no_extra_sizes and S == 1024
+    want_sizes = not a.no_extra_sizes and S == 1024 and a.model == "vgg19"
     if rank != 0:
         if want_sizes:  # every rank runs the other sizes on its own GPU (north_star: 512x512 at 1, 2, 4 and 8 GPUs too)
             del opt
@@ -548,6 +569,36 @@ def main():
                        "frac_hbm_peak": round((work["bytes_feval"] + (work["bytes_lbfgs"] if a.optimizer == "lbfgs" else 0)) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         "roofline": roofline,
     }
+    if nin:
+        # BASELINE config 5.  Its dominant kernels are the two L-BFGS history sweeps (a third of the iteration: profiles/): HBM roofline.
+        # Algorithmic bytes of one update: (4 m + 10) n 4 B (the two-loop recursion touches 2 m vectors twice + ~10
+        # vector passes), n = 3 S^2, m = pairs held; measured with HIP events around the five launches of maua_lbfgs_iterate.
+        n_px, m_hist = 3 * S * S, int(status.get("history_len") or a.history)
+        lb_bytes = (4 * m_hist + 10) * n_px * 4
+        out["metric"] = f"optimizer iterations/sec at {S}x{S} NIN + covariance (BASELINE config 5)"
+        out["config"]["workload"] = (f"{S}x{S} NIN (models.py:74-113) + --use_covariance, style relu1,3,5,7,9,11 / content relu8, "
+                                     f"{a.optimizer.upper()} history {m_hist}, one image per GPU, seeded synthetic weights and images")
+        flops5, bytes5 = (115.9e9, 1.291e9) if S == 1024 else (None, None)  # SURVEY.md section 8d, config 5 work
+        out["model_flops_per_step"] = flops5
+        out["whole_step"] = None if flops5 is None else {
+            "tflops": round(flops5 / (ms * 1e-3) / 1e12, 2), "alg_gbs": round((bytes5 + lb_bytes) / (ms * 1e-3) / 1e9, 1),
+            "frac_hbm_peak": round((bytes5 + lb_bytes) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        conv_part = roofline
+        roofline = None
+        if lbfgs_events:
+            lb_ms = sum(e0.elapsed_time(e1) for e0, e1 in lbfgs_events) / len(lbfgs_events)
+            ach = lb_bytes / (lb_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": "lbfgs_pair_dots_kernel + lbfgs_combine_v4_kernel (the two history sweeps; the five launches of "
+                                                  "one maua_lbfgs_iterate bracketed together)",
+                        "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                        "algorithmic_bytes_per_launch": lb_bytes, "avg_launch_ms": round(lb_ms, 4), "launches": len(lbfgs_events),
+                        "share_of_step": round(lb_ms / ms, 3), "traffic": None,
+                        "traffic_note": "no PMC pass committed for this workload",
+                        "events_from": "second pass of K eager iterations (the timed region replays a hipGraph)",
+                        "eager_ms_per_step_with_events": round(eager_ms, 4) if eager_ms is not None else None,
+                        "matrix_kernels": None if conv_part is None else {
+                            k: conv_part[k] for k in ("per_kernel_ms_per_step", "per_kernel_tflops", "per_kernel_alg_gbs") if k in conv_part}}
+        out["roofline"] = roofline
     extra = {}
     if repeats:
         import statistics
@@ -572,7 +623,7 @@ def main():
     if extra:
         out["extra"] = extra
     if world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(S, a.optimizer)
+        out["cpu_baseline"] = cpu_baseline(S, a.optimizer, model=a.model)
     print(json.dumps(out), flush=True)
 
 
