@@ -361,6 +361,7 @@ def main():
     ap.add_argument("--hip_graph", action="store_true", help="(default) replay each iteration from a captured hipGraph")
     ap.add_argument("--no_hip_graph", action="store_true", help="launch every kernel eagerly in the timed region too")
     ap.add_argument("--no_extra_sizes", action="store_true", help="skip the 512x512 / 256x256 figures in `extra`")
+    ap.add_argument("--extra_sizes", default=None, help="comma-separated image sizes for `extra.other_sizes` (default: 512,256 next to a 1024 run)")
     ap.add_argument("--no_exact_split", action="store_true", help="skip the bf16x6 (MAUA_CONV_X3=0) figure in `extra`")
     ap.add_argument("--no_repeats", action="store_true", help="skip the repeated timed regions in `extra.repeats`")
     ap.add_argument("--repeats", type=int, default=5, help="further K-step regions timed after the headline one")
@@ -483,12 +484,13 @@ def main():
     if opt.engine is not None:
         opt.engine.timer = None
 
-    want_sizes = not a.no_extra_sizes and S == 1024 and a.model == "vgg19"
+    want_sizes = not a.no_extra_sizes and a.model == "vgg19" and (S == 1024 or a.extra_sizes is not None)
+    extra_sizes = [int(v) for v in (a.extra_sizes or "512,256").split(",") if v]
     if rank != 0:
         if want_sizes:  # every rank runs the other sizes on its own GPU (north_star: 512x512 at 1, 2, 4 and 8 GPUs too)
             del opt
-            for sz in (512, 256):
-                steady_rate(sz, max(a.steps, 100), a.optimizer, a.history)
+            for sz in extra_sizes:
+                steady_rate(sz, max(a.steps, 100) if a.extra_sizes is None else a.steps, a.optimizer, a.history)
         return
     status = opt.state.status() if a.optimizer == "lbfgs" else {}
     work = algorithmic_work(S, a.history)
@@ -616,7 +618,8 @@ def main():
         out["note_gpus"] = f"{a.requested_gpus} GPUs requested, {world} visible: ran on {world} (--allow_fewer)"
     if want_sizes:
         del opt  # frees the 2.5 GB history slab before the next job allocates its own
-        extra["other_sizes"] = [steady_rate(sz, max(a.steps, 100), a.optimizer, a.history) for sz in (512, 256)]
+        extra["other_sizes"] = [steady_rate(sz, max(a.steps, 100) if a.extra_sizes is None else a.steps, a.optimizer, a.history)
+                                for sz in extra_sizes]
     if exact_child is not None:
         torch.cuda.empty_cache()
         extra["exact_split"] = finish_exact_split_child(exact_child)

@@ -275,13 +275,18 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     env = dict(os.environ, MAUA_DIST_BACKEND="gloo")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                           "127.0.0.1", "--master-port", "29541", os.path.join(REPO, "bench.py"), "--gpus", "2", "--size", "128",
-                          "--steps", "4", "--warmup", "1", "--history", "5"], capture_output=True, text=True, env=env,
-                         timeout=900, cwd=str(tmp_path))
+                          "--steps", "4", "--warmup", "1", "--history", "5", "--extra_sizes", "64", "--repeats", "2"],
+                         capture_output=True, text=True, env=env, timeout=900, cwd=str(tmp_path))
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d
+    # the second size north_star names is measured at N > 1 too (every rank runs it, aggregated like the headline), the timed region is
+    # repeated, and the exact-split child is a single-GPU extra
+    other = d["extra"]["other_sizes"]
+    assert len(other) == 1 and other[0]["image_size"] == 64 and other[0]["n_gpus"] == 2 and other[0]["iterations_per_s"] > 0
+    assert d["extra"]["repeats"]["regions"] == 2 and "exact_split" not in d["extra"]
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) <= 1e-2 * d["value"]
     assert "x2" in d["config"]["parallelism"]
 
