@@ -528,7 +528,7 @@ extern "C" void maua_wn_set_stamp_buffer(float* buf) { g_wn_stamp = buf; }
 extern "C" {
 
 size_t maua_conv_wino_bank_bytes(int cout, int cin) {
-    if (cout <= 0 || cin <= 0) return 0;
+    if (cout <= 0 || cin <= 0 || cout > (1 << 20) || cin > (1 << 20)) return 0;  // (checked before any arithmetic on them)
     return (size_t)WN_BANK_HDR + (size_t)((cin + 15) / 16) * ((cout + WN_COT - 1) / WN_COT) * WN_U_BYTES;
 }
 

@@ -47,14 +47,15 @@ def main():
                  L.maua_conv_x6_bank_bytes(cout, cin), L.maua_conv_x3_bank_bytes(cout, cin), L.maua_conv_x3w_bank_bytes(cout, cin),
                  L.maua_conv_kxk_x3_bank_bytes(cout, cin, k), L.maua_gram_workspace_bytes(cin, h * w if abs(h * w) < 1 << 40 else 1),
                  L.maua_reduce_workspace_bytes(h * w), L.maua_lbfgs_state_bytes(h * w, rng.choice([1, 5, 100, 254, 255, 0, -1])),
-                 L.maua_channel_stats_workspace_bytes(h, w), L.maua_loss_ledger_bytes(n, cin)]
+                 L.maua_channel_stats_workspace_bytes(h, w), L.maua_loss_ledger_bytes(n, cin), L.maua_conv_wino_bank_bytes(cout, cin)]
         assert all(s >= 0 for s in sizes)
         if min(n, cin, cout, h, w) <= 0:
             assert sizes[1] == 0 and sizes[2] == 0 and sizes[3] == 0, (n, cin, cout, h, w, sizes)
         if min(cin, cout) <= 0:
-            assert sizes[6] == 0 and sizes[7] == 0 and sizes[8] == 0, (cin, cout, sizes)
+            assert sizes[6] == 0 and sizes[7] == 0 and sizes[8] == 0 and sizes[15] == 0, (cin, cout, sizes)
         L.maua_pool_out_size(h, rng.choice([2, 3, 0, -1]), rng.choice([2, 1, 0]), rng.randint(0, 1))
         L.maua_conv_x3w_supported(cin, h, w, pad)
+        L.maua_conv_wino_supported(cin, h, w, pad)
         assert L.maua_conv_x3w_split(n, cin, h, w, cout, pad) >= 0 and L.maua_conv_x3w_dmat_bank_bytes(cin) >= 0
         L.maua_conv_pack_dmat_x3w(None, cin, None, None, None)
         # compute entry points: null pointers and bad dims must be refused with a negative code before any launch; good
@@ -64,6 +65,7 @@ def main():
         ws_bytes = rng.choice([0, 1 << 10, 1 << 30])
         ptr = P if no_gpu else None
         rcs = [
+            L.maua_conv3x3_wino(ptr, ptr, ptr, None, ptr, n, cin, h, w, cout, pad, 1, 0, None),
             L.maua_conv3x3_x3w(ptr, ptr, 1.0, ptr, None, ptr, n, cin, h, w, cout, pad, 1, 0, ptr, ws_bytes, None),
             L.maua_conv3x3_x3w_relu_pool(ptr, ptr, 1.0, ptr, ptr, ptr, n, cin, h, w, cout, pad, None),
             L.maua_conv3x3_x3w_gram(ptr, ptr, 1.0, ptr, ptr, ptr, ptr, n, cin, h, w, cout, pad, 0, ptr, ws_bytes, None),
@@ -84,6 +86,8 @@ def main():
             L.maua_gram_fwd_mse_ledger(ptr, ptr, None, cin, h * w if abs(h * w) < 1 << 40 else 1, 1.0, 0, ptr, ptr, 1.0, 1.0, ptr,
                                        rng.choice([0, 3, -1]), ptr, ws_bytes, None),
             L.maua_loss_ledger_sum(ptr, n, cin, ptr, ptr, None),
+            L.maua_loss_ledger_sum_f64(ptr, n, cin, ptr, ptr, ptr, None),
+            L.maua_conv_pack_filters_wino(None, ptr, ptr, cout, cin, None),
             L.maua_gram_mse_ledger_supported(cin),
             L.maua_tv_fwd_bwd(ptr, ptr, n, cin, h, w, 1.0, 0, ptr, ptr, ws_bytes, None),
             L.maua_resize_bilinear(ptr, ptr, n, h, w, cout, cin, 0.5, 0.5, None),
@@ -91,7 +95,7 @@ def main():
             L.maua_lbfgs_iterate(ptr, ptr, ptr, None, h * w, rng.choice([1, 100, 254, 255]), 1.0, -1.0, -1.0, None),
         ]
         if min(n, cin, cout, h, w) <= 0:  # (the 1x1 entry takes the product h * w, which two negative extents make positive)
-            assert all(rc < 0 for rc in rcs[:8]), (n, cin, cout, h, w, rcs)
+            assert all(rc < 0 for rc in rcs[:9]), (n, cin, cout, h, w, rcs)
         checked += len(rcs) + len(sizes)
     L.maua_set_split_batch_hint(1)
     print(f"fuzz_abi_host: {n_cases} cases, {checked} calls, no sanitizer report, return codes consistent")
