@@ -257,6 +257,16 @@ int maua_gram_mse_ledger_supported(int c);
 int maua_gram_fwd_mse_ledger(const float* f, float* gram, float* row_mean_out, int c, int64_t hw, float scale, int center,
                              const float* target, float* dmat, float loss_scale, float grad_scale, double* ledger, int slot,
                              void* workspace, size_t workspace_bytes, maua_stream_t stream);
+/* The same chain in two calls, so that ONE finishing launch serves every style layer of an evaluation (their D matrices are needed only
+ * when the backward pass starts): maua_gram_partial leaves the split-K slabs of F F^T (and the row means, `center`) in the layer's OWN
+ * workspace (maua_gram_workspace_bytes, untouched until the batch call); maua_gram_finish_mse_batch (count <= 8 layers, host arrays of
+ * `count` entries) then does for each layer what maua_gram_fwd_mse_ledger's finishing launch does - gram, dmat, the ledger record of
+ * `slots[i]` in `ledgers[i]` - with the same arithmetic in the same order: bit-identical results. */
+int maua_gram_partial(const float* f, float* row_mean_out, int c, int64_t hw, int center, void* workspace, size_t workspace_bytes,
+                      maua_stream_t stream);
+int maua_gram_finish_mse_batch(int count, const void* const* workspaces, float* const* grams, const float* const* targets,
+                               float* const* dmats, const int* cs, const int64_t* hws, const float* scales, const float* loss_scales,
+                               const float* grad_scales, double* const* ledgers, const int* slots, maua_stream_t stream);
 int maua_loss_ledger_sum(double* ledger, int frames, int slots, float* losses, float* totals, maua_stream_t stream);
 /* The same launch, which also leaves every filled record's loss BEFORE its rounding to fp32 in losses_f64[frames][slots]
  * (`mod.loss` of optim.py:207-211 as a double; slots whose record is empty are not written): full-size derivative tests

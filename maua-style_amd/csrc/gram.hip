@@ -436,6 +436,68 @@ gram_finish_mse_kernel(const float* __restrict__ partial, float* __restrict__ gr
     }
 }
 
+// gram_finish_mse_kernel for up to GB_MAX style layers in ONE launch (grid z = layer; a layer's surplus workgroups leave at once):
+// the Gram / loss chains of an evaluation need their D matrices only when the backward pass starts, so their finishing passes - each a
+// latency-bound launch of a few microseconds of work - can all wait for the last partial kernel.  Same arithmetic, same summation
+// order, same ledger records as the per-layer launch: bit-identical results.
+constexpr int GB_MAX = 8;
+struct GramFinishBatch {
+    const float* partial[GB_MAX];
+    float* gram[GB_MAX];
+    const float* target[GB_MAX];
+    float* dmat[GB_MAX];
+    double* rec[GB_MAX];
+    int C[GB_MAX], ksplit[GB_MAX], kstride[GB_MAX], npairs[GB_MAX];
+    float scale[GB_MAX], grad_scale[GB_MAX], loss_scale[GB_MAX];
+};
+__global__ void __launch_bounds__(256) gram_finish_mse_batch_kernel(GramFinishBatch b) {
+    __shared__ double scratch[16];
+    const int z = blockIdx.z;
+    if ((int)blockIdx.x >= b.npairs[z]) return;  // (whole workgroup)
+    const int C = b.C[z], ksplit = b.ksplit[z], kstride = b.kstride[z];
+    int pair = blockIdx.x, ti = 0;
+    const int ntile = (C + GT - 1) / GT;
+    while (pair >= ntile - ti) {
+        pair -= ntile - ti;
+        ++ti;
+    }
+    const int tj = ti + pair;
+    const float* base = b.partial[z] + (int64_t)blockIdx.x * ksplit * (GT * GT);
+    const int e = blockIdx.y * 256 + threadIdx.x;
+    const int er = e / GT, ec = e % GT;
+    const int src = (ti == tj && er > ec) ? ec * GT + er : e;
+    double sd = 0.0;
+    for (int k = 0; k < ksplit; k += kstride) sd += (double)base[(int64_t)k * (GT * GT) + src];
+    const float s = (float)(sd * (double)b.scale[z]);
+    const int gi = ti * GT + er, gj = tj * GT + ec;
+    const float* __restrict__ target = b.target[z];
+    float* __restrict__ gram = b.gram[z];
+    float* __restrict__ dmat = b.dmat[z];
+    const float grad_scale = b.grad_scale[z];
+    double sq = 0.0;
+    if (gi < C && gj < C) {
+        const float d = s - target[(int64_t)gi * C + gj];
+        gram[(int64_t)gi * C + gj] = s;
+        dmat[(int64_t)gi * C + gj] = grad_scale * d;
+        sq = (double)d * (double)d;
+        if (ti != tj) {
+            const float dt = s - target[(int64_t)gj * C + gi];
+            gram[(int64_t)gj * C + gi] = s;
+            dmat[(int64_t)gj * C + gi] = grad_scale * dt;
+            sq += (double)dt * (double)dt;
+        }
+    }
+    sq = block_sum(sq, scratch);
+    if (threadIdx.x == 0) {
+        double* rec = b.rec[z];
+        rec[2 + blockIdx.x * gridDim.y + blockIdx.y] = sq;
+        if (blockIdx.x == 0 && blockIdx.y == 0) {
+            rec[0] = (double)(b.npairs[z] * gridDim.y);
+            rec[1] = (double)b.loss_scale[z];
+        }
+    }
+}
+
 // bias[c] = - sum_k D[k][c] * mean[k]   (the centering term of gf = D (F - mean 1^T)).  D is symmetric, so row c is
 // read instead of column c: one wave per output, coalesced loads, fixed-order wave reduction.
 __global__ void __launch_bounds__(256) center_bias_kernel(const float* __restrict__ d, const float* __restrict__ mean,
@@ -601,9 +663,11 @@ struct GramMse {  // the fused tail of maua_gram_fwd_mse_ledger (null target: pl
     double* rec;
 };
 
-static int gram_fwd_impl(const float* f, float* gram, float* row_mean_out, int c, int64_t hw, float scale, int center,
-                         void* workspace, size_t workspace_bytes, maua_stream_t stream, const GramMse& mse) {
-    MAUA_REQUIRE(f && gram && workspace && c > 0 && hw > 0 && c <= (1 << 16) && hw < (1ll << 30), MAUA_E_INVAL, "gram_fwd: bad args");
+// Row means (covariance form), the partial tiles of F F^T as split-K slabs in `workspace`, and - with many slabs - their first-level fold.
+// *kstride_out = distance between the slabs the finishing pass has to add.
+static int gram_partial_impl(const float* f, float* row_mean_out, int c, int64_t hw, int center, void* workspace, size_t workspace_bytes,
+                             maua_stream_t stream, int* npairs_out, int* ksplit_out, int* kstride_out) {
+    MAUA_REQUIRE(f && workspace && c > 0 && hw > 0 && c <= (1 << 16) && hw < (1ll << 30), MAUA_E_INVAL, "gram_fwd: bad args");
     MAUA_REQUIRE(!center || row_mean_out, MAUA_E_INVAL, "gram_fwd: center needs row_mean_out");
     MAUA_REQUIRE(workspace_bytes >= maua_gram_workspace_bytes(c, hw), MAUA_E_WORKSPACE, "gram_fwd: workspace %zu < %zu",
                  workspace_bytes, maua_gram_workspace_bytes(c, hw));
@@ -650,6 +714,19 @@ static int gram_fwd_impl(const float* f, float* gram, float* row_mean_out, int c
         if (rc) return rc;
         kstride = GF_FOLD;
     }
+    *npairs_out = npairs;
+    *ksplit_out = ksplit;
+    *kstride_out = kstride;
+    return MAUA_OK;
+}
+
+static int gram_fwd_impl(const float* f, float* gram, float* row_mean_out, int c, int64_t hw, float scale, int center,
+                         void* workspace, size_t workspace_bytes, maua_stream_t stream, const GramMse& mse) {
+    MAUA_REQUIRE(gram, MAUA_E_INVAL, "gram_fwd: bad args");
+    int npairs, ksplit, kstride;
+    int rc = gram_partial_impl(f, row_mean_out, c, hw, center, workspace, workspace_bytes, stream, &npairs, &ksplit, &kstride);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
     if (mse.target) {
         hipLaunchKernelGGL(gram_finish_mse_kernel, dim3(npairs, GT * GT / 256), dim3(256), 0, s, (const float*)workspace, gram, c,
                            ksplit, kstride, scale, mse.target, mse.dmat, mse.grad_scale, mse.loss_scale, mse.rec);
@@ -679,6 +756,47 @@ int maua_gram_fwd_mse_ledger(const float* f, float* gram, float* row_mean_out, i
                  c, LEDGER_MAX);
     GramMse m{target, dmat, loss_scale, grad_scale, ledger + (int64_t)slot * LEDGER_STRIDE};
     return gram_fwd_impl(f, gram, row_mean_out, c, hw, scale, center, workspace, workspace_bytes, stream, m);
+}
+
+int maua_gram_partial(const float* f, float* row_mean_out, int c, int64_t hw, int center, void* workspace, size_t workspace_bytes,
+                      maua_stream_t stream) {
+    int npairs, ksplit, kstride;
+    return gram_partial_impl(f, row_mean_out, c, hw, center, workspace, workspace_bytes, stream, &npairs, &ksplit, &kstride);
+}
+
+int maua_gram_finish_mse_batch(int count, const void* const* workspaces, float* const* grams, const float* const* targets,
+                               float* const* dmats, const int* cs, const int64_t* hws, const float* scales, const float* loss_scales,
+                               const float* grad_scales, double* const* ledgers, const int* slots, maua_stream_t stream) {
+    MAUA_REQUIRE(count > 0 && count <= GB_MAX && workspaces && grams && targets && dmats && cs && hws && scales && loss_scales &&
+                     grad_scales && ledgers && slots,
+                 MAUA_E_INVAL, "gram_finish_mse_batch: bad args (at most %d layers per call)", GB_MAX);
+    GramFinishBatch b{};
+    int max_pairs = 0;
+    for (int i = 0; i < count; ++i) {
+        MAUA_REQUIRE(workspaces[i] && grams[i] && targets[i] && dmats[i] && ledgers[i] && slots[i] >= 0 && slots[i] < (1 << 28) &&
+                         cs[i] > 0 && cs[i] <= (1 << 16) && hws[i] > 0 && hws[i] < (1ll << 30),
+                     MAUA_E_INVAL, "gram_finish_mse_batch: bad args for layer %d", i);
+        MAUA_REQUIRE(maua_gram_mse_ledger_supported(cs[i]), MAUA_E_UNSUPPORTED, "gram_finish_mse_batch: %d channels need more than %d partial sums",
+                     cs[i], LEDGER_MAX);
+        int npairs, ksplit;
+        int64_t chunk;
+        gram_plan(cs[i], hws[i], &npairs, &ksplit, &chunk);
+        b.partial[i] = (const float*)workspaces[i];
+        b.gram[i] = grams[i];
+        b.target[i] = targets[i];
+        b.dmat[i] = dmats[i];
+        b.rec[i] = ledgers[i] + (int64_t)slots[i] * LEDGER_STRIDE;
+        b.C[i] = cs[i];
+        b.ksplit[i] = ksplit;
+        b.kstride[i] = ksplit > 2 * GF_FOLD ? GF_FOLD : 1;
+        b.npairs[i] = npairs;
+        b.scale[i] = scales[i];
+        b.grad_scale[i] = grad_scales[i];
+        b.loss_scale[i] = loss_scales[i];
+        max_pairs = npairs > max_pairs ? npairs : max_pairs;
+    }
+    hipLaunchKernelGGL(gram_finish_mse_batch_kernel, dim3(max_pairs, GT * GT / 256, count), dim3(256), 0, (hipStream_t)stream, b);
+    return check_launch("gram_finish_mse_batch_kernel");
 }
 
 int maua_gram_bwd(const float* d_sym, const float* f, const float* row_mean, const float* relu_mask, float* gf, int c,

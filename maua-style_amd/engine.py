@@ -166,6 +166,10 @@ class StyleEngine:
         self.slots_f64 = None  # tests set this (zeros_like(slots_all, dtype=float64)): the losses before their rounding to fp32
         if (B == 1 or self.independent) and os.environ.get("MAUA_LOSS_LEDGER", "1") != "0":
             self.ledger = hip.loss_ledger(B, n_slots, dev)
+        # Gram / loss chains of a single image: split-K slabs per layer, ONE finishing launch per evaluation (MAUA_GRAM_BATCH=0: a
+        # finishing launch per layer, the round-2 form; same bits)
+        self.gram_batch_on = os.environ.get("MAUA_GRAM_BATCH", "1") != "0"
+        self._gram_wsp, self._gram_batches = getattr(self, "_gram_wsp", {}), {}
         # conv + ReLU whose only consumer is a 2x2 / 2 max pool with kept decisions, on conv_x3w.hip in one pass over the
         # channels: the pool runs in the convolution's epilogue and the full-size activation is never written (nothing reads
         # it: the backward pass routes by the decision bytes).  fused_pool[conv step] = pool step.
@@ -340,6 +344,15 @@ class StyleEngine:
             ev.record(st)
             cur.wait_event(ev)
 
+    def _gram_ws(self, s, c, hw, dev):
+        """The style layer's own split-K workspace (its slabs wait for the batched finishing launch)."""
+        need = hip.gram_workspace_bytes(c, hw)
+        t = self._gram_wsp.get(id(s))
+        if t is None or t.numel() < need or t.device != dev:
+            t = torch.empty(need, dtype=torch.uint8, device=dev)
+            self._gram_wsp[id(s)] = t
+        return t
+
     def frame_stream(self, b):
         """(context manager selecting frame b's stream, that stream's workspace): the current stream and the shared workspace
         when side streams are off."""
@@ -381,6 +394,7 @@ class StyleEngine:
         a[0] = x
         hip.fill_(self.slots_all, 0.0)
         forked = False
+        batch = []
         # ---------------- forward
         for s in self.steps:
             if s.kind == "conv":
@@ -478,6 +492,18 @@ class StyleEngine:
                     else:
                         ctx, wsb = contextlib.nullcontext(), self.ws
                     with ctx:
+                        if self.gram_batch_on and not forked:
+                            # (large images keep the per-layer form: their chains run on the side stream beside the convolutions, finishing
+                            #  launches included - batching those would expose them at the join in front of the backward pass)
+                            # only the split-K slabs now (into the layer's own workspace); ONE finishing launch for all style layers
+                            # of the evaluation follows the forward pass (their D matrices are not needed before the backward pass)
+                            gws = self._gram_ws(s, c, n // c, f.device)
+                            self._timed("gram_fwd", 2 * c * c * (n // c), n * 4 + c * c * 4, lambda: hip.gram_partial(
+                                f, s.mod.use_covariance, self.mean[id(s)], gws))
+                            batch.append(dict(step=s, workspace=gws, gram=self.gram[id(s)], target=s.mod.target, dmat=self.dmat[id(s)], c=c,
+                                              hw=n // c, scale=1.0 / n, loss_scale=lw / (c * c), grad_scale=gw * 4.0 / (c * c) / n,
+                                              ledger=self.ledger[0], slot=s.slot))
+                            continue
                         self._timed("gram_fwd", 2 * c * c * (n // c), n * 4 + c * c * 4, lambda: hip.gram_fwd_mse_ledger(
                             f, 1.0 / n, s.mod.use_covariance, self.gram[id(s)], self.mean[id(s)], s.mod.target, self.dmat[id(s)],
                             lw / (c * c), gw * 4.0 / (c * c) / n, self.ledger[0], s.slot, workspace=wsb))
@@ -490,6 +516,21 @@ class StyleEngine:
                                 False, self.slots[s.slot:s.slot + 1], workspace=self.ws)
                 if id(s) in self.fused_style:
                     hip.conv_pack_dmat_x3w(self.dmat[id(s)], self.fused_style[id(s)][1][0], self.fused_style[id(s)][2])
+        if batch:  # the finishing pass of every style layer's Gram / loss chain in one launch (groups of eight), then the D banks
+            if batch:
+                for k0 in range(0, len(batch), 8):
+                    grp = batch[k0:k0 + 8]
+                    key = tuple((id(l["step"]), l["target"].data_ptr(), l["workspace"].data_ptr(), l["gram"].data_ptr(), l["dmat"].data_ptr(),
+                                 l["ledger"].data_ptr(), l["slot"], l["loss_scale"], l["grad_scale"]) for l in grp)
+                    fin = self._gram_batches.get(k0)
+                    if fin is None or fin[0] != key:
+                        fin = (key, hip.GramFinishBatch(grp))
+                        self._gram_batches[k0] = fin
+                    self._timed("gram_fwd", 0, sum(l["c"] * l["c"] * 8 for l in grp), fin[1].run)
+                for l in batch:
+                    if id(l["step"]) in self.fused_style:
+                        fs = self.fused_style[id(l["step"])]
+                        hip.conv_pack_dmat_x3w(l["dmat"], fs[1][0], fs[2])
         # ---------------- backward
         # Gradient buffers of fused conv+ReLU activations are kept PRE-MASKED: the last kernel that writes g[k] (the
         # backward of the consumer, or the last loss term attached to k) zeroes it where a[k] <= 0, so no backward-data

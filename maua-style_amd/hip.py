@@ -87,6 +87,8 @@ SIGNATURES = {
     "maua_tv_fwd_bwd_ledger": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_i, c_p]),
     "maua_gram_mse_ledger_supported": (c_i, [c_i]),
     "maua_gram_fwd_mse_ledger": (c_i, [c_p, c_p, c_p, c_i, c_i64, c_f, c_i, c_p, c_p, c_f, c_f, c_p, c_i, c_p, c_sz, c_p]),
+    "maua_gram_partial": (c_i, [c_p, c_p, c_i, c_i64, c_i, c_p, c_sz, c_p]),
+    "maua_gram_finish_mse_batch": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "maua_loss_ledger_sum": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p]),
     "maua_loss_ledger_sum_f64": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
     "maua_lbfgs_state_bytes": (c_sz, [c_i64, c_i]),
@@ -531,6 +533,38 @@ def gram_fwd_mse_ledger(f, scale, center, out, mean_out, target, dmat, loss_scal
                                           float(grad_scale), ledger.data_ptr(), int(slot), workspace.data_ptr(),
                                           workspace.numel() * workspace.element_size(), _stream()), "maua_gram_fwd_mse_ledger")
     return out
+
+
+def gram_partial(f, center, mean_out, workspace):
+    """First half of gram_fwd_mse_ledger: the split-K slabs of F F^T (and the row means) into the layer's own `workspace`."""
+    c = f.shape[1] if f.dim() == 4 else f.shape[0]
+    hw = f.numel() // c
+    _check(lib().maua_gram_partial(_ptr(_f32(f, "f")), _ptr(mean_out) if center else None, c, hw, int(center), workspace.data_ptr(),
+                                   workspace.numel() * workspace.element_size(), _stream()), "maua_gram_partial")
+
+
+class GramFinishBatch:
+    """Second half for up to eight layers in one launch.  The argument arrays are built once (device addresses and coefficients of a
+    fixed engine plan) and reused by every evaluation."""
+
+    def __init__(self, layers):
+        """layers: list of dicts with workspace, gram, target, dmat, c, hw, scale, loss_scale, grad_scale, ledger (one frame's records), slot."""
+        n = len(layers)
+        self.n = n
+        self.keep = layers  # (the tensors must outlive the addresses)
+        arr = lambda ct, vals: (ct * n)(*vals)
+        self.args = (
+            arr(ctypes.c_void_p, [l["workspace"].data_ptr() for l in layers]), arr(ctypes.c_void_p, [_ptr(l["gram"]) for l in layers]),
+            arr(ctypes.c_void_p, [_ptr(_f32(l["target"], "target")) for l in layers]), arr(ctypes.c_void_p, [_ptr(l["dmat"]) for l in layers]),
+            arr(ctypes.c_int, [int(l["c"]) for l in layers]), arr(ctypes.c_int64, [int(l["hw"]) for l in layers]),
+            arr(ctypes.c_float, [float(l["scale"]) for l in layers]), arr(ctypes.c_float, [float(l["loss_scale"]) for l in layers]),
+            arr(ctypes.c_float, [float(l["grad_scale"]) for l in layers]), arr(ctypes.c_void_p, [l["ledger"].data_ptr() for l in layers]),
+            arr(ctypes.c_int, [int(l["slot"]) for l in layers]))
+
+    def run(self):
+        a = self.args
+        _check(lib().maua_gram_finish_mse_batch(self.n, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], _stream()),
+               "maua_gram_finish_mse_batch")
 
 
 def mse_fwd_bwd_ledger(x, target, grad, loss_scale, grad_scale, accumulate, ledger, slot, mask_grad_by_x=False):

@@ -1055,3 +1055,36 @@ def test_fused_launches_give_the_same_bits_every_time():
     import sys
     r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "stress_fused.py"), "40"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "TOTAL MISMATCHES 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_gram_finish_batch_equals_the_per_layer_launches(hip):
+    """maua_gram_partial + ONE maua_gram_finish_mse_batch over five style-layer shapes (covariance form among them, a layer with the
+    first-level slab fold) against maua_gram_fwd_mse_ledger per layer: Gram, D and the ledger losses bit for bit."""
+    shapes = [(64, 300 * 300, False), (128, 150 * 150, True), (256, 75 * 75, False), (512, 37 * 37, False), (96, 1000, True)]
+    led_a, led_b = hip.loss_ledger(1, 8, "cuda"), hip.loss_ledger(1, 8, "cuda")
+    layers, want = [], []
+    for k, (c, hw, center) in enumerate(shapes):
+        f = dev(torch.relu(rnd(1, c, hw, 1, seed=200 + k)))
+        t = dev(rnd(c, c, seed=300 + k) * 0.1)
+        ws = torch.empty(hip.gram_workspace_bytes(c, hw), dtype=torch.uint8, device="cuda")
+        g0, d0, m0 = torch.empty(c, c, device="cuda"), torch.empty(c, c, device="cuda"), torch.empty(c, device="cuda")
+        hip.gram_fwd_mse_ledger(f, 1.0 / (c * hw), center, g0, m0, t, d0, 0.5 / (c * c), 3.0 / (c * c), led_a[0], k, workspace=ws)
+        want.append((g0, d0, m0))
+        ws2 = torch.full_like(ws, 255)
+        g1, d1, m1 = torch.full_like(g0, float("nan")), torch.full_like(d0, float("nan")), torch.full_like(m0, float("nan"))
+        hip.gram_partial(f, center, m1, ws2)
+        layers.append(dict(workspace=ws2, gram=g1, target=t, dmat=d1, c=c, hw=hw, scale=1.0 / (c * hw), loss_scale=0.5 / (c * c),
+                           grad_scale=3.0 / (c * c), ledger=led_b[0], slot=k, mean=m1, center=center))
+    hip.GramFinishBatch(layers).run()
+    la, ta = torch.zeros(8, device="cuda"), torch.zeros(1, device="cuda")
+    lb, tb = torch.zeros(8, device="cuda"), torch.zeros(1, device="cuda")
+    hip.loss_ledger_sum(led_a, la, ta)
+    hip.loss_ledger_sum(led_b, lb, tb)
+    torch.cuda.synchronize()
+    for (g0, d0, m0), l in zip(want, layers):
+        assert torch.equal(g0, l["gram"]) and torch.equal(d0, l["dmat"])
+        if l["center"]:
+            assert torch.equal(m0, l["mean"])
+    assert torch.equal(la, lb) and torch.equal(ta, tb) and float(ta) > 0
+    with pytest.raises(hip.HipError):
+        hip.GramFinishBatch(layers + layers).run()       # at most eight layers per call
