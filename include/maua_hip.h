@@ -140,6 +140,18 @@ int maua_conv3x3_x3w_gram(const float* x, const void* bank, float w_scale, const
                           const float* dmat_inv_scale, float* y, int n, int cin, int h, int w, int cout, int pad, int accumulate,
                           void* workspace, size_t workspace_bytes, maua_stream_t stream);
 
+/* The backward-data pass of a 3x3 layer whose output went through ReLU + `nn.MaxPool2d(2, 2)` (models.py:120, 129-130), fused with
+ * that pool's backward pass (autograd's max_pool2d_with_indices_backward + threshold_backward): `pooled_x` is the gradient w.r.t. the
+ * POOLED map (n, cin, h / 2, w / 2), `codes` the pool's decision bytes (maua_conv3x3_x3w_relu_pool / maua_pool2x2_fwd_codes); the
+ * kernel stages element (y, x) of the full-size gradient as pooled_x[y / 2][x / 2] where the byte names that corner (and, with
+ * `honour_relu_bit`, the winning value was positive), 0 elsewhere - exactly what maua_pool2x2_bwd_codes would have written, which is
+ * then never written nor read.  h, w = the full-size plane (even); bank = the layer's backward bank, cin = channels of the gradient.
+ * out_relu_mask / dmat_bank / dmat_inv_scale (nullable) as in maua_conv3x3_x3w / maua_conv3x3_x3w_gram (with a bank, out_relu_mask is
+ * the feature map F).  Bit-identical to maua_pool2x2_bwd_codes followed by maua_conv3x3_x3w / _gram. */
+int maua_conv3x3_x3w_unpool(const float* pooled_x, const unsigned char* codes, int honour_relu_bit, const void* bank, float w_scale,
+                            const float* out_relu_mask, const void* dmat_bank, const float* dmat_inv_scale, float* y, int n, int cin,
+                            int h, int w, int cout, int pad, void* workspace, size_t workspace_bytes, maua_stream_t stream);
+
 /* ---- KS x KS stride-1 convolution in the same fp16x3 arithmetic (conv_kxk_x3.hip; KS = 5: NIN's conv2, models.py:86).
  *      Banks as for maua_conv_pack_filters_x3 with KS*KS taps; backward-data of a pad-p conv: bank_bwd, cin/cout exchanged,
  *      pad KS-1-p.  workspace (nullable) as for maua_conv3x3_x6: lets small output grids split the channel loop. ---- */
@@ -179,7 +191,9 @@ int maua_pool2d_bwd(const float* gy, const float* x, float* gx, int n, int c, in
 /* 2x2 stride-2 max pooling on even planes (every VGG pool, `nn.MaxPool2d(2, 2)` models.py:120) with the decision kept: the
  * forward pass also writes one byte per window (bits 1:0 = position of the first maximum in scan order, ATen's tie rule; bit 2
  * = the winning value is <= 0), the backward pass routes the gradient from those bytes without reading the input map again;
- * `relu_mask` as in maua_pool2d_bwd's relu_mask_by_x.  Bit-identical to maua_pool2d_fwd / maua_pool2d_bwd. */
+ * `relu_mask` as in maua_pool2d_bwd's relu_mask_by_x.  Bit-identical to maua_pool2d_fwd / maua_pool2d_bwd.
+ * The bytes are laid out [image][c / 8][pooled pixel][c % 8] (n * c * h / 2 * w / 2 bytes, c % 8 == 0): the eight channels a staging
+ * item of maua_conv3x3_x3w_unpool consumes are one 8-byte load. */
 int maua_pool2x2_codes_supported(int n, int c, int h, int w);
 int maua_pool2x2_fwd_codes(const float* x, float* y, unsigned char* codes, int n, int c, int h, int w, maua_stream_t stream);
 int maua_pool2x2_bwd_codes(const float* gy, const unsigned char* codes, float* gx, int n, int c, int h, int w, int relu_mask,

@@ -108,6 +108,9 @@ struct ConvArgs {
                                 // `y` is the POOLED map and these are its decision bytes (pool2x2_fwd_codes_kernel's)
     const void* dbank;   // conv_x3w, nullable: packed Cout x Cout matrix D (maua_conv_pack_dmat_x3w); the kernel adds D . omask
     const float* dinv;   //   (the Gram backward of the style loss on this layer's output) to its sums; dinv[0] = 1 / scale of the bank
+    const unsigned char* in_codes;  // conv_x3w backward, nullable: `x` is the pooled map [Cin][H/2][W/2] of a 2x2 / 2 max pool and these are its
+    int in_code_mask;               //   decision bytes; the kernel reads x as the pool's backward pass over them: element (y, x) =
+                                    //   pooled[y/2][x/2] if (code & in_code_mask) == 2 (y & 1) + (x & 1) else 0  (mask 7: ReLU bit honoured, 3: not)
 };
 int split_batch_hint();  // conv_api.hip: frames per launch the caller plans with (split-K cost models), >= 1
 int conv_mfma_dispatch(const ConvArgs& a, int ks, int n, hipStream_t stream);

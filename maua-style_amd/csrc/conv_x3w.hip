@@ -32,6 +32,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 constexpr int XW_COT = 64;
 constexpr int XW_ROWS = 8, XW_PR = 10, XW_PC = 34;
@@ -154,7 +155,9 @@ __global__ void __launch_bounds__(1024) pack_dmat_x3w_kernel(const float* __rest
 #define XW_MARK(k) do {} while (0)
 #endif
 
-template <bool ACC, bool OM, bool POOL = false>
+// UNPOOL: `x` is the POOLED map of a 2x2 / 2 max pool and `in_codes` its decision bytes; the input the convolution sees is the pool's
+// backward pass over them (pool2x2_bwd_codes_kernel's arithmetic), rebuilt while staging - the full-size gradient never exists.
+template <bool ACC, bool OM, bool POOL = false, bool UNPOOL = false>
 __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_inv_scale) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[XW_PATCH_BYTES + XW_W_BYTES + 16];
     unsigned char* Pl = smem;                    // [part][octet][pos][16 B]
@@ -164,6 +167,7 @@ __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_in
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, half = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
     const int n = blockIdx.z / ksplit, split = blockIdx.z - n * ksplit;
     const int cotile = blockIdx.y;
@@ -171,7 +175,11 @@ __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_in
     const int ntile = gridDim.y;
     const int in_plane = p.H * p.W;
     const int64_t out_plane = (int64_t)p.OH * p.OW;
-    const float* __restrict__ xin = p.x + (int64_t)n * p.Cin * in_plane;
+    const int st_w = UNPOOL ? p.W >> 1 : p.W;                              // row pitch and plane of the array the patch is staged from
+    const int st_plane = UNPOOL ? (p.H >> 1) * (p.W >> 1) : in_plane;
+    const float* __restrict__ xin = p.x + (int64_t)n * p.Cin * st_plane;
+    const unsigned char* __restrict__ xcodes = UNPOOL ? p.in_codes + (int64_t)n * p.Cin * st_plane : nullptr;
+    const unsigned code_mask = (unsigned)p.in_code_mask;
     // XCD-aware tile order (conv_x6.hip): XCD k owns the k-th contiguous band of tiles
     const int tiles_total = p.tiles_x * ((p.OH + XW_ROWS - 1) / XW_ROWS);
     const int per_xcd = (tiles_total + 7) >> 3;
@@ -182,22 +190,56 @@ __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_in
     // Staging items of this thread: item k = (octet, position) number tid + 256 k.  voff = byte offset of the item's first
     // channel from the chunk's first plane; out-of-image positions and items past the end get an offset beyond the buffer's
     // range, for which a buffer load returns 0 (no selects on the values).
+    //
+    // UNPOOL: one item per thread, and it is a POOLED element - (octet, pooled row, pooled column) number tid of the 2 x 6 x 18 pooled
+    // elements whose 2x2 windows cover the 10 x 34 patch.  The thread loads its eight channels and their eight decision bytes (one
+    // 8-byte load from the [octet][pooled pixel][8] layout), splits the eight values once, and writes each of the window's four
+    // corners that lies inside the patch: channel c's halves where the byte names that corner, zero elsewhere - the patch in LDS is
+    // bit for bit what staging pool2x2_bwd_codes_kernel's output would have left (a quarter of the loads and splits, no full-size
+    // gradient in memory).
     unsigned voff[3], lds_w[3];
+    unsigned vcode = 0x80000000u, inmask = 0;  // UNPOOL: offset of the item's decision bytes; bit q = corner q (2 dy + dx) is a patch position
+    if constexpr (UNPOOL) {
+        constexpr int PR = XW_ROWS / 2 + 2, PCW = 18;  // pooled rows / columns under the patch (any pad in 0 ... 2)
+        const int oct = tid >= PR * PCW ? 1 : 0;
+        const int rem = tid - oct * PR * PCW;
+        const int pr = rem / PCW, pc = rem - pr * PCW;
+        const int ppy = ((y0 - p.pad) >> 1) + pr, ppx = ((x0 - p.pad) >> 1) + pc;  // (arithmetic shifts: floor for the -1 / -2 of the first tiles)
+        const bool item = tid < 2 * PR * PCW;
+        const bool ok = item && ppy >= 0 && ppy < (p.H >> 1) && ppx >= 0 && ppx < st_w;
+        const int pidx = ppy * st_w + ppx;
+        voff[0] = ok ? (unsigned)(oct * 8 * st_plane + pidx) * 4u : 0x80000000u;
+        vcode = ok ? (unsigned)(oct * st_plane + pidx) * 8u : 0x80000000u;
+        const int r0 = 2 * ppy - (y0 - p.pad), c0 = 2 * ppx - (x0 - p.pad);  // patch position of the window's first corner (-1 ... )
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int idx = tid + 256 * k;
-        const int oct = idx >= XW_NPOS ? 1 : 0;
-        const int pos = idx - oct * XW_NPOS;
-        const int r = pos / XW_PC, c = pos - r * XW_PC;
-        const int iy = y0 + r - p.pad, ix = x0 + c - p.pad;
-        const bool ok = idx < XW_ITEMS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        voff[k] = ok ? (unsigned)(oct * 8 * in_plane + iy * p.W + ix) * 4u : 0x80000000u;
-        lds_w[k] = (unsigned)(oct * XW_PLANE + pos * 16);
+        for (int q = 0; q < 4; ++q) {
+            const int r = r0 + (q >> 1), c = c0 + (q & 1);
+            if (item && r >= 0 && r < XW_ROWS + 2 && c >= 0 && c < XW_PC) inmask |= 1u << q;
+        }
+        lds_w[0] = (unsigned)(oct * XW_PLANE + (r0 * XW_PC + c0) * 16);  // (of corner 0; only ever used plus a corner's offset, for corners inside)
+        voff[1] = voff[2] = 0x80000000u;
+        lds_w[1] = lds_w[2] = 0;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int idx = tid + 256 * k;
+            const int oct = idx >= XW_NPOS ? 1 : 0;
+            const int pos = idx - oct * XW_NPOS;
+            const int r = pos / XW_PC, c = pos - r * XW_PC;
+            const int iy = y0 + r - p.pad, ix = x0 + c - p.pad;
+            const bool ok = idx < XW_ITEMS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            voff[k] = ok ? (unsigned)(oct * 8 * in_plane + iy * p.W + ix) * 4u : 0x80000000u;
+            lds_w[k] = (unsigned)(oct * XW_PLANE + pos * 16);
+        }
     }
     // buffer resource over 16 planes from the chunk's first one: the range check sees the vector offset only
-    const unsigned range = (unsigned)in_plane * 64u;
-    float rp[3][8];
-    u32x4 hl[3][2];  // the split chunk waiting for its LDS write: [item][part]
+    const unsigned range = (unsigned)in_plane * 64u;    // (planes of the layer's own size: the fused Gram backward's F)
+    const unsigned range_x = (unsigned)st_plane * 64u;  // planes of the staged array
+    constexpr int NI = UNPOOL ? 1 : 3;  // staging items per thread
+    float rp[NI][8];
+    u32x2 cd = {0u, 0u};  // UNPOOL: the item's decision bytes
+    unsigned sel2[4];     // UNPOOL: the decisions two per register (16-bit lanes, channels 2 i and 2 i + 1), ReLU bit masked as asked
+    u32x4 hl[3][2];  // the split chunk waiting for its LDS write: [item][part]  (UNPOOL: [0], [1] = corners 0 and 1, [2] = the unmasked split)
     // The chunk list of a workgroup: the layer's input in 16-channel chunks, then (fused Gram backward) the 16-channel chunks
     // of the layer's OUTPUT-side feature map F = omask, which meet the one-tap bank of D.
     const int nmain = p.Cin / 16;
@@ -205,21 +247,38 @@ __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_in
     const float* __restrict__ fin = p.dbank ? p.omask + (int64_t)n * p.Cout * in_plane : nullptr;  // (same plane size: checked on the host)
     auto load_patch = [&](int ch) {
         asm volatile("" : "+s"(ch));
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin + (int64_t)ch * 16 * in_plane), 0, range, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin + (int64_t)ch * 16 * st_plane), 0, range_x, 0x00020000);
+        if constexpr (UNPOOL) {
+            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(xcodes + (int64_t)ch * 16 * st_plane), 0,
+                                                                                range_x >> 2, 0x00020000);
+            cd = __builtin_amdgcn_raw_buffer_load_b64(rc, vcode, 0, 0);
+        }
 #pragma unroll
         for (int c = 0; c < 8; ++c)
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
-                rp[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[k], c * in_plane * 4, 0));
+            for (int k = 0; k < NI; ++k)
+                rp[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[k], c * st_plane * 4, 0));
     };
     auto publish_max = [&]() {
+        if constexpr (UNPOOL) {
+            // A value counts (for the chunk's scale, and at all) where its byte names a corner that is a patch position - bit 2 of the
+            // byte, kept by code_mask = 7, names none.  What another tile's patch holds of this window is that tile's business.
+            const unsigned m2 = code_mask * 0x00010001u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sel2[i] = __builtin_amdgcn_perm(0u, cd[i >> 1], (i & 1) ? 0x0c030c02u : 0x0c010c00u) & m2;
+                const unsigned s0 = sel2[i] & 0xffffu, s1 = sel2[i] >> 16;
+                rp[0][2 * i] = ((inmask >> s0) & 1u) ? rp[0][2 * i] : 0.f;
+                rp[0][2 * i + 1] = ((inmask >> s1) & 1u) ? rp[0][2 * i + 1] : 0.f;
+            }
+        }
         float m = 0.f;
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+        for (int k = 0; k < NI; ++k)
 #pragma unroll
             for (int c = 0; c < 8; ++c) m = fmaxf(m, fabsf(rp[k][c]));
         m = wave_max_nonneg(m);
-        if (lane == 0) Ml[wave] = m;
+        if (lane == 0) Ml[UNPOOL ? wv : wave] = m;
     };
     // scale of the staged chunk: max in [2^11, 2^12) after scaling.  Returns the INVERSE scale, sets `sx`.
     float sx = 1.f;
@@ -230,20 +289,61 @@ __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_in
         sx = __builtin_bit_cast(float, (unsigned)(127 + 11 - e) << 23);
         return __builtin_bit_cast(float, (unsigned)(127 + e - 11) << 23);
     };
-    // split of one staged item in place: rp[k][0..3] <- packed high parts, rp[k][4..7] <- packed low parts (bit patterns)
+    // split of one staged item: hl[k][0] <- packed high parts, hl[k][1] <- packed low parts (bit patterns)
+    // UNPOOL: step 0 splits the item into hl[2]; step 1 cuts the vectors of corners 0 and 1 out of it (corners 2 and 3: store_patch, so
+    // that no more registers wait for the write than in the plain kernel)
+    auto corner_of = [&](int q, int part, int i) {  // dword i of corner q's vector: the halves of the channels whose byte names q
+        const unsigned t = sel2[i] ^ ((unsigned)q * 0x00010001u);                           // 16-bit lane == 0 where it does
+        const unsigned keep = ((t & 0xffffu) ? 0u : 0xffffu) | ((t >> 16) ? 0u : 0xffff0000u);
+        return hl[2][part][i] & keep;
+    };
     auto split_item = [&](int k) {
+        if constexpr (UNPOOL) {
+            if (k == 1) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        hl[q][0][i] = corner_of(q, 0, i);
+                        hl[q][1][i] = corner_of(q, 1, i);
+                    }
+            }
+            if (k > 0) return;
+        }
+        const int dst = UNPOOL ? 2 : k;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float v0 = rp[k][2 * q] * sx, v1 = rp[k][2 * q + 1] * sx;
             const unsigned H = xw_cvt_pk_f16(v0, v1);
             const unsigned Lo = xw_cvt_pk_f16(v0 - xw_f16_lo(H), v1 - xw_f16_hi(H));
-            hl[k][0][q] = H;
-            hl[k][1][q] = Lo;
+            hl[dst][0][q] = H;
+            hl[dst][1][q] = Lo;
         }
     };
     auto store_patch = [&]() {
+        if constexpr (UNPOOL) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
+            for (int q = 0; q < 4; ++q)
+                if ((inmask >> q) & 1u) {
+                    const unsigned dst = lds_w[0] + (unsigned)(((q >> 1) * XW_PC + (q & 1)) * 16);
+                    u32x4 h, l;
+                    if (q < 2) {
+                        h = hl[q][0];
+                        l = hl[q][1];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            h[i] = corner_of(q, 0, i);
+                            l[i] = corner_of(q, 1, i);
+                        }
+                    }
+                    *reinterpret_cast<u32x4*>(Pl + dst) = h;
+                    *reinterpret_cast<u32x4*>(Pl + 2 * XW_PLANE + dst) = l;
+                }
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
             if (k == 2 && tid >= XW_ITEMS - 512) break;
             *reinterpret_cast<u32x4*>(Pl + lds_w[k]) = hl[k][0];
             *reinterpret_cast<u32x4*>(Pl + 2 * XW_PLANE + lds_w[k]) = hl[k][1];
@@ -252,7 +352,6 @@ __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_in
 
     const unsigned char* __restrict__ bank = reinterpret_cast<const unsigned char*>(p.w6);
     // Filter slice of a chunk = 36 planes of 1 KiB in LDS order; wave w streams planes w, w + 4, ... (9 LDS-DMA instructions)
-    const int wv = __builtin_amdgcn_readfirstlane(wave);
     const unsigned lane16 = lane * 16;
     // planes [first, first + 4 count) of chunk ch, one per wave and step: taps 0-4 are planes 0-19 (5 per wave), taps 5-8 planes 20-35
     auto dma_filters = [&](int ch, int first, int count) {
@@ -535,7 +634,8 @@ __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_in
     if constexpr (POOL) {
         // ReLU + the 2x2 / 2 max pool behind it: a wave's two rows and neighbouring lanes are exactly the windows, so the
         // full-size activation never goes to memory - only the pooled map and one decision byte per window (what
-        // pool2x2_fwd_codes_kernel leaves: position of the first maximum in scan order, bit 2 = the maximum is <= 0).
+        // pool2x2_fwd_codes_kernel leaves: position of the first maximum in scan order, bit 2 = the maximum is <= 0; bytes laid out
+        // [octet of channels][pooled pixel][8 channels], Cout % 8 == 0).
         const int PW = p.OW >> 1;
         const int64_t pplane = (int64_t)(p.OH >> 1) * PW;
         float* __restrict__ py = p.y + (int64_t)n * p.Cout * pplane;
@@ -546,22 +646,26 @@ __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_in
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                float a = master[t][0][r], c = master[t][1][r];
-                a = a > 0.f ? a : 0.f;
-                c = c > 0.f ? c : 0.f;
-                const float b = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x101, 0xf, 0xf, false));  // row_shl:1
-                const float d = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c), 0x101, 0xf, 0xf, false));
-                float m = a;
-                int arg = 0;
-                if (b > m) { m = b; arg = 1; }
-                if (c > m) { m = c; arg = 2; }
-                if (d > m) { m = d; arg = 3; }
-                if (store && co < p.Cout) {
-                    py[(int64_t)co * pplane + ppix] = m;
-                    pc[(int64_t)co * pplane + ppix] = (unsigned char)(arg | (m > 0.f ? 0 : 4));
+            for (int q = 0; q < 4; ++q) {  // four consecutive channels per step: their decision bytes are one dword of the octet-interleaved layout
+                const int cq = co0 + t * 32 + 8 * q + 4 * half;
+                unsigned pk = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 4 * q + i;
+                    float a = master[t][0][r], c = master[t][1][r];
+                    a = a > 0.f ? a : 0.f;
+                    c = c > 0.f ? c : 0.f;
+                    const float b = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x101, 0xf, 0xf, false));  // row_shl:1
+                    const float d = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c), 0x101, 0xf, 0xf, false));
+                    float m = a;
+                    unsigned arg = 0;
+                    if (b > m) { m = b; arg = 1; }
+                    if (c > m) { m = c; arg = 2; }
+                    if (d > m) { m = d; arg = 3; }
+                    pk |= (arg | (m > 0.f ? 0u : 4u)) << (8 * i);
+                    if (store && cq < p.Cout) py[(int64_t)(cq + i) * pplane + ppix] = m;
                 }
+                if (store && cq < p.Cout) *reinterpret_cast<unsigned*>(pc + ((int64_t)(cq >> 3) * pplane + ppix) * 8 + 4 * half) = pk;
             }
         return;
     }
@@ -681,6 +785,8 @@ int conv_x3w_launch(const ConvArgs& a, int n, float w_scale, hipStream_t stream)
         p.stagger = stagger;
     }
     if (a.pool_codes) hipLaunchKernelGGL((conv_x3w_kernel<false, false, true>), grid, dim3(256), 0, stream, p, w_inv);
+    else if (a.in_codes && om) hipLaunchKernelGGL((conv_x3w_kernel<false, true, false, true>), grid, dim3(256), 0, stream, p, w_inv);
+    else if (a.in_codes) hipLaunchKernelGGL((conv_x3w_kernel<false, false, false, true>), grid, dim3(256), 0, stream, p, w_inv);
     else if (acc && om) hipLaunchKernelGGL((conv_x3w_kernel<true, true>), grid, dim3(256), 0, stream, p, w_inv);
     else if (acc) hipLaunchKernelGGL((conv_x3w_kernel<true, false>), grid, dim3(256), 0, stream, p, w_inv);
     else if (om) hipLaunchKernelGGL((conv_x3w_kernel<false, true>), grid, dim3(256), 0, stream, p, w_inv);
@@ -757,7 +863,8 @@ size_t maua_conv_x3w_workspace_bytes(int n, int cin, int h, int w, int cout, int
 
 static int conv3x3_x3w_entry(const float* x, const void* bank, float w_scale, const float* bias, const float* out_relu_mask, float* y,
                              int n, int cin, int h, int w, int cout, int pad, int relu, int accumulate, const void* dbank,
-                             const float* dinv, void* workspace, size_t workspace_bytes, maua_stream_t stream) {
+                             const float* dinv, void* workspace, size_t workspace_bytes, maua_stream_t stream,
+                             const unsigned char* in_codes = nullptr, int in_code_mask = 0) {
     MAUA_REQUIRE(x && bank && y && w_scale > 0.f, MAUA_E_INVAL, "conv3x3_x3w: bad args");
     MAUA_REQUIRE(conv_dims_ok(n, cin, h, w, cout, pad) && pad <= 2, MAUA_E_INVAL, "conv3x3_x3w: bad dims");
     MAUA_REQUIRE(h + 2 * pad >= 3 && w + 2 * pad >= 3, MAUA_E_UNSUPPORTED, "conv3x3_x3w: input smaller than the filter");
@@ -783,6 +890,11 @@ static int conv3x3_x3w_entry(const float* x, const void* bank, float w_scale, co
                      "conv3x3_x3w_gram: needs cout %% 16 == 0 and an output plane of the input's size");
         a.dbank = dbank;
         a.dinv = dinv;
+    }
+    if (in_codes) {
+        MAUA_REQUIRE(h % 2 == 0 && w % 2 == 0 && !accumulate, MAUA_E_UNSUPPORTED, "conv3x3_x3w_unpool: needs an even input plane, no accumulation");
+        a.in_codes = in_codes;
+        a.in_code_mask = in_code_mask;
     }
     a.ws = (workspace && workspace_bytes >= maua_conv_x3w_workspace_bytes(n, cin, h, w, cout, pad)) ? (float*)workspace : nullptr;
     return conv_x3w_launch(a, n, w_scale, (hipStream_t)stream);
@@ -824,8 +936,8 @@ int maua_conv3x3_x3w_relu_pool(const float* x, const void* bank, float w_scale, 
     a.OW = w + 2 * pad - 2;
     a.pad = pad;
     a.relu = 1;
-    MAUA_REQUIRE(a.OH >= 2 && a.OW >= 2 && a.OH % 2 == 0 && a.OW % 2 == 0 && conv_x3w_supports(a), MAUA_E_UNSUPPORTED,
-                 "conv3x3_x3w_relu_pool: needs an even output plane, cin %% 16 == 0");
+    MAUA_REQUIRE(a.OH >= 2 && a.OW >= 2 && a.OH % 2 == 0 && a.OW % 2 == 0 && cout % 8 == 0 && conv_x3w_supports(a), MAUA_E_UNSUPPORTED,
+                 "conv3x3_x3w_relu_pool: needs an even output plane, cin %% 16 == 0, cout %% 8 == 0");
     a.ws = nullptr;  // one pass over the channels: the epilogue holds complete sums
     return conv_x3w_launch(a, n, w_scale, (hipStream_t)stream);
 }
@@ -836,6 +948,14 @@ int maua_conv3x3_x3w_gram(const float* x, const void* bank, float w_scale, const
     MAUA_REQUIRE(dmat_bank, MAUA_E_INVAL, "conv3x3_x3w_gram: null bank");
     return conv3x3_x3w_entry(x, bank, w_scale, nullptr, feature_map, y, n, cin, h, w, cout, pad, 0, accumulate, dmat_bank,
                              dmat_inv_scale, workspace, workspace_bytes, stream);
+}
+
+int maua_conv3x3_x3w_unpool(const float* pooled_x, const unsigned char* codes, int honour_relu_bit, const void* bank, float w_scale,
+                            const float* out_relu_mask, const void* dmat_bank, const float* dmat_inv_scale, float* y, int n, int cin,
+                            int h, int w, int cout, int pad, void* workspace, size_t workspace_bytes, maua_stream_t stream) {
+    MAUA_REQUIRE(codes, MAUA_E_INVAL, "conv3x3_x3w_unpool: null decision bytes");
+    return conv3x3_x3w_entry(pooled_x, bank, w_scale, nullptr, out_relu_mask, y, n, cin, h, w, cout, pad, 0, 0, dmat_bank, dmat_inv_scale,
+                             workspace, workspace_bytes, stream, codes, honour_relu_bit ? 7 : 3);
 }
 
 }  // extern "C"

@@ -299,6 +299,12 @@ pool2x2_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x, fl
 // The same pair with the decision kept: the forward pass leaves one byte per window - the winner's position in scan order
 // (bits 1:0) and whether the winning value is <= 0 (bit 2: for a ReLU input, its threshold_backward) - so that the backward
 // pass routes the gradient without reading the input map again (pool1 at 1024x1024: 603 -> 352 MB).  Same decisions, same bits.
+// Layout of the bytes: [image][octet of channels][pooled pixel][channel within the octet] (C % 8 == 0) - the eight channels a staging
+// item of conv_x3w.hip consumes are one 8-byte load there (maua_conv3x3_x3w_unpool), and its pooling epilogue stores four at a time.
+__device__ __forceinline__ int64_t pool_code_index(int64_t image_channel, int64_t pooled_plane, int64_t pooled_pixel) {
+    return ((image_channel >> 3) * pooled_plane + pooled_pixel) * 8 + (image_channel & 7);  // (C % 8 == 0: n * C + c keeps c's low bits)
+}
+
 __global__ void __launch_bounds__(256)
 pool2x2_fwd_codes_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ codes, int W, int OW) {
     const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y;
@@ -313,7 +319,7 @@ pool2x2_fwd_codes_kernel(const float* __restrict__ x, float* __restrict__ y, uns
     if (r1.y > m || r1.y != r1.y) { m = r1.y; arg = 3; }
     const int64_t o = ((int64_t)blockIdx.z * OHl + oy) * OW + ox;
     y[o] = m;
-    codes[o] = (unsigned char)(arg | (m > 0.f ? 0 : 4));
+    codes[pool_code_index(blockIdx.z, OHl * OW, oy * (int64_t)OW + ox)] = (unsigned char)(arg | (m > 0.f ? 0 : 4));
 }
 
 __global__ void __launch_bounds__(256)
@@ -324,7 +330,7 @@ pool2x2_bwd_codes_kernel(const float* __restrict__ gy, const unsigned char* __re
     const int64_t OHl = gridDim.y;
     const int64_t base = ((int64_t)blockIdx.z * 2 * OHl + 2 * oy) * W + 2 * ox;
     const int64_t o = ((int64_t)blockIdx.z * OHl + oy) * OW + ox;
-    const int code = codes[o];
+    const int code = codes[pool_code_index(blockIdx.z, OHl * OW, oy * (int64_t)OW + ox)];
     const int arg = code & 3;
     float g = gy[o];
     if (relu_mask && (code & 4)) g = 0.f;
@@ -512,12 +518,12 @@ int maua_pool2d_bwd(const float* gy, const float* x, float* gx, int n, int c, in
 }
 
 int maua_pool2x2_codes_supported(int n, int c, int h, int w) {
-    return conv_dims_ok(n, c, h, w, 1, 0) && h % 2 == 0 && w % 2 == 0 && (int64_t)n * c <= 65535 && h / 2 <= 65535;
+    return conv_dims_ok(n, c, h, w, 1, 0) && h % 2 == 0 && w % 2 == 0 && c % 8 == 0 && (int64_t)n * c <= 65535 && h / 2 <= 65535;
 }
 
 int maua_pool2x2_fwd_codes(const float* x, float* y, unsigned char* codes, int n, int c, int h, int w, maua_stream_t stream) {
     MAUA_REQUIRE(x && y && codes, MAUA_E_INVAL, "pool2x2_fwd_codes: null pointer");
-    MAUA_REQUIRE(maua_pool2x2_codes_supported(n, c, h, w), MAUA_E_UNSUPPORTED, "pool2x2_fwd_codes: needs even planes");
+    MAUA_REQUIRE(maua_pool2x2_codes_supported(n, c, h, w), MAUA_E_UNSUPPORTED, "pool2x2_fwd_codes: needs even planes and c %% 8 == 0");
     hipLaunchKernelGGL(pool2x2_fwd_codes_kernel, dim3((w / 2 + 255) / 256, h / 2, n * c), dim3(256), 0, (hipStream_t)stream, x, y,
                        codes, w, w / 2);
     return check_launch("pool2x2_fwd_codes_kernel");
@@ -526,7 +532,7 @@ int maua_pool2x2_fwd_codes(const float* x, float* y, unsigned char* codes, int n
 int maua_pool2x2_bwd_codes(const float* gy, const unsigned char* codes, float* gx, int n, int c, int h, int w, int relu_mask,
                            maua_stream_t stream) {
     MAUA_REQUIRE(gy && gx && codes, MAUA_E_INVAL, "pool2x2_bwd_codes: null pointer");
-    MAUA_REQUIRE(maua_pool2x2_codes_supported(n, c, h, w), MAUA_E_UNSUPPORTED, "pool2x2_bwd_codes: needs even planes");
+    MAUA_REQUIRE(maua_pool2x2_codes_supported(n, c, h, w), MAUA_E_UNSUPPORTED, "pool2x2_bwd_codes: needs even planes and c %% 8 == 0");
     hipLaunchKernelGGL(pool2x2_bwd_codes_kernel, dim3((w / 2 + 255) / 256, h / 2, n * c), dim3(256), 0, (hipStream_t)stream, gy,
                        codes, gx, w, w / 2, relu_mask);
     return check_launch("pool2x2_bwd_codes_kernel");

@@ -187,6 +187,21 @@ class StyleEngine:
         for s in self.steps:  # (those activations exist as shapes only: 0.5 GB less at 1024x1024)
             if id(s) in self.fused_pool:
                 self.act[s.dst] = torch.empty(shapes[s.dst], device="meta")
+        # Such groups on the way back (whether or not the forward pass fused the pool: the decision bytes are the same): where the
+        # backward-data pass of the convolution runs on conv_x3w.hip, it stages its input straight from the pooled map's gradient and
+        # the decision bytes (hip.conv3x3_x3w_unpool) - the pool's backward launch and the full-size gradient it would write and the
+        # convolution read again do not exist.  fused_unpool[conv step] = pool step.
+        self.fused_unpool = {}
+        if self.x6_bwd and os.environ.get("MAUA_FUSE_UNPOOL", "1") != "0":
+            for s in self.steps:
+                if s.kind != "conv" or not s.relu or s.k != 3 or s.stride != 1 or s.pad != 1:
+                    continue
+                users = [t for t in self.steps if t.src == s.dst and t is not s]
+                if len(users) == 1 and users[0].kind == "pool" and id(users[0]) in self.pool_codes and \
+                        self._x6_ok(s, s.mod.in_channels) and models_mod.conv3x3_bwd_is_x3w(s.mod, *shapes[s.dst][2:]):
+                    self.fused_unpool[id(s)] = users[0]
+                    self.gbuf[s.dst] = torch.empty(shapes[s.dst], device="meta")
+        self.unpooled_by_conv = {id(v) for v in self.fused_unpool.values()}
         # Single images: where a style loss is the only loss on the input activation of a 3x3 layer whose backward-data pass runs
         # on conv_x3w.hip, that pass takes the Gram backward along (D . F as extra one-tap chunks of its K loop) instead of a
         # separate read-modify-write pass over the gradient map: fused_gram[conv step] = (style step, bank of D, 1 / scale).
@@ -653,7 +668,16 @@ class StyleEngine:
                 fl, nb = self._conv_work(s, a[s.src].shape, a[s.dst].shape, True)
                 im = a[s.src] if premask(s) else None
                 fg = self.fused_gram.get(id(s))
-                if fg is not None and self._active(fg[0], a[s.src].shape) and premask(fg[0]):
+                with_gram = fg is not None and self._active(fg[0], a[s.src].shape) and premask(fg[0])
+                up = self.fused_unpool.get(id(s))
+                if up is not None:  # from the pooled map's gradient and the pool's decisions (the pool step below was skipped)
+                    c, n = a[s.src].shape[1], a[s.src][0].nelement()
+                    self._timed("conv3x3_split_bwd", fl + (2 * c * c * (n // c) if with_gram else 0), nb, lambda: models_mod.conv3x3_bwd_from_pooled(
+                        g[up.dst], self.pool_codes[id(up)], premask(up), s.mod, g[s.src], out_relu_mask=a[s.src] if with_gram else im,
+                        dmat_bank=fg[1] if with_gram else None, dmat_inv_scale=fg[2] if with_gram else None, workspace=self.ws))
+                    if with_gram:
+                        fused_done.add(id(fg[0]))
+                elif with_gram:
                     c, n = a[s.src].shape[1], a[s.src][0].nelement()
                     self._timed("conv3x3_split_bwd", fl + 2 * c * c * (n // c), nb, lambda: models_mod.conv3x3_bwd_with_gram(
                         g[s.dst], s.mod, a[s.src], fg[1], fg[2], out=g[s.src], workspace=self.ws))
@@ -677,7 +701,9 @@ class StyleEngine:
                 hip.relu_bwd(g[s.src], a[s.src], out=g[s.src])
             elif s.kind == "pool":
                 assert cur == s.dst
-                if id(s) in self.pool_codes:
+                if id(s) in self.unpooled_by_conv:
+                    pass  # its backward pass happens in the staging of the convolution's (fused_unpool)
+                elif id(s) in self.pool_codes:
                     hip.pool2x2_bwd_codes(g[s.dst], self.pool_codes[id(s)], g[s.src], premask(s))
                 else:
                     hip.pool2d_bwd(g[s.dst], a[s.src], s.k, s.stride, s.ceil, s.mode, out=g[s.src],

@@ -78,6 +78,7 @@ SIGNATURES = {
     "maua_conv_x3w_dmat_bank_bytes": (c_sz, [c_i]),
     "maua_conv_pack_dmat_x3w": (c_i, [c_p, c_i, c_p, c_p, c_p]),
     "maua_conv3x3_x3w_gram": (c_i, [c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
+    "maua_conv3x3_x3w_unpool": (c_i, [c_p, c_p, c_i, c_p, c_f, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "maua_conv_wino_bank_bytes": (c_sz, [c_i, c_i]),
     "maua_conv_pack_filters_wino": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p]),
     "maua_conv_wino_supported": (c_i, [c_i, c_i, c_i, c_i]),
@@ -333,6 +334,24 @@ def conv3x3_x3w_gram(x, bank, w_scale, feature_map, dmat_bank, dmat_inv_scale, c
     _check(lib().maua_conv3x3_x3w_gram(_ptr(_f32(x, "x")), bank.data_ptr(), float(w_scale), _ptr(_f32(feature_map, "feature_map")),
                                        dmat_bank.data_ptr(), _ptr(dmat_inv_scale), _ptr(out), n, cin, h, w, cout, pad,
                                        int(accumulate), wp, wn, _stream()), "maua_conv3x3_x3w_gram")
+    return out
+
+
+def conv3x3_x3w_unpool(pooled_x, codes, honour_relu_bit, bank, w_scale, cout, pad, out=None, out_relu_mask=None, dmat_bank=None,
+                       dmat_inv_scale=None, workspace=None):
+    """Backward-data pass of a conv + ReLU + 2x2 max pool group straight from the POOLED gradient and the pool's decision bytes (the
+    pool's backward pass happens while the kernel stages its input); with `dmat_bank`, the Gram backward of the style loss on the
+    layer's input (out_relu_mask = F) goes along as in conv3x3_x3w_gram."""
+    n, cin, ph, pw = pooled_x.shape
+    h, w = 2 * ph, 2 * pw
+    if out is None:
+        out = torch.empty(n, cout, h + 2 * pad - 2, w + 2 * pad - 2, device=pooled_x.device, dtype=torch.float32)
+    wp, wn = _ws_args(workspace, conv_x3w_workspace_bytes(n, cin, h, w, cout, pad) if workspace is None else 0, pooled_x.device)
+    _check(lib().maua_conv3x3_x3w_unpool(_ptr(_f32(pooled_x, "pooled_x")), codes.data_ptr(), int(bool(honour_relu_bit)), bank.data_ptr(),
+                                         float(w_scale), _ptr(out_relu_mask) if out_relu_mask is not None else None,
+                                         dmat_bank.data_ptr() if dmat_bank is not None else None,
+                                         _ptr(dmat_inv_scale) if dmat_inv_scale is not None else None, _ptr(out), n, cin, h, w, cout, pad,
+                                         wp, wn, _stream()), "maua_conv3x3_x3w_unpool")
     return out
 
 

@@ -133,6 +133,16 @@ def conv3x3_bwd_with_gram(gy, mod, feature_map, dmat_bank, dmat_inv_scale, out, 
                                 workspace=workspace)
 
 
+def conv3x3_bwd_from_pooled(gy_pooled, codes, honour_relu_bit, mod, out, out_relu_mask=None, dmat_bank=None, dmat_inv_scale=None,
+                            workspace=None):
+    """Backward-data pass of a conv + ReLU + 2x2 max pool group from the gradient of the POOLED map and the pool's decision bytes
+    (hip.conv3x3_x3w_unpool): the pool's backward pass happens while the kernel stages its input; with `dmat_bank`, the Gram backward
+    of the style loss on the layer's input goes along (out_relu_mask = that activation)."""
+    _, bb, wsc = mod.banks3w()
+    return hip.conv3x3_x3w_unpool(gy_pooled, codes, honour_relu_bit, bb, wsc, mod.in_channels, 2 - mod.padding[0], out=out,
+                                  out_relu_mask=out_relu_mask, dmat_bank=dmat_bank, dmat_inv_scale=dmat_inv_scale, workspace=workspace)
+
+
 def conv1x1_is_mfma(mod, backward):
     """Whether a layer's pass runs on the fp16x3 1x1 kernel (conv1x1_x3.hip): 1x1, stride 1, no padding (NIN's cccp layers,
     reference models.py:84-110), the split-precision path enabled for that pass and fp16x3 selected."""

@@ -139,3 +139,10 @@ def write_video_fixture(root, n_frames=3, S=64):
                 rel = ((torch.rand(S, S, generator=g) > 0.2).float() * 255).byte().numpy()
                 Image.fromarray(rel, mode="L").save(os.path.join(flow_dir, f"{direction}_{a}_{b}.png"))
     return fdir, os.path.join(root, "out")
+
+
+def planar_codes(codes):
+    """The decision bytes of maua_pool2x2_fwd_codes / maua_conv3x3_x3w_relu_pool ([image][c / 8][pooled pixel][c % 8] in memory, held in
+    a tensor of (n, c, h / 2, w / 2) bytes) as a per-channel (n, c, h / 2, w / 2) tensor."""
+    n, c, ph, pw = codes.shape
+    return codes.reshape(n, c // 8, ph, pw, 8).permute(0, 1, 4, 2, 3).reshape(n, c, ph, pw)

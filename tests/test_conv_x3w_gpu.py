@@ -15,7 +15,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import rel_l2
+from conftest import planar_codes, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -176,7 +176,7 @@ def test_conv_relu_pool_in_one_launch_against_fp64(hip, n, cin, cout, H, W):
     hip.conv3x3_x3w_relu_pool(dev(x), bank_f, wsc, dev(b), cout, 1, pooled, codes)
     torch.cuda.synchronize()
     assert rel_l2(pooled.cpu(), ref) <= BAR
-    codes = codes.cpu()
+    codes = planar_codes(codes.cpu())
     assert int(codes.max()) <= 7
     # bit 2 = "the maximum is not positive"
     clear_sign = ref.abs() > 1e-5
@@ -218,3 +218,71 @@ def test_backward_pass_with_the_gram_backward_along_at_256_channels(hip, cin, c,
     torch.cuda.synchronize()
     assert rel_l2(conv_only.cpu(), F.conv_transpose2d(gy.double(), w.double(), padding=1) * (f > 0)) <= BAR
     assert rel_l2(gram_only.cpu(), torch.einsum("kc,bkhw->bchw", d.double(), f.double()) * (f > 0)) <= BAR
+
+
+# channels of the gradient (= couts of the layer), channels produced, full-size H, W, images
+UNPOOL_CASES = [
+    (64, 64, 128, 96, 1),          # conv1_2's group
+    (128, 128, 64, 64, 2),
+    (256, 256, 66, 70, 1),         # ragged tiles (even plane)
+    (512, 512, 64, 64, 1),         # conv4_4: split-K at this size
+    (32, 200, 18, 260, 1),         # ragged cout tile of the produced gradient
+]
+
+
+@pytest.mark.parametrize("cg,c,H,W,n", UNPOOL_CASES)
+@pytest.mark.parametrize("relu_bit", [True, False])
+def test_backward_pass_straight_from_the_pooled_gradient(hip, cg, c, H, W, n, relu_bit):
+    """maua_conv3x3_x3w_unpool against maua_pool2x2_bwd_codes followed by maua_conv3x3_x3w: the same bits (one-pass and split-K forms,
+    with and without the ReLU mask of the produced gradient), and against autograd's arithmetic in fp64
+    (max_pool2d backward + threshold_backward + conv_transpose2d, /root/reference/models.py:120,129-130)."""
+    act = torch.relu(rnd(n, cg, H, W, seed=31))
+    act[:, :, :4, :4] = 0.0                                            # all-zero windows: bit 2 of their bytes
+    gp = rnd(n, cg, H // 2, W // 2, seed=32)
+    w = rnd(cg, c, 3, 3, seed=33, scale=math.sqrt(2.0 / (9 * c)))
+    fmap = torch.relu(rnd(n, c, H, W, seed=34))
+    _, bb, wsc = hip.conv_pack_filters_x3w(dev(w))
+    pooled = torch.empty(n, cg, H // 2, W // 2, device="cuda")
+    codes = torch.empty(n, cg, H // 2, W // 2, dtype=torch.uint8, device="cuda")
+    hip.pool2x2_fwd_codes(dev(act), pooled, codes)
+    full = hip.pool2x2_bwd_codes(dev(gp), codes, torch.empty(n, cg, H, W, device="cuda"), relu_bit)
+    # fp64 reference of the unpooled gradient
+    a64 = act.double().requires_grad_(True)
+    F.max_pool2d(a64, 2, 2).backward(gp.double())
+    gfull = a64.grad * (act > 0) if relu_bit else a64.grad
+    assert torch.equal(full.cpu().double(), gfull)                     # (routing only: exact)
+    ref = F.conv_transpose2d(gfull, w.double(), padding=1)
+    for mask in (None, dev(fmap)):
+        for ws in (None, one_pass_ws()):
+            two = hip.conv3x3_x3w(full, bb, wsc, None, c, 1, False, out_relu_mask=mask, workspace=ws)
+            one = hip.conv3x3_x3w_unpool(dev(gp), codes, relu_bit, bb, wsc, c, 1, out_relu_mask=mask, workspace=ws)
+            torch.cuda.synchronize()
+            assert torch.equal(one, two), (mask is not None, ws is not None)
+        assert rel_l2(one.cpu(), ref * (fmap > 0) if mask is not None else ref) <= BAR
+
+
+@pytest.mark.parametrize("cg,c,H,W", [(64, 64, 128, 96), (128, 128, 66, 70), (256, 256, 64, 64)])
+def test_unpooling_backward_pass_with_the_gram_backward_along(hip, cg, c, H, W):
+    """The same launch carrying the Gram backward of the style loss on the layer's input (relu1_1 / relu2_1 / relu3_1 in the network):
+    bit-identical to maua_pool2x2_bwd_codes + maua_conv3x3_x3w_gram, and [F > 0] (conv_transpose(unpool(g)) + D F) in fp64."""
+    act = torch.relu(rnd(1, cg, H, W, seed=41))
+    gp = rnd(1, cg, H // 2, W // 2, seed=42)
+    w = rnd(cg, c, 3, 3, seed=43, scale=math.sqrt(2.0 / (9 * c)))
+    f = torch.relu(rnd(1, c, H, W, seed=44))
+    d = rnd(c, c, seed=45) * 1e-3
+    d = (d + d.t()).contiguous()
+    _, bb, wsc = hip.conv_pack_filters_x3w(dev(w))
+    dbank, dinv = hip.conv_x3w_dmat_bank(c, "cuda")
+    hip.conv_pack_dmat_x3w(dev(d), dbank, dinv)
+    pooled = torch.empty(1, cg, H // 2, W // 2, device="cuda")
+    codes = torch.empty(1, cg, H // 2, W // 2, dtype=torch.uint8, device="cuda")
+    hip.pool2x2_fwd_codes(dev(act), pooled, codes)
+    full = hip.pool2x2_bwd_codes(dev(gp), codes, torch.empty(1, cg, H, W, device="cuda"), True)
+    two = hip.conv3x3_x3w_gram(full, bb, wsc, dev(f), dbank, dinv, c, 1)
+    one = hip.conv3x3_x3w_unpool(dev(gp), codes, True, bb, wsc, c, 1, out_relu_mask=dev(f), dmat_bank=dbank, dmat_inv_scale=dinv)
+    torch.cuda.synchronize()
+    assert torch.equal(one, two)
+    a64 = act.double().requires_grad_(True)
+    F.max_pool2d(a64, 2, 2).backward(gp.double())
+    ref = F.conv_transpose2d(a64.grad * (act > 0), w.double(), padding=1) + torch.einsum("kc,bkhw->bchw", d.double(), f.double())
+    assert rel_l2(one.cpu(), ref * (f > 0)) <= 3e-7

@@ -718,6 +718,45 @@ def test_gram_backward_fused_into_the_convolution_equals_the_separate_pass(weigh
         assert rel_l2(res[k][2], res["0"][2].double()) <= 2e-6
 
 
+def test_pool_backward_in_the_convolution_staging_changes_no_bit(weight_files, monkeypatch):
+    """The way back through the same groups: the backward-data pass of the convolution stages its input from the pooled map's gradient
+    and the pool's decision bytes (maua_conv3x3_x3w_unpool; with the Gram backward of relu1_1 / relu2_1 / relu3_1 along where that is
+    fused) - no pool backward launch, no full-size gradient buffer.  Same losses, same pixel gradient, bit for bit."""
+    import engine
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MAUA_FUSE_UNPOOL", flag)
+        monkeypatch.setenv("MAUA_DEBUG_POISON", "1")
+        args = product_args(weight_files, S=512)
+        content, style, init = synth.images(512)
+        net, losses = build(args, content, [style], 512)
+        eng = engine.StyleEngine(net, losses)
+        slots, total, grad = eng.feval(init.cuda())
+        torch.cuda.synchronize()
+        res[flag] = (slots.clone().cpu(), grad.clone().cpu(), len(eng.fused_unpool), sum(t.is_meta for t in eng.gbuf.values()))
+    assert res["0"][2] == 0 and res["1"][2] >= 3 and res["1"][3] == res["1"][2], res["1"][2:]
+    assert torch.isfinite(res["1"][1]).all()
+    assert torch.equal(res["0"][0], res["1"][0]) and torch.equal(res["0"][1], res["1"][1])
+
+
+def test_pool_backward_in_the_convolution_staging_on_a_frame_batch(weight_files, monkeypatch):
+    """The same on optim.optimize_frames (three frames through every launch, grid z = frame): bit-identical results with and without."""
+    import models
+    import optim
+    S, B, N = 256, 3, 4
+    style = synth.images(S)[1]
+    contents = torch.cat([synth.images(S, seed=50 + k)[0] for k in range(B)])
+    inits = torch.cat([synth.images(S, seed=60 + k)[2] for k in range(B)])
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MAUA_FUSE_UNPOOL", flag)
+        args = product_args(weight_files, optimizer="lbfgs", S=S, N=N)
+        optim.set_model_args(args, S)
+        net, losses = models.load_model(args)
+        out[flag] = optim.optimize_frames(contents.cuda(), [style], inits.cuda(), N, args, net, losses).cpu()
+    assert torch.equal(out["0"], out["1"]) and not torch.equal(out["1"][0], out["1"][1])
+
+
 def test_pool_in_the_convolution_epilogue_changes_no_bit(weight_files, monkeypatch):
     """Where a conv + ReLU feeds nothing but a 2x2 max pool and runs in one pass over its channels, the pool happens in the
     convolution's epilogue and the full-size activation is never written: same losses, same gradient, bit for bit."""

@@ -161,6 +161,18 @@ def _crop_reference(x_gpu, w, bias, y0, x0, size, pad, dtype):
     return F.conv2d(win, w.cpu().to(dtype), None if bias is None else bias.cpu().to(dtype))
 
 
+def _grad_wrt_output(eng, step):
+    """d loss / d (output of a conv + ReLU step), ReLU-masked.  Where the engine's backward pass goes straight from the pooled map's
+    gradient to the convolution's input gradient (fused_unpool: that buffer exists as a shape only) it is rebuilt here the way the
+    separate launch would have written it: maua_pool2x2_bwd_codes over the pooled gradient and the decision bytes."""
+    import hip
+    g = eng.gbuf[step.dst]
+    if not g.is_meta:
+        return g
+    pool = eng.fused_unpool[id(step)]
+    return hip.pool2x2_bwd_codes(eng.gbuf[pool.dst], eng.pool_codes[id(pool)], torch.empty(g.shape, device="cuda"), True)
+
+
 @pytest.mark.parametrize("kernel", ["x3w", "x3"])
 @pytest.mark.parametrize("layer", ["conv1_2", "conv2_2", "conv3_2", "conv4_2", "conv5_1"])
 @pytest.mark.parametrize("direction", ["fwd", "bwd"])
@@ -185,7 +197,7 @@ def test_full_size_fp16x3_conv_is_as_close_to_fp64_as_fp32_cpu(setup, layer, dir
         got = conv(inp, bf, wsc, mod.bias_device(), mod.out_channels, 1, False)
         w_eff, bias = mod.weight.detach(), mod.bias_device()
     else:
-        inp = eng.gbuf[step.dst].clone()  # d loss / d (conv output), already ReLU-masked by its producer
+        inp = _grad_wrt_output(eng, step).clone()  # d loss / d (conv output), already ReLU-masked by its producer
         got = conv(inp, bb, wsc, None, mod.in_channels, 1, False)
         w_eff, bias = mod.weight.detach().flip(2, 3).transpose(0, 1).contiguous(), None  # backward-data as a correlation
     torch.cuda.synchronize()
@@ -216,7 +228,7 @@ def test_full_size_backward_pass_gradients_against_fp64(setup, layer):
     cands = [s for s in eng.steps if s.kind == "conv" and (s.mod.in_channels, s.mod.out_channels) == want[:2] and eng.act[s.src].shape[2] == want[2]]
     step = cands[want[3]] if len(cands) > want[3] else cands[-1]
     mod = step.mod
-    g_out = eng.gbuf[step.dst]
+    g_out = _grad_wrt_output(eng, step)  # (conv3_4, conv4_4: the engine's launch reads the pooled gradient and the pool's decisions instead)
     g_in = eng.gbuf[step.src]
     a_in = eng.act[step.src]
     assert not g_out.is_meta and not a_in.is_meta and float(g_out.abs().max()) > 0

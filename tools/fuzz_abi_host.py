@@ -69,6 +69,8 @@ def main():
             L.maua_conv3x3_x3w(ptr, ptr, 1.0, ptr, None, ptr, n, cin, h, w, cout, pad, 1, 0, ptr, ws_bytes, None),
             L.maua_conv3x3_x3w_relu_pool(ptr, ptr, 1.0, ptr, ptr, ptr, n, cin, h, w, cout, pad, None),
             L.maua_conv3x3_x3w_gram(ptr, ptr, 1.0, ptr, ptr, ptr, ptr, n, cin, h, w, cout, pad, 0, ptr, ws_bytes, None),
+            L.maua_conv3x3_x3w_unpool(ptr, ptr, rng.randint(0, 1), ptr, 1.0, rng.choice([None, ptr]), rng.choice([None, ptr]), ptr, ptr, n, cin, h, w,
+                                      cout, pad, ptr, ws_bytes, None),
             L.maua_conv3x3_x3(ptr, ptr, 1.0, ptr, None, ptr, n, cin, h, w, cout, pad, 1, 0, ptr, ws_bytes, None),
             L.maua_conv3x3_x6(ptr, ptr, ptr, None, ptr, n, cin, h, w, cout, pad, 1, 0, ptr, ws_bytes, None),
             L.maua_conv2d_fwd(ptr, None, ptr, ptr, ptr, n, cin, h, w, cout, k, k, stride, pad, 1, 0, ptr, ws_bytes, None),
@@ -97,7 +99,7 @@ def main():
             L.maua_lbfgs_iterate(ptr, ptr, ptr, None, h * w, rng.choice([1, 100, 254, 255]), 1.0, -1.0, -1.0, None),
         ]
         if min(n, cin, cout, h, w) <= 0:  # (the 1x1 entry takes the product h * w, which two negative extents make positive)
-            assert all(rc < 0 for rc in rcs[:9]), (n, cin, cout, h, w, rcs)
+            assert all(rc < 0 for rc in rcs[:10]), (n, cin, cout, h, w, rcs)
         checked += len(rcs) + len(sizes)
     L.maua_set_split_batch_hint(1)
     print(f"fuzz_abi_host: {n_cases} cases, {checked} calls, no sanitizer report, return codes consistent")
