@@ -278,6 +278,11 @@ int maua_gram_fwd_mse_ledger(const float* f, float* gram, float* row_mean_out, i
  * `slots[i]` in `ledgers[i]` - with the same arithmetic in the same order: bit-identical results. */
 int maua_gram_partial(const float* f, float* row_mean_out, int c, int64_t hw, int center, void* workspace, size_t workspace_bytes,
                       maua_stream_t stream);
+/* maua_gram_partial (center = 0) for up to 8 layers at once - at most two partial launches (the layers of one 64-channel tile; the others)
+ * and one first-level fold instead of one to two launches per layer; every layer keeps the plan of its own call: the same slabs, bit for
+ * bit.  Host arrays of `count` entries. */
+int maua_gram_partial_batch(int count, const float* const* fs, const int* cs, const int64_t* hws, void* const* workspaces,
+                            const size_t* workspace_bytes, maua_stream_t stream);
 int maua_gram_finish_mse_batch(int count, const void* const* workspaces, float* const* grams, const float* const* targets,
                                float* const* dmats, const int* cs, const int64_t* hws, const float* scales, const float* loss_scales,
                                const float* grad_scales, double* const* ledgers, const int* slots, maua_stream_t stream);

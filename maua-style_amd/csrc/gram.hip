@@ -173,9 +173,10 @@ __device__ __forceinline__ unsigned gx_cvt_pk(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, g16x2));
 }
 
-__global__ void __launch_bounds__(256, 2)
-gram_x3_partial_kernel(const float* __restrict__ f, const float* __restrict__ mean, float* __restrict__ partial, int C,
-                       int64_t HW, int ksplit, int64_t chunk, int nplanes) {
+// (workgroup `pair_index` of the tile pairs, slab `ks`: blockIdx.x / .y of a single layer's launch, decoded by the batch kernel below)
+__device__ __forceinline__ void gram_x3_partial_body(const float* __restrict__ f, const float* __restrict__ mean, float* __restrict__ partial,
+                                                     int C, int64_t HW, int ksplit, int64_t chunk, int nplanes, const int pair_index,
+                                                     const int ks) {
     // two buffers of `nplanes` planes (4 = [tile][part]; 2 when C <= 64: the single, diagonal tile pair needs no second tile,
     // and four such workgroups fit a CU) + 64 bytes of inverse scales each
     extern __shared__ __attribute__((aligned(16))) float smem_f32[];  // (one dynamic-LDS symbol per translation unit)
@@ -184,7 +185,7 @@ gram_x3_partial_kernel(const float* __restrict__ f, const float* __restrict__ me
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i32 = lane & 31, half = lane >> 5;
     const int wi = wave >> 1, wj = wave & 1;
-    int pair = blockIdx.x, ti = 0;
+    int pair = pair_index, ti = 0;
     const int ntile = (C + GT - 1) / GT;
     while (pair >= ntile - ti) {
         pair -= ntile - ti;
@@ -192,7 +193,6 @@ gram_x3_partial_kernel(const float* __restrict__ f, const float* __restrict__ me
     }
     const int tj = ti + pair;
     const bool diag = ti == tj;
-    const int ks = blockIdx.y;
     const int64_t p_begin = (int64_t)ks * chunk;
     const int64_t p_end = min(HW, p_begin + chunk);
 
@@ -343,12 +343,55 @@ gram_x3_partial_kernel(const float* __restrict__ f, const float* __restrict__ me
             __syncthreads();  // buffer `nxt` is complete; every wave is done with `cur` (rewritten two stages on)
         }
     }
-    float* out = partial + ((int64_t)blockIdx.x * ksplit + ks) * (GT * GT);
+    float* out = partial + ((int64_t)pair_index * ksplit + ks) * (GT * GT);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         out[row * GT + wj * 32 + i32] = master[r];
     }
+}
+
+__global__ void __launch_bounds__(256, 2)
+gram_x3_partial_kernel(const float* __restrict__ f, const float* __restrict__ mean, float* __restrict__ partial, int C,
+                       int64_t HW, int ksplit, int64_t chunk, int nplanes) {
+    gram_x3_partial_body(f, mean, partial, C, HW, ksplit, chunk, nplanes, blockIdx.x, blockIdx.y);
+}
+
+// The partial kernels of up to GB_MAX style layers in ONE launch (grid z = layer, x / y = the largest layer's; a layer's surplus
+// workgroups leave at once): below 768 x 768 the Gram chains run in stream order and each layer's launch is 10 - 25 us of mostly latency
+// on a part of the chip; together they fill it.  Every layer keeps its own plan (tile pairs, slabs): the slabs hold the same bits.
+constexpr int GB_MAX = 8;
+struct GramPartialBatch {
+    const float* f[GB_MAX];
+    float* partial[GB_MAX];
+    int64_t HW[GB_MAX], chunk[GB_MAX];
+    int C[GB_MAX], ksplit[GB_MAX], npairs[GB_MAX], nplanes[GB_MAX];
+    int first[GB_MAX + 1];  // workgroups [first[z], first[z + 1]) belong to layer z: a dense 1-D grid (no workgroup is launched to leave)
+    int count;
+};
+__global__ void __launch_bounds__(256, 2) gram_x3_partial_batch_kernel(GramPartialBatch b) {
+    int z = 0;
+    while (z + 1 < b.count && (int)blockIdx.x >= b.first[z + 1]) ++z;
+    const int local = blockIdx.x - b.first[z];
+    const int ks = local / b.npairs[z];  // (tile pair fastest, as blockIdx.x of the layer's own launch)
+    gram_x3_partial_body(b.f[z], nullptr, b.partial[z], b.C[z], b.HW[z], b.ksplit[z], b.chunk[z], b.nplanes[z], local - ks * b.npairs[z], ks);
+}
+
+// sum of slab values base[k * stride_elems] for k = 0, kstride, 2 kstride, ... < ksplit in index order (fp64): eight loads in flight per
+// step - the finishing passes are a handful of workgroups whose time is the latency of this chain - and the additions in the order of a
+// plain loop (same bits).
+__device__ __forceinline__ double slab_sum(const float* __restrict__ base, int ksplit, int kstride) {
+    double sd = 0.0;
+    int k = 0;
+    for (; k + 7 * kstride < ksplit; k += 8 * kstride) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = base[(int64_t)(k + u * kstride) * (GT * GT)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sd += (double)v[u];
+    }
+    for (; k < ksplit; k += kstride) sd += (double)base[(int64_t)k * (GT * GT)];
+    return sd;
 }
 
 // First level of the slab sum when there are many slabs (relu1_1 at 1024x1024: 745): grid (pairs, 16, groups), every thread
@@ -358,8 +401,23 @@ __global__ void __launch_bounds__(256)
 gram_fold_kernel(float* __restrict__ partial, int ksplit) {
     float* base = partial + (int64_t)blockIdx.x * ksplit * (GT * GT) + blockIdx.y * 256 + threadIdx.x;
     const int k0 = blockIdx.z * GF_FOLD, k1 = min(k0 + GF_FOLD, ksplit);
-    double sd = 0.0;
-    for (int k = k0; k < k1; ++k) sd += (double)base[(int64_t)k * (GT * GT)];
+    const double sd = slab_sum(base + (int64_t)k0 * (GT * GT), k1 - k0, 1);
+    base[(int64_t)k0 * (GT * GT)] = (float)sd;
+}
+
+// gram_fold_kernel for the layers of a batch: grid z = layer * groups of the layer with the most + group
+struct GramFoldBatch {
+    float* partial[GB_MAX];
+    int ksplit[GB_MAX], npairs[GB_MAX];
+    int max_groups;
+};
+__global__ void __launch_bounds__(256) gram_fold_batch_kernel(GramFoldBatch b) {
+    const int z = blockIdx.z / b.max_groups, grp = blockIdx.z - z * b.max_groups;
+    const int ksplit = b.ksplit[z];
+    const int k0 = grp * GF_FOLD, k1 = min(k0 + GF_FOLD, ksplit);
+    if ((int)blockIdx.x >= b.npairs[z] || ksplit <= 2 * GF_FOLD || k0 >= ksplit) return;
+    float* base = b.partial[z] + (int64_t)blockIdx.x * ksplit * (GT * GT) + blockIdx.y * 256 + threadIdx.x;
+    const double sd = slab_sum(base + (int64_t)k0 * (GT * GT), k1 - k0, 1);
     base[(int64_t)k0 * (GT * GT)] = (float)sd;
 }
 
@@ -380,8 +438,7 @@ gram_finish_kernel(const float* __restrict__ partial, float* __restrict__ gram, 
     // diagonal tiles: the lower triangle is read from the upper one - block (1,0) was not computed at all, and G comes out
     // exactly symmetric whatever arithmetic produced the slabs
     const int src = (ti == tj && er > ec) ? ec * GT + er : e;
-    double sd = 0.0;  // fp64 keeps the split-K sum exact to fp32 rounding; slabs k = 0, kstride, 2 kstride, ...
-    for (int k = 0; k < ksplit; k += kstride) sd += (double)base[(int64_t)k * (GT * GT) + src];
+    const double sd = slab_sum(base + src, ksplit, kstride);  // fp64 keeps the split-K sum exact to fp32 rounding; slabs k = 0, kstride, 2 kstride, ...
     const float s = (float)(sd * (double)scale);
     const int gi = ti * GT + er, gj = tj * GT + ec;
     if (gi < C && gj < C) {
@@ -409,8 +466,7 @@ gram_finish_mse_kernel(const float* __restrict__ partial, float* __restrict__ gr
     const int e = blockIdx.y * 256 + threadIdx.x;
     const int er = e / GT, ec = e % GT;
     const int src = (ti == tj && er > ec) ? ec * GT + er : e;
-    double sd = 0.0;
-    for (int k = 0; k < ksplit; k += kstride) sd += (double)base[(int64_t)k * (GT * GT) + src];
+    const double sd = slab_sum(base + src, ksplit, kstride);
     const float s = (float)(sd * (double)scale);
     const int gi = ti * GT + er, gj = tj * GT + ec;
     double sq = 0.0;
@@ -440,7 +496,6 @@ gram_finish_mse_kernel(const float* __restrict__ partial, float* __restrict__ gr
 // the Gram / loss chains of an evaluation need their D matrices only when the backward pass starts, so their finishing passes - each a
 // latency-bound launch of a few microseconds of work - can all wait for the last partial kernel.  Same arithmetic, same summation
 // order, same ledger records as the per-layer launch: bit-identical results.
-constexpr int GB_MAX = 8;
 struct GramFinishBatch {
     const float* partial[GB_MAX];
     float* gram[GB_MAX];
@@ -466,8 +521,7 @@ __global__ void __launch_bounds__(256) gram_finish_mse_batch_kernel(GramFinishBa
     const int e = blockIdx.y * 256 + threadIdx.x;
     const int er = e / GT, ec = e % GT;
     const int src = (ti == tj && er > ec) ? ec * GT + er : e;
-    double sd = 0.0;
-    for (int k = 0; k < ksplit; k += kstride) sd += (double)base[(int64_t)k * (GT * GT) + src];
+    const double sd = slab_sum(base + src, ksplit, kstride);
     const float s = (float)(sd * (double)b.scale[z]);
     const int gi = ti * GT + er, gj = tj * GT + ec;
     const float* __restrict__ target = b.target[z];
@@ -762,6 +816,78 @@ int maua_gram_partial(const float* f, float* row_mean_out, int c, int64_t hw, in
                       maua_stream_t stream) {
     int npairs, ksplit, kstride;
     return gram_partial_impl(f, row_mean_out, c, hw, center, workspace, workspace_bytes, stream, &npairs, &ksplit, &kstride);
+}
+
+int maua_gram_partial_batch(int count, const float* const* fs, const int* cs, const int64_t* hws, void* const* workspaces,
+                            const size_t* workspace_bytes, maua_stream_t stream) {
+    MAUA_REQUIRE(count > 0 && count <= GB_MAX && fs && cs && hws && workspaces && workspace_bytes, MAUA_E_INVAL,
+                 "gram_partial_batch: bad args (at most %d layers per call)", GB_MAX);
+    for (int i = 0; i < count; ++i) {
+        MAUA_REQUIRE(fs[i] && workspaces[i] && cs[i] > 0 && cs[i] <= (1 << 16) && hws[i] > 0 && hws[i] < (1ll << 30), MAUA_E_INVAL,
+                     "gram_partial_batch: bad args for layer %d", i);
+        MAUA_REQUIRE(workspace_bytes[i] >= maua_gram_workspace_bytes(cs[i], hws[i]), MAUA_E_WORKSPACE, "gram_partial_batch: workspace %zu < %zu (layer %d)",
+                     workspace_bytes[i], maua_gram_workspace_bytes(cs[i], hws[i]), i);
+    }
+    static const bool use_x3 = [] {
+        const char* e = getenv("MAUA_GRAM_X3");
+        return !(e && e[0] == '0');
+    }();
+    if (!use_x3) {  // (the fp32-MFMA comparison kernel has no batched form)
+        for (int i = 0; i < count; ++i) {
+            int rc = maua_gram_partial(fs[i], nullptr, cs[i], hws[i], 0, workspaces[i], workspace_bytes[i], stream);
+            if (rc) return rc;
+        }
+        return MAUA_OK;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gram_x3_partial_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GXBUF);
+        attr_set = true;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    GramFoldBatch fold{};
+    int nfold = 0, fold_pairs = 0;
+    // two launches at most: the layers of one tile (C <= 64: two planes of LDS per buffer, four workgroups per CU) and the others
+    for (int wide = 0; wide < 2; ++wide) {
+        GramPartialBatch b{};
+        int nb = 0;
+        for (int i = 0; i < count; ++i) {
+            if ((cs[i] > GT) != (wide == 1)) continue;
+            int npairs, ksplit;
+            int64_t chunk;
+            gram_plan(cs[i], hws[i], &npairs, &ksplit, &chunk);
+            b.f[nb] = fs[i];
+            b.partial[nb] = (float*)workspaces[i];
+            b.HW[nb] = hws[i];
+            b.chunk[nb] = chunk;
+            b.C[nb] = cs[i];
+            b.ksplit[nb] = ksplit;
+            b.npairs[nb] = npairs;
+            b.nplanes[nb] = wide ? 4 : 2;
+            b.first[nb + 1] = b.first[nb] + npairs * ksplit;
+            ++nb;
+            if (ksplit > 2 * GF_FOLD) {
+                fold.partial[nfold] = (float*)workspaces[i];
+                fold.ksplit[nfold] = ksplit;
+                fold.npairs[nfold] = npairs;
+                const int groups = (ksplit + GF_FOLD - 1) / GF_FOLD;
+                fold.max_groups = groups > fold.max_groups ? groups : fold.max_groups;
+                fold_pairs = npairs > fold_pairs ? npairs : fold_pairs;
+                ++nfold;
+            }
+        }
+        if (!nb) continue;
+        const size_t lds = 2 * ((size_t)(wide ? 4 : 2) * GXPLANE + 64);
+        b.count = nb;
+        hipLaunchKernelGGL(gram_x3_partial_batch_kernel, dim3(b.first[nb]), dim3(256), lds, s, b);
+        int rc = check_launch("gram_x3_partial_batch_kernel");
+        if (rc) return rc;
+    }
+    if (nfold) {
+        hipLaunchKernelGGL(gram_fold_batch_kernel, dim3(fold_pairs, GT * GT / 256, nfold * fold.max_groups), dim3(256), 0, s, fold);
+        return check_launch("gram_fold_batch_kernel");
+    }
+    return MAUA_OK;
 }
 
 int maua_gram_finish_mse_batch(int count, const void* const* workspaces, float* const* grams, const float* const* targets,

@@ -169,6 +169,7 @@ class StyleEngine:
         # Gram / loss chains of a single image: split-K slabs per layer, ONE finishing launch per evaluation (MAUA_GRAM_BATCH=0: a
         # finishing launch per layer, the round-2 form; same bits)
         self.gram_batch_on = os.environ.get("MAUA_GRAM_BATCH", "1") != "0"
+        self.gram_partial_batch_on = os.environ.get("MAUA_GRAM_PARTIAL_BATCH", "1") != "0"  # (... and one partial launch for the Gram-form layers)
         self._gram_wsp, self._gram_batches = getattr(self, "_gram_wsp", {}), {}
         # conv + ReLU whose only consumer is a 2x2 / 2 max pool with kept decisions, on conv_x3w.hip in one pass over the
         # channels: the pool runs in the convolution's epilogue and the full-size activation is never written (nothing reads
@@ -513,11 +514,16 @@ class StyleEngine:
                             # only the split-K slabs now (into the layer's own workspace); ONE finishing launch for all style layers
                             # of the evaluation follows the forward pass (their D matrices are not needed before the backward pass)
                             gws = self._gram_ws(s, c, n // c, f.device)
-                            self._timed("gram_fwd", 2 * c * c * (n // c), n * 4 + c * c * 4, lambda: hip.gram_partial(
-                                f, s.mod.use_covariance, self.mean[id(s)], gws))
+                            # Gram form: the slabs wait too - the partial kernels of all style layers go out together behind the forward
+                            # pass (hip.GramFinishBatch.run_partial: each alone is 10-25 us of latency on a part of the chip); the
+                            # covariance form needs its row means first and keeps its own launches
+                            later = self.gram_partial_batch_on and not s.mod.use_covariance
+                            if not later:
+                                self._timed("gram_fwd", 2 * c * c * (n // c), n * 4 + c * c * 4, lambda: hip.gram_partial(
+                                    f, s.mod.use_covariance, self.mean[id(s)], gws))
                             batch.append(dict(step=s, workspace=gws, gram=self.gram[id(s)], target=s.mod.target, dmat=self.dmat[id(s)], c=c,
                                               hw=n // c, scale=1.0 / n, loss_scale=lw / (c * c), grad_scale=gw * 4.0 / (c * c) / n,
-                                              ledger=self.ledger[0], slot=s.slot))
+                                              ledger=self.ledger[0], slot=s.slot, f=f if later else None))
                             continue
                         self._timed("gram_fwd", 2 * c * c * (n // c), n * 4 + c * c * 4, lambda: hip.gram_fwd_mse_ledger(
                             f, 1.0 / n, s.mod.use_covariance, self.gram[id(s)], self.mean[id(s)], s.mod.target, self.dmat[id(s)],
@@ -536,11 +542,19 @@ class StyleEngine:
                 for k0 in range(0, len(batch), 8):
                     grp = batch[k0:k0 + 8]
                     key = tuple((id(l["step"]), l["target"].data_ptr(), l["workspace"].data_ptr(), l["gram"].data_ptr(), l["dmat"].data_ptr(),
-                                 l["ledger"].data_ptr(), l["slot"], l["loss_scale"], l["grad_scale"]) for l in grp)
+                                 l["ledger"].data_ptr(), l["slot"], l["loss_scale"], l["grad_scale"],
+                                 None if l["f"] is None else l["f"].data_ptr()) for l in grp)
+                    later = [l for l in grp if l["f"] is not None]
+                    if later and len(later) != len(grp):  # (mixed Gram / covariance layers: the waiting ones one by one)
+                        for l in later:
+                            hip.gram_partial(l["f"], False, None, l["workspace"])
+                        later = []
                     fin = self._gram_batches.get(k0)
                     if fin is None or fin[0] != key:
                         fin = (key, hip.GramFinishBatch(grp))
                         self._gram_batches[k0] = fin
+                    if later:
+                        self._timed("gram_fwd", sum(2 * l["c"] * l["c"] * l["hw"] for l in grp), sum(l["c"] * l["hw"] * 4 for l in grp), fin[1].run_partial)
                     self._timed("gram_fwd", 0, sum(l["c"] * l["c"] * 8 for l in grp), fin[1].run)
                 for l in batch:
                     if id(l["step"]) in self.fused_style:

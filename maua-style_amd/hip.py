@@ -90,6 +90,7 @@ SIGNATURES = {
     "maua_gram_fwd_mse_ledger": (c_i, [c_p, c_p, c_p, c_i, c_i64, c_f, c_i, c_p, c_p, c_f, c_f, c_p, c_i, c_p, c_sz, c_p]),
     "maua_gram_partial": (c_i, [c_p, c_p, c_i, c_i64, c_i, c_p, c_sz, c_p]),
     "maua_gram_finish_mse_batch": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "maua_gram_partial_batch": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "maua_loss_ledger_sum": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p]),
     "maua_loss_ledger_sum_f64": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
     "maua_lbfgs_state_bytes": (c_sz, [c_i64, c_i]),
@@ -579,6 +580,15 @@ class GramFinishBatch:
             arr(ctypes.c_float, [float(l["scale"]) for l in layers]), arr(ctypes.c_float, [float(l["loss_scale"]) for l in layers]),
             arr(ctypes.c_float, [float(l["grad_scale"]) for l in layers]), arr(ctypes.c_void_p, [l["ledger"].data_ptr() for l in layers]),
             arr(ctypes.c_int, [int(l["slot"]) for l in layers]))
+
+        self.partial_args = (
+            arr(ctypes.c_void_p, [_ptr(_f32(l["f"], "f")) if l.get("f") is not None else None for l in layers]), self.args[4], self.args[5],
+            self.args[0], arr(ctypes.c_size_t, [l["workspace"].numel() * l["workspace"].element_size() for l in layers]))
+
+    def run_partial(self):
+        """maua_gram_partial of every layer (each dict's "f" = its feature map) in at most three launches."""
+        a = self.partial_args
+        _check(lib().maua_gram_partial_batch(self.n, a[0], a[1], a[2], a[3], a[4], _stream()), "maua_gram_partial_batch")
 
     def run(self):
         a = self.args
