@@ -120,11 +120,13 @@ int maua_conv3x3_x3w(const float* x, const void* bank, float w_scale, const floa
 /* conv3x3 + bias + ReLU + the 2x2 stride-2 max pool that follows it (`nn.Conv2d` / `nn.ReLU` / `nn.MaxPool2d(2, 2)`,
  * models.py:120-130) in one launch: the full-size activation is not written at all - `pooled` (n, cout, oh / 2, ow / 2) and
  * the decision bytes of maua_pool2x2_fwd_codes come out of the convolution's epilogue; bit-identical to the two separate
- * launches.  One pass over the input channels (no split-K): meant for launches where maua_conv_x3w_split(...) - the number of
- * channel-loop splits maua_conv3x3_x3w would use for this geometry under the current batch hint - is 1. */
+ * launches.  workspace (nullable) as for maua_conv3x3_x3w: where maua_conv_x3w_split(...) - the number of channel-loop splits
+ * maua_conv3x3_x3w would use for this geometry under the current batch hint - is above 1 and the workspace holds the slabs, the
+ * ReLU and the pool happen in the pass that adds the slabs (two launches; still no full-size activation, still the same bits). */
 int maua_conv_x3w_split(int n, int cin, int h, int w, int cout, int pad);
 int maua_conv3x3_x3w_relu_pool(const float* x, const void* bank, float w_scale, const float* bias, float* pooled,
-                               unsigned char* codes, int n, int cin, int h, int w, int cout, int pad, maua_stream_t stream);
+                               unsigned char* codes, int n, int cin, int h, int w, int cout, int pad, void* workspace,
+                               size_t workspace_bytes, maua_stream_t stream);
 
 /* The backward-data pass of a 3x3 layer fused with the Gram backward of the style loss that sits on the layer's INPUT
  * activation F (reference: autograd of `torch.mm(x, y.T)` in GramMatrix.forward, loss.py:91, summed by autograd with the

@@ -116,6 +116,7 @@ int split_batch_hint();  // conv_api.hip: frames per launch the caller plans wit
 int conv_mfma_dispatch(const ConvArgs& a, int ks, int n, hipStream_t stream);
 int conv3x3_few_out(const ConvArgs& a, int n, hipStream_t stream);
 int conv_splitk_finish(const ConvArgs& a, int n, int ksplit, hipStream_t stream);
+int conv_splitk_finish_pool(const ConvArgs& a, int n, int ksplit, hipStream_t stream);  // ... + ReLU + 2x2 max pool: a.y = pooled map, a.pool_codes
 int conv_x3_launch(const ConvArgs& a, int n, float w_scale, hipStream_t stream);  // conv_x3.hip  // y = act(bias + sum of a.ws partials) ...
 int conv_x3w_launch(const ConvArgs& a, int n, float w_scale, hipStream_t stream);  // conv_x3w.hip (16-channel chunks, a.Cin % 16 == 0)
 bool conv_x3w_supports(const ConvArgs& a);

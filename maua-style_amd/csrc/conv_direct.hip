@@ -230,6 +230,44 @@ int conv_splitk_finish(const ConvArgs& a, int n, int ksplit, hipStream_t stream)
     return check_launch("conv_splitk_finish_kernel");
 }
 
+// The same second stage for a convolution whose ReLU output feeds nothing but a 2x2 / 2 max pool (conv_x3w's pooling epilogue needs
+// complete sums, which a split channel loop does not have): relu(bias + sum of the slabs) of a window's four elements - the additions in
+// conv_splitk_finish_kernel's order - then pool2x2_fwd_codes_kernel's decision (first maximum in scan order, NaN wins; bit 2 = not
+// positive) and its byte layout.  The full-size activation is not written.
+__global__ void __launch_bounds__(256)
+conv_splitk_finish_pool_kernel(const float* __restrict__ ws, const float* __restrict__ bias, float* __restrict__ pooled,
+                               unsigned char* __restrict__ codes, int ksplit, int Cout, int OW, int PW, int64_t pplane) {
+    const int px = blockIdx.x * 256 + threadIdx.x, py = blockIdx.y;
+    if (px >= PW) return;
+    const int nc = blockIdx.z, n = nc / Cout, co = nc - n * Cout;  // (image, channel): one division per workgroup
+    const int64_t out_plane = 4 * pplane, per_n = (int64_t)Cout * out_plane;
+    const float* src = ws + (int64_t)n * ksplit * per_n + (int64_t)co * out_plane + (int64_t)(2 * py) * OW + 2 * px;
+    float2 r0 = make_float2(0.f, 0.f), r1 = make_float2(0.f, 0.f);
+    for (int k = 0; k < ksplit; ++k) {
+        const float2 a = *reinterpret_cast<const float2*>(src + (int64_t)k * per_n), c = *reinterpret_cast<const float2*>(src + (int64_t)k * per_n + OW);
+        r0.x += a.x; r0.y += a.y; r1.x += c.x; r1.y += c.y;
+    }
+    const float b = bias ? bias[co] : 0.f;
+    r0.x += b; r0.y += b; r1.x += b; r1.y += b;
+    r0.x = r0.x > 0.f ? r0.x : 0.f; r0.y = r0.y > 0.f ? r0.y : 0.f; r1.x = r1.x > 0.f ? r1.x : 0.f; r1.y = r1.y > 0.f ? r1.y : 0.f;
+    float m = r0.x;
+    int arg = 0;
+    if (r0.y > m || r0.y != r0.y) { m = r0.y; arg = 1; }
+    if (r1.x > m || r1.x != r1.x) { m = r1.x; arg = 2; }
+    if (r1.y > m || r1.y != r1.y) { m = r1.y; arg = 3; }
+    const int64_t ppix = (int64_t)py * PW + px;
+    pooled[(int64_t)nc * pplane + ppix] = m;
+    codes[(((int64_t)nc >> 3) * pplane + ppix) * 8 + (nc & 7)] = (unsigned char)(arg | (m > 0.f ? 0 : 4));  // (Cout % 8 == 0)
+}
+
+int conv_splitk_finish_pool(const ConvArgs& a, int n, int ksplit, hipStream_t stream) {
+    const int PW = a.OW / 2, PH = a.OH / 2;
+    dim3 grid((unsigned)((PW + 255) / 256), (unsigned)PH, (unsigned)(n * a.Cout));
+    hipLaunchKernelGGL(conv_splitk_finish_pool_kernel, grid, dim3(256), 0, stream, a.ws, a.bias, a.y, a.pool_codes, ksplit, a.Cout, a.OW, PW,
+                       (int64_t)PW * PH);
+    return check_launch("conv_splitk_finish_pool_kernel");
+}
+
 int conv3x3_few_out(const ConvArgs& a, int n, hipStream_t stream) {
     dim3 grid((unsigned)((a.OW + FO_TW - 1) / FO_TW), (unsigned)((a.OH + 4 * FO_R - 1) / (4 * FO_R)), (unsigned)n);
 #define MAUA_FO(CO_)                                                                                            \

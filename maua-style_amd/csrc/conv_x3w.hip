@@ -784,7 +784,7 @@ int conv_x3w_launch(const ConvArgs& a, int n, float w_scale, hipStream_t stream)
         }();
         p.stagger = stagger;
     }
-    if (a.pool_codes) hipLaunchKernelGGL((conv_x3w_kernel<false, false, true>), grid, dim3(256), 0, stream, p, w_inv);
+    if (a.pool_codes && ks == 1) hipLaunchKernelGGL((conv_x3w_kernel<false, false, true>), grid, dim3(256), 0, stream, p, w_inv);
     else if (a.in_codes && om) hipLaunchKernelGGL((conv_x3w_kernel<false, true, false, true>), grid, dim3(256), 0, stream, p, w_inv);
     else if (a.in_codes) hipLaunchKernelGGL((conv_x3w_kernel<false, false, false, true>), grid, dim3(256), 0, stream, p, w_inv);
     else if (acc && om) hipLaunchKernelGGL((conv_x3w_kernel<true, true>), grid, dim3(256), 0, stream, p, w_inv);
@@ -793,7 +793,8 @@ int conv_x3w_launch(const ConvArgs& a, int n, float w_scale, hipStream_t stream)
     else hipLaunchKernelGGL((conv_x3w_kernel<false, false>), grid, dim3(256), 0, stream, p, w_inv);
     int rc = check_launch("conv_x3w_kernel");
     if (rc || ks == 1) return rc;
-    return conv_splitk_finish(a, n, ks, stream);
+    // (a split channel loop leaves partial sums: the ReLU + pool of a pooling launch then happen in the pass that adds them)
+    return a.pool_codes ? conv_splitk_finish_pool(a, n, ks, stream) : conv_splitk_finish(a, n, ks, stream);
 }
 
 }  // namespace maua
@@ -919,7 +920,8 @@ int maua_conv_x3w_split(int n, int cin, int h, int w, int cout, int pad) {
 }
 
 int maua_conv3x3_x3w_relu_pool(const float* x, const void* bank, float w_scale, const float* bias, float* pooled,
-                               unsigned char* codes, int n, int cin, int h, int w, int cout, int pad, maua_stream_t stream) {
+                               unsigned char* codes, int n, int cin, int h, int w, int cout, int pad, void* workspace,
+                               size_t workspace_bytes, maua_stream_t stream) {
     MAUA_REQUIRE(x && bank && pooled && codes && w_scale > 0.f, MAUA_E_INVAL, "conv3x3_x3w_relu_pool: bad args");
     MAUA_REQUIRE(conv_dims_ok(n, cin, h, w, cout, pad) && pad <= 2, MAUA_E_INVAL, "conv3x3_x3w_relu_pool: bad dims");
     ConvArgs a{};
@@ -938,7 +940,8 @@ int maua_conv3x3_x3w_relu_pool(const float* x, const void* bank, float w_scale, 
     a.relu = 1;
     MAUA_REQUIRE(a.OH >= 2 && a.OW >= 2 && a.OH % 2 == 0 && a.OW % 2 == 0 && cout % 8 == 0 && conv_x3w_supports(a), MAUA_E_UNSUPPORTED,
                  "conv3x3_x3w_relu_pool: needs an even output plane, cin %% 16 == 0, cout %% 8 == 0");
-    a.ws = nullptr;  // one pass over the channels: the epilogue holds complete sums
+    // without a workspace: one pass over the channels, the epilogue holds complete sums and pools them itself
+    a.ws = (workspace && workspace_bytes >= maua_conv_x3w_workspace_bytes(n, cin, h, w, cout, pad)) ? (float*)workspace : nullptr;
     return conv_x3w_launch(a, n, w_scale, (hipStream_t)stream);
 }
 

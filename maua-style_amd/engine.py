@@ -171,9 +171,9 @@ class StyleEngine:
         self.gram_batch_on = os.environ.get("MAUA_GRAM_BATCH", "1") != "0"
         self.gram_partial_batch_on = os.environ.get("MAUA_GRAM_PARTIAL_BATCH", "1") != "0"  # (... and one partial launch for the Gram-form layers)
         self._gram_wsp, self._gram_batches = getattr(self, "_gram_wsp", {}), {}
-        # conv + ReLU whose only consumer is a 2x2 / 2 max pool with kept decisions, on conv_x3w.hip in one pass over the
-        # channels: the pool runs in the convolution's epilogue and the full-size activation is never written (nothing reads
-        # it: the backward pass routes by the decision bytes).  fused_pool[conv step] = pool step.
+        # conv + ReLU whose only consumer is a 2x2 / 2 max pool with kept decisions, on conv_x3w.hip: the pool runs in the convolution's
+        # epilogue (or, where a small grid splits the channel loop, in the pass that adds the slabs) and the full-size activation is
+        # never written (nothing reads it: the backward pass routes by the decision bytes).  fused_pool[conv step] = pool step.
         self.fused_pool = {}
         if self.x6_fwd and os.environ.get("MAUA_FUSE_POOL", "1") != "0":
             for s in self.steps:
@@ -182,7 +182,8 @@ class StyleEngine:
                 users = [t for t in self.steps if t.src == s.dst and t is not s]
                 if len(users) == 1 and users[0].kind == "pool" and id(users[0]) in self.pool_codes and \
                         self._x6_ok(s, s.mod.out_channels) and models_mod.conv3x3_fwd_is_x3w(s.mod, *shapes[s.src][2:]) and \
-                        hip.conv_x3w_split(B, shapes[s.src][1], shapes[s.src][2], shapes[s.src][3], s.mod.out_channels, s.pad) == 1:
+                        s.mod.out_channels % 8 == 0 and (os.environ.get("MAUA_FUSE_POOL_SPLIT", "1") != "0" or hip.conv_x3w_split(
+                            B, shapes[s.src][1], shapes[s.src][2], shapes[s.src][3], s.mod.out_channels, s.pad) == 1):
                     self.fused_pool[id(s)] = users[0]
         self.pooled_by_conv = {id(v) for v in self.fused_pool.values()}
         for s in self.steps:  # (those activations exist as shapes only: 0.5 GB less at 1024x1024)
@@ -418,7 +419,7 @@ class StyleEngine:
                 if id(s) in self.fused_pool:
                     ps = self.fused_pool[id(s)]
                     self._timed("conv3x3_split_fwd", fl, nb, lambda: models_mod.conv3x3_relu_pool(
-                        a[s.src], s.mod, a[ps.dst], self.pool_codes[id(ps)]))
+                        a[s.src], s.mod, a[ps.dst], self.pool_codes[id(ps)], workspace=self.ws))
                 elif self.x6_fwd and self._x6_ok(s, s.mod.out_channels):
                     self._timed("conv3x3_split_fwd", fl, nb, lambda: models_mod.conv3x3_mfma(
                         a[s.src], s.mod, False, out=a[s.dst], relu=s.relu, workspace=self.ws))
@@ -751,7 +752,7 @@ class StyleEngine:
             if s.kind == "conv":
                 if id(s) in self.fused_pool:
                     ps = self.fused_pool[id(s)]
-                    models_mod.conv3x3_relu_pool(a[s.src], s.mod, a[ps.dst], self.pool_codes[id(ps)])
+                    models_mod.conv3x3_relu_pool(a[s.src], s.mod, a[ps.dst], self.pool_codes[id(ps)], workspace=self.ws)
                 elif self.x6_fwd and self._x6_ok(s, s.mod.out_channels):
                     models_mod.conv3x3_mfma(a[s.src], s.mod, False, out=a[s.dst], relu=s.relu, workspace=self.ws)
                 elif self.x6_fwd and models_mod.conv1x1_is_mfma(s.mod, False):

@@ -74,7 +74,7 @@ SIGNATURES = {
     "maua_set_split_batch_hint": (None, [c_i]),
     "maua_get_split_batch_hint": (c_i, []),
     "maua_conv_x3w_split": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
-    "maua_conv3x3_x3w_relu_pool": (c_i, [c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "maua_conv3x3_x3w_relu_pool": (c_i, [c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "maua_conv_x3w_dmat_bank_bytes": (c_sz, [c_i]),
     "maua_conv_pack_dmat_x3w": (c_i, [c_p, c_i, c_p, c_p, c_p]),
     "maua_conv3x3_x3w_gram": (c_i, [c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
@@ -302,11 +302,13 @@ def conv_x3w_split(n, cin, h, w, cout, pad):
     return int(lib().maua_conv_x3w_split(int(n), int(cin), int(h), int(w), int(cout), int(pad)))
 
 
-def conv3x3_x3w_relu_pool(x, bank, w_scale, bias, cout, pad, pooled, codes):
-    """conv + bias + ReLU + 2x2 / 2 max pool in one launch: writes `pooled` and the pool's decision bytes only."""
+def conv3x3_x3w_relu_pool(x, bank, w_scale, bias, cout, pad, pooled, codes, workspace=None):
+    """conv + bias + ReLU + 2x2 / 2 max pool: writes `pooled` and the pool's decision bytes only.  One launch without a workspace (one
+    pass over the channels); with one, small grids split the channel loop and the pass that adds the slabs applies ReLU and pool."""
     n, cin, h, w = x.shape
+    wp, wn = (workspace.data_ptr(), workspace.numel() * workspace.element_size()) if workspace is not None else (None, 0)
     _check(lib().maua_conv3x3_x3w_relu_pool(_ptr(_f32(x, "x")), bank.data_ptr(), float(w_scale), _ptr(bias), _ptr(pooled),
-                                            codes.data_ptr(), n, cin, h, w, cout, pad, _stream()), "maua_conv3x3_x3w_relu_pool")
+                                            codes.data_ptr(), n, cin, h, w, cout, pad, wp, wn, _stream()), "maua_conv3x3_x3w_relu_pool")
     return pooled
 
 

@@ -111,10 +111,11 @@ def conv3x3_fwd_is_x3w(mod, h, w):
         hip.conv_x3w_supported(mod.in_channels, h, w, mod.padding[0])
 
 
-def conv3x3_relu_pool(x, mod, pooled, codes):
-    """conv + bias + ReLU + the 2x2 / 2 max pool behind it in one launch (hip.conv3x3_x3w_relu_pool)."""
+def conv3x3_relu_pool(x, mod, pooled, codes, workspace=None):
+    """conv + bias + ReLU + the 2x2 / 2 max pool behind it without the full-size activation (hip.conv3x3_x3w_relu_pool: one launch, or -
+    small grids, with a workspace - a split channel loop whose adding pass pools)."""
     bf, _, wsc = mod.banks3w()
-    return hip.conv3x3_x3w_relu_pool(x, bf, wsc, mod.bias_device(), mod.out_channels, mod.padding[0], pooled, codes)
+    return hip.conv3x3_x3w_relu_pool(x, bf, wsc, mod.bias_device(), mod.out_channels, mod.padding[0], pooled, codes, workspace=workspace)
 
 
 def conv3x3_bwd_is_x3w(mod, h, w):

@@ -1026,7 +1026,8 @@ def test_backward_pass_with_the_gram_backward_along(hip, cin, c, H, W):
     assert 32.0 <= float(d.abs().max()) / float(dinv[0]) < 64.0
 
 
-@pytest.mark.parametrize("n,cin,cout,H,W", [(1, 64, 64, 64, 96), (2, 128, 128, 40, 72), (1, 64, 128, 34, 62), (1, 16, 200, 18, 260)])
+@pytest.mark.parametrize("n,cin,cout,H,W", [(1, 64, 64, 64, 96), (2, 128, 128, 40, 72), (1, 64, 128, 34, 62), (1, 16, 200, 18, 260),
+                                            (1, 512, 512, 64, 64), (1, 256, 256, 32, 64)])
 def test_conv_relu_pool_in_one_launch_equals_the_three_steps(hip, n, cin, cout, H, W):
     """maua_conv3x3_x3w_relu_pool against maua_conv3x3_x3w (+ ReLU) followed by maua_pool2x2_fwd_codes: the same pooled map
     and the same decision bytes, bit for bit (zero windows, ties and all), and the backward routing from those bytes."""
@@ -1045,6 +1046,15 @@ def test_conv_relu_pool_in_one_launch_equals_the_three_steps(hip, n, cin, cout, 
     hip.conv3x3_x3w_relu_pool(dev(x), bf, wsc, dev(b), cout, 1, p1, c1)
     torch.cuda.synchronize()
     assert torch.equal(p0, p1) and torch.equal(c0, c1)
+    # with room for slabs the channel loop may be split: ReLU and pool then happen in the pass that adds the slabs - against the same
+    # three steps under the same split
+    ws = torch.empty(max(hip.conv_x3w_workspace_bytes(n, cin, H, W, cout, 1), 16), dtype=torch.uint8, device="cuda")
+    y = hip.conv3x3_x3w(dev(x), bf, wsc, dev(b), cout, 1, True, workspace=ws)
+    hip.pool2x2_fwd_codes(y, p0, c0)
+    p2, c2 = torch.full_like(p0, float("nan")), torch.full_like(c0, 255)
+    hip.conv3x3_x3w_relu_pool(dev(x), bf, wsc, dev(b), cout, 1, p2, c2, workspace=ws)
+    torch.cuda.synchronize()
+    assert torch.equal(p0, p2) and torch.equal(c0, c2)
     from conftest import planar_codes
     assert int((planar_codes(c1)[:, :4] == 4).all()) == 1  # zero channels: first position, "not positive"
 

@@ -10,7 +10,7 @@ libs = [ctypes.CDLL(os.path.abspath(p)) for p in sys.argv[1:3]]
 c_p, c_i, c_f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 for L in libs:
     L.maua_conv3x3_x3w_relu_pool.restype = c_i
-    L.maua_conv3x3_x3w_relu_pool.argtypes = [c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]
+    L.maua_conv3x3_x3w_relu_pool.argtypes = [c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, ctypes.c_size_t, c_p]
 torch.manual_seed(0)
 for name, c, s in (("conv1_2", 64, side), ("conv2_2", 128, side // 2), ("conv3_4", 256, side // 4), ("conv4_4", 512, side // 8)):
     x = torch.relu(torch.randn(1, c, s, s, device="cuda"))
@@ -24,7 +24,7 @@ for name, c, s in (("conv1_2", 64, side), ("conv2_2", 128, side // 2), ("conv3_4
     outs = []
     for L in libs:
         def run():
-            rc = L.maua_conv3x3_x3w_relu_pool(x.data_ptr(), bf.data_ptr(), float(wsc), b.data_ptr(), pooled.data_ptr(), codes.data_ptr(), 1, c, s, s, c, 1, st)
+            rc = L.maua_conv3x3_x3w_relu_pool(x.data_ptr(), bf.data_ptr(), float(wsc), b.data_ptr(), pooled.data_ptr(), codes.data_ptr(), 1, c, s, s, c, 1, None, 0, st)
             assert rc == 0
         best = 1e9
         for _ in range(5):

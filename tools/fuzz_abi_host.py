@@ -67,7 +67,7 @@ def main():
         rcs = [
             L.maua_conv3x3_wino(ptr, ptr, ptr, None, ptr, n, cin, h, w, cout, pad, 1, 0, None),
             L.maua_conv3x3_x3w(ptr, ptr, 1.0, ptr, None, ptr, n, cin, h, w, cout, pad, 1, 0, ptr, ws_bytes, None),
-            L.maua_conv3x3_x3w_relu_pool(ptr, ptr, 1.0, ptr, ptr, ptr, n, cin, h, w, cout, pad, None),
+            L.maua_conv3x3_x3w_relu_pool(ptr, ptr, 1.0, ptr, ptr, ptr, n, cin, h, w, cout, pad, ptr, ws_bytes, None),
             L.maua_conv3x3_x3w_gram(ptr, ptr, 1.0, ptr, ptr, ptr, ptr, n, cin, h, w, cout, pad, 0, ptr, ws_bytes, None),
             L.maua_conv3x3_x3w_unpool(ptr, ptr, rng.randint(0, 1), ptr, 1.0, rng.choice([None, ptr]), rng.choice([None, ptr]), ptr, ptr, n, cin, h, w,
                                       cout, pad, ptr, ws_bytes, None),
