@@ -90,13 +90,17 @@ __device__ inline float lane_from_right(float v) {  // lane i <- lane i+1  (wave
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));
 }
 
-template <int CO, bool MASK>
+// KS4 (small images: a 256 x 256 plane is 80 workgroups of the plain form on 256 CUs, each walking all 64 channels): the four waves of
+// a workgroup share ONE strip of FO_R rows and take a quarter of the input channels each; waves 1-3 leave their sums in LDS and wave 0
+// adds them in wave order (fixed order).  Four times the workgroups, a quarter of the dependent channel steps per wave.
+template <int CO, bool MASK, bool KS4 = false>
 __global__ void __launch_bounds__(256)
 conv3x3_few_out_kernel(ConvArgs p, const float* __restrict__ wbank) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = blockIdx.z;
     const int ox = blockIdx.x * FO_TW + lane - 1;          // output column (lanes 1..62 are stored)
-    const int oy0 = (blockIdx.y * 4 + wave) * FO_R;        // first of the FO_R output rows of this wave
+    const int oy0 = (KS4 ? blockIdx.y : blockIdx.y * 4 + wave) * FO_R;  // first of the FO_R output rows of this wave
+    const int ci_begin = KS4 ? wave * (p.Cin >> 2) : 0, ci_end = KS4 ? ci_begin + (p.Cin >> 2) : p.Cin;
     const int cx = ox - p.pad + 1;                         // input column of the centre tap
     const bool col_ok = cx >= 0 && cx < p.W;
     const int64_t plane = (int64_t)p.H * p.W;
@@ -126,9 +130,9 @@ conv3x3_few_out_kernel(ConvArgs p, const float* __restrict__ wbank) {
 #pragma unroll
         for (int c = 0; c < CO; ++c) master[r][c] = acc[r][c] = 0.f;
     float cur[FO_R + 2], nxt[FO_R + 2];
-    load(0, cur);
-    for (int ci = 0; ci < p.Cin; ++ci) {
-        load(min(ci + 1, p.Cin - 1), nxt);  // unconditional (the last one re-reads its own channel)
+    load(ci_begin, cur);
+    for (int ci = ci_begin; ci < ci_end; ++ci) {
+        load(min(ci + 1, ci_end - 1), nxt);  // unconditional (the last one re-reads its own channel)
         float wv[9][CO];  // wave-uniform: bank layout [tap][ci][co]
 #pragma unroll
         for (int t = 0; t < 9; ++t)
@@ -149,7 +153,7 @@ conv3x3_few_out_kernel(ConvArgs p, const float* __restrict__ wbank) {
                 }
             }
         }
-        if ((ci & 7) == 7 || ci + 1 == p.Cin) {  // two-level accumulation like the MFMA kernels
+        if ((ci & 7) == 7 || ci + 1 == ci_end) {  // two-level accumulation like the MFMA kernels
 #pragma unroll
             for (int r = 0; r < FO_R; ++r)
 #pragma unroll
@@ -160,6 +164,23 @@ conv3x3_few_out_kernel(ConvArgs p, const float* __restrict__ wbank) {
         }
 #pragma unroll
         for (int r = 0; r < FO_R + 2; ++r) cur[r] = nxt[r];
+    }
+    if constexpr (KS4) {
+        __shared__ float red[3][FO_R * CO][64];
+        if (wave > 0) {
+#pragma unroll
+            for (int r = 0; r < FO_R; ++r)
+#pragma unroll
+                for (int c = 0; c < CO; ++c) red[wave - 1][r * CO + c][lane] = master[r][c];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int r = 0; r < FO_R; ++r)
+#pragma unroll
+                for (int c = 0; c < CO; ++c) master[r][c] += red[w][r * CO + c][lane];
     }
     if (lane < 1 || lane > FO_TW || ox >= p.OW) return;
     const int64_t oplane = (int64_t)p.OH * p.OW;
@@ -270,9 +291,19 @@ int conv_splitk_finish_pool(const ConvArgs& a, int n, int ksplit, hipStream_t st
 
 int conv3x3_few_out(const ConvArgs& a, int n, hipStream_t stream) {
     dim3 grid((unsigned)((a.OW + FO_TW - 1) / FO_TW), (unsigned)((a.OH + 4 * FO_R - 1) / (4 * FO_R)), (unsigned)n);
+    // channel quarters per wave where the plain grid leaves most of the chip idle (the planned frames per launch count, not this
+    // launch's: a frame's bits do not depend on how many others share its launch)
+    static const int ks4_below = [] {
+        const char* e = getenv("MAUA_FEW_OUT_KS4_BELOW");
+        return e ? atoi(e) : 1024;
+    }();
+    const bool ks4 = (int64_t)grid.x * grid.y * split_batch_hint() < ks4_below && a.Cin % 32 == 0;
+    if (ks4) grid.y = (unsigned)((a.OH + FO_R - 1) / FO_R);
 #define MAUA_FO(CO_)                                                                                            \
     case CO_:                                                                                                   \
-        if (a.mask) hipLaunchKernelGGL((conv3x3_few_out_kernel<CO_, true>), grid, dim3(256), 0, stream, a, a.w);      \
+        if (ks4 && a.mask) hipLaunchKernelGGL((conv3x3_few_out_kernel<CO_, true, true>), grid, dim3(256), 0, stream, a, a.w);  \
+        else if (ks4) hipLaunchKernelGGL((conv3x3_few_out_kernel<CO_, false, true>), grid, dim3(256), 0, stream, a, a.w);      \
+        else if (a.mask) hipLaunchKernelGGL((conv3x3_few_out_kernel<CO_, true>), grid, dim3(256), 0, stream, a, a.w); \
         else hipLaunchKernelGGL((conv3x3_few_out_kernel<CO_, false>), grid, dim3(256), 0, stream, a, a.w);             \
         break;
     switch (a.Cout) {
