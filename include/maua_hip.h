@@ -138,6 +138,9 @@ int maua_conv3x3_x3w_relu_pool(const float* x, const void* bank, float w_scale, 
  * no covariance centring; `feature_map` is both the ReLU mask and the operand of D . F. */
 size_t maua_conv_x3w_dmat_bank_bytes(int c);
 int maua_conv_pack_dmat_x3w(const float* dmat, int c, void* bank, float* inv_scale_out, maua_stream_t stream);
+/* ... of up to four layers in one launch (host arrays of `count` entries; the same banks and scales as the per-layer call) */
+int maua_conv_pack_dmat_x3w_batch(int count, const float* const* dmats, const int* cs, void* const* banks, float* const* inv_scales_out,
+                                  maua_stream_t stream);
 int maua_conv3x3_x3w_gram(const float* x, const void* bank, float w_scale, const float* feature_map, const void* dmat_bank,
                           const float* dmat_inv_scale, float* y, int n, int cin, int h, int w, int cout, int pad, int accumulate,
                           void* workspace, size_t workspace_bytes, maua_stream_t stream);

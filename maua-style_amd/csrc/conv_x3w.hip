@@ -90,8 +90,8 @@ __global__ void pack_x3w_kernel(const float* __restrict__ w, unsigned short* __r
 // conv_x3w_kernel: bank[chunk16][cotile][part][octet][co][ch] = D[co][ch] scaled by a power of two that brings max |D| into
 // [32, 64) like the 3x3 banks; inv[0] = 1 / scale.  Every workgroup finds the maximum itself (C <= 512: 1 MB out of L2), then
 // packs its share: a thread takes the 8 consecutive values of one (chunk, tile, octet, co) and writes their two 16-byte halves.
-__global__ void __launch_bounds__(1024) pack_dmat_x3w_kernel(const float* __restrict__ d, int C, unsigned short* __restrict__ bank,
-                                                             float* __restrict__ inv) {
+__device__ __forceinline__ void pack_dmat_x3w_body(const float* __restrict__ d, int C, unsigned short* __restrict__ bank,
+                                                   float* __restrict__ inv) {
     __shared__ float wmax[16];
     const int tid = threadIdx.x;
     const int64_t total4 = (int64_t)C * C / 4;  // (C % 16 == 0)
@@ -138,6 +138,20 @@ __global__ void __launch_bounds__(1024) pack_dmat_x3w_kernel(const float* __rest
         *reinterpret_cast<u32x4*>(base + (0 * 2 + oct) * 1024) = Hh;
         *reinterpret_cast<u32x4*>(base + (1 * 2 + oct) * 1024) = Ll;
     }
+}
+__global__ void __launch_bounds__(1024) pack_dmat_x3w_kernel(const float* __restrict__ d, int C, unsigned short* __restrict__ bank,
+                                                             float* __restrict__ inv) {
+    pack_dmat_x3w_body(d, C, bank, inv);
+}
+// ... of up to four style layers in one launch (grid y = layer; every layer's workgroups stride over its own groups)
+struct DmatPackBatch {
+    const float* d[4];
+    unsigned short* bank[4];
+    float* inv[4];
+    int C[4];
+};
+__global__ void __launch_bounds__(1024) pack_dmat_x3w_batch_kernel(DmatPackBatch b) {
+    pack_dmat_x3w_body(b.d[blockIdx.y], b.C[blockIdx.y], b.bank[blockIdx.y], b.inv[blockIdx.y]);
 }
 
 // Diagnostic build only (-DXW_STAMP, tools/x3w_clock.py): shader-clock stamps at the phase boundaries of every chunk go to a
@@ -839,6 +853,25 @@ int maua_conv_pack_dmat_x3w(const float* dmat, int c, void* bank, float* inv_sca
     hipLaunchKernelGGL(pack_dmat_x3w_kernel, dim3((unsigned)((groups + 4095) / 4096)), dim3(1024), 0, (hipStream_t)stream, dmat, c,
                        (unsigned short*)bank, inv_scale_out);
     return check_launch("pack_dmat_x3w_kernel");
+}
+
+int maua_conv_pack_dmat_x3w_batch(int count, const float* const* dmats, const int* cs, void* const* banks, float* const* inv_scales_out,
+                                  maua_stream_t stream) {
+    MAUA_REQUIRE(count > 0 && count <= 4 && dmats && cs && banks && inv_scales_out, MAUA_E_INVAL, "conv_pack_dmat_x3w_batch: bad args (at most 4 layers)");
+    DmatPackBatch b{};
+    int64_t most = 0;
+    for (int i = 0; i < count; ++i) {
+        MAUA_REQUIRE(dmats[i] && banks[i] && inv_scales_out[i] && cs[i] > 0 && cs[i] % 16 == 0 && cs[i] <= (1 << 14), MAUA_E_INVAL,
+                     "conv_pack_dmat_x3w_batch: layer %d needs a C x C matrix with C %% 16 == 0", i);
+        b.d[i] = dmats[i];
+        b.bank[i] = (unsigned short*)banks[i];
+        b.inv[i] = inv_scales_out[i];
+        b.C[i] = cs[i];
+        const int64_t groups = (int64_t)(cs[i] / 16) * ((cs[i] + XW_COT - 1) / XW_COT) * 2 * XW_COT;
+        most = groups > most ? groups : most;
+    }
+    hipLaunchKernelGGL(pack_dmat_x3w_batch_kernel, dim3((unsigned)((most + 4095) / 4096), (unsigned)count), dim3(1024), 0, (hipStream_t)stream, b);
+    return check_launch("pack_dmat_x3w_batch_kernel");
 }
 
 int maua_conv_x3w_supported(int cin, int h, int w, int pad) {

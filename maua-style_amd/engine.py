@@ -557,10 +557,20 @@ class StyleEngine:
                     if later:
                         self._timed("gram_fwd", sum(2 * l["c"] * l["c"] * l["hw"] for l in grp), sum(l["c"] * l["hw"] * 4 for l in grp), fin[1].run_partial)
                     self._timed("gram_fwd", 0, sum(l["c"] * l["c"] * 8 for l in grp), fin[1].run)
-                for l in batch:
-                    if id(l["step"]) in self.fused_style:
-                        fs = self.fused_style[id(l["step"])]
-                        hip.conv_pack_dmat_x3w(l["dmat"], fs[1][0], fs[2])
+                packs = [(l["dmat"], self.fused_style[id(l["step"])][1][0], self.fused_style[id(l["step"])][2]) for l in batch
+                         if id(l["step"]) in self.fused_style]
+                if os.environ.get("MAUA_DMAT_PACK_BATCH", "1") == "0":
+                    for d, b, i in packs:
+                        hip.conv_pack_dmat_x3w(d, b, i)
+                    packs = []
+                for k0 in range(0, len(packs), 4):  # the one-tap banks of the fused layers' D matrices, one launch
+                    grp = packs[k0:k0 + 4]
+                    key = tuple((d.data_ptr(), b.data_ptr(), i.data_ptr()) for d, b, i in grp)
+                    pk = self._gram_batches.get(("pack", k0))
+                    if pk is None or pk[0] != key:
+                        pk = (key, hip.DmatPackBatch(grp))
+                        self._gram_batches[("pack", k0)] = pk
+                    pk[1].run()
         # ---------------- backward
         # Gradient buffers of fused conv+ReLU activations are kept PRE-MASKED: the last kernel that writes g[k] (the
         # backward of the consumer, or the last loss term attached to k) zeroes it where a[k] <= 0, so no backward-data

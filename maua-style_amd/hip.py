@@ -77,6 +77,7 @@ SIGNATURES = {
     "maua_conv3x3_x3w_relu_pool": (c_i, [c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "maua_conv_x3w_dmat_bank_bytes": (c_sz, [c_i]),
     "maua_conv_pack_dmat_x3w": (c_i, [c_p, c_i, c_p, c_p, c_p]),
+    "maua_conv_pack_dmat_x3w_batch": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p]),
     "maua_conv3x3_x3w_gram": (c_i, [c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "maua_conv3x3_x3w_unpool": (c_i, [c_p, c_p, c_i, c_p, c_f, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "maua_conv_wino_bank_bytes": (c_sz, [c_i, c_i]),
@@ -325,6 +326,21 @@ def conv_pack_dmat_x3w(dmat, bank, inv_scale):
     c = dmat.shape[0]
     _check(lib().maua_conv_pack_dmat_x3w(_ptr(_f32(dmat, "dmat")), c, bank.data_ptr(), _ptr(inv_scale), _stream()),
            "maua_conv_pack_dmat_x3w")
+
+
+class DmatPackBatch:
+    """conv_pack_dmat_x3w for up to four layers in one launch; the argument arrays are built once per engine plan."""
+
+    def __init__(self, items):
+        """items: list of (dmat (C, C), bank, inv_scale) as for conv_pack_dmat_x3w"""
+        n = len(items)
+        self.n, self.keep = n, items
+        self.args = ((ctypes.c_void_p * n)(*[_ptr(_f32(d, "dmat")) for d, _, _ in items]), (ctypes.c_int * n)(*[int(d.shape[0]) for d, _, _ in items]),
+                     (ctypes.c_void_p * n)(*[b.data_ptr() for _, b, _ in items]), (ctypes.c_void_p * n)(*[_ptr(i) for _, _, i in items]))
+
+    def run(self):
+        a = self.args
+        _check(lib().maua_conv_pack_dmat_x3w_batch(self.n, a[0], a[1], a[2], a[3], _stream()), "maua_conv_pack_dmat_x3w_batch")
 
 
 def conv3x3_x3w_gram(x, bank, w_scale, feature_map, dmat_bank, dmat_inv_scale, cout, pad, out=None, accumulate=False,

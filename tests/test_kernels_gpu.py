@@ -1135,3 +1135,23 @@ def test_gram_partial_batch_leaves_the_slabs_of_the_per_layer_launches(hip):
     for (g0, d0), l in zip(want, layers):
         assert torch.equal(g0, l["gram"]) and torch.equal(d0, l["dmat"])
     assert torch.equal(la, lb) and torch.equal(ta, tb) and float(ta) > 0
+
+
+def test_dmat_pack_batch_equals_the_per_layer_launches(hip):
+    """maua_conv_pack_dmat_x3w_batch (the one-tap banks of relu1_1 / 2_1 / 3_1's D matrices in one launch) against the per-layer call."""
+    items, want = [], []
+    for k, c in enumerate((64, 128, 256, 48)):
+        d = rnd(c, c, seed=700 + k) * 10.0 ** (k - 4)
+        d = dev((d + d.t()).contiguous())
+        b0, i0 = hip.conv_x3w_dmat_bank(c, "cuda")
+        hip.conv_pack_dmat_x3w(d, b0[0], i0)
+        want.append((b0, i0))
+        b1, i1 = hip.conv_x3w_dmat_bank(c, "cuda")
+        b1.fill_(255)
+        items.append((d, b1[0], i1))
+    hip.DmatPackBatch(items).run()
+    torch.cuda.synchronize()
+    for (b0, i0), (_, b1, i1) in zip(want, items):
+        assert torch.equal(b0[0], b1) and torch.equal(i0, i1)
+    with pytest.raises(hip.HipError):
+        hip.DmatPackBatch(items + items[:1]).run()
