@@ -270,11 +270,13 @@ class StyleEngine:
         # streams so that the GPU overlaps them (fork after the kernel that produced their input, join before the next
         # kernel that reads their output).  Every stream has its own reduction / split-K workspace.
         # A single image: the Gram / loss chain of a style layer only has to be done when the backward pass starts, so it
-        # runs on ONE side stream next to the following convolutions (large images; MAUA_STYLE_STREAM=0 / 1 forces it off / on).
+        # can run on ONE side stream next to the following convolutions (MAUA_STYLE_STREAM=0 / 1 forces it off / on).  Round 3: with the
+        # partial kernels of all layers in one launch behind the forward pass the serial form wins up to 1448 x 1448 (724: 263.7 vs
+        # 261.8 it/s, 1024: 178.9 vs 177.8, 1448: 80.3 vs 80.9, 2048: 44.07 vs 44.35) - the side stream is for the largest images.
         self.side, self.side_ws, self.ev_main, self.ev_side = [], [], None, []
-        aside = os.environ.get("MAUA_STYLE_STREAM", "auto")  # measured: +1 % at 1024x1024, -3 % at 256x256 (graph edges cost there)
+        aside = os.environ.get("MAUA_STYLE_STREAM", "auto")
         self.style_aside = B == 1 and self.ledger is not None and \
-            (aside == "1" or (aside == "auto" and x.shape[2] * x.shape[3] >= 768 * 768))
+            (aside == "1" or (aside == "auto" and x.shape[2] * x.shape[3] >= 1536 * 1536))
         if (B > 1 and self.independent and int(os.environ.get("MAUA_SIDE_STREAMS", "4")) > 0) or self.style_aside:
             ns = min(B, int(os.environ.get("MAUA_SIDE_STREAMS", "4"))) if B > 1 else 1
             small = hip.reduce_workspace_bytes(max(t.numel() for t in self.gbuf.values()) // B)

@@ -39,35 +39,31 @@ for a, b in (("sizes_lbfgs.jsonl", f"bench_r{rr}_sizes_lbfgs.jsonl"), ("sizes_ad
              ("configs.json", f"configs_r{rr}_final.json"), ("pmc_traffic.json", f"pmc_r{rr}_traffic.json")):
     shutil.copy(os.path.join(src, a), os.path.join(dst, b))
 serial = os.path.join(src, "stats", "p_kernel_stats.csv")
-overlap = os.path.join(src, "stats_overlap", "p_kernel_stats.csv")
 shutil.copy(serial, os.path.join(dst, f"rocprof_r{rr}_kernel_stats_1024_lbfgs.csv"))
 table = subprocess.run([sys.executable, os.path.join(REPO, "tools", "summarise_stats.py"), serial, "122", rr], capture_output=True, text=True, check=True).stdout
-table = table.replace("--no_cpu_baseline --no_extra_sizes --no_hip_graph`   (tools/profile_round.sh)",
-                      "--no_cpu_baseline --no_extra_sizes --no_hip_graph` with `MAUA_STYLE_STREAM=0` in the environment   (tools/profile_round.sh)")
 s_avg, s_calls = conv_avg(serial)
-o_avg, _ = conv_avg(overlap)
 under = last_json(os.path.join(src, "bench_under_rocprof.json"))
 graph = last_json(os.path.join(src, "bench_graph.json"))
 note = f"""
-**Why `MAUA_STYLE_STREAM=0` here.**  By default (images of 768² and more) the Gram / loss chain of a style layer runs on a side
-stream NEXT TO the following convolutions; in a kernel trace the concurrent kernels then stretch each other (same command without the
-variable: `gram_x3_partial_kernel` {kernel_avg(overlap, 'gram_x3_partial_kernel'):.0f} µs per launch instead of {kernel_avg(serial, 'gram_x3_partial_kernel'):.0f}, `conv_x3w_kernel` {o_avg:.1f} µs averaged over its
-variants instead of {s_avg:.1f}) although the iteration is shorter.  `bench.py` brackets every convolution launch with HIP events in a
-pass of its own where everything is in stream order, so this serial trace is the one its `roofline.avg_launch_ms` has to agree with:
+Everything of an iteration is in stream order at this size (the Gram / loss chains moved off the side stream in round 3: their partial
+kernels go out in two launches behind the forward pass; images of 1536² and more still overlap them with the convolutions).  `bench.py`
+brackets every convolution launch with HIP events in a pass of its own, and this trace is what its `roofline.avg_launch_ms` has to agree with:
 **{s_avg:.1f} µs here ({s_calls} launches of the `conv_x3w_kernel` variants) against {under['roofline']['avg_launch_ms'] * 1e3:.1f} µs in `bench_r{rr}_under_rocprof.json`** (the JSON
 line of this very run: the events also see the launch gaps of an eager run under the profiler).  Unprofiled, the same figure is
-{graph['roofline']['avg_launch_ms'] * 1e3:.1f} µs (`bench_r{rr}_final_1024_lbfgs.json`, {graph['value']:.1f} it/s with graph replay and the side stream on).
+{graph['roofline']['avg_launch_ms'] * 1e3:.1f} µs (`bench_r{rr}_final_1024_lbfgs.json`, {graph['value']:.1f} it/s with graph replay).
 
-What the variants are: `<false,false,false>` plain forward / backward-data launches; `<false,true,false>` backward-data with the ReLU mask of the
-produced gradient in the epilogue - five per iteration, three of them carrying the Gram backward of relu1_1 / relu2_1 / relu3_1
-(`maua_conv3x3_x3w_gram`); `<false,false,true>` forward with ReLU + 2x2 max pool in the epilogue (conv1_2, 2_2, 3_4, 4_4).
+What the variants are (template arguments ACC, OM, POOL, UNPOOL): `<false,false,false,false>` plain forward / backward-data launches;
+`<false,true,false,false>` backward-data with the ReLU mask of the produced gradient in the epilogue, one of them carrying the Gram backward of
+relu3_1 (`maua_conv3x3_x3w_gram`); `<false,true,false,true>` the backward passes of conv1_2 / 2_2 / 3_4 / 4_4 staged from the POOLED map's gradient
+and the pool's decision bytes (`maua_conv3x3_x3w_unpool`; conv1_2 / conv2_2 with the Gram backward of relu1_1 / relu2_1 along);
+`<false,false,true,false>` forward with ReLU + 2x2 max pool in the epilogue (conv1_2, 2_2, 3_4, 4_4).
 L-BFGS kernels: the averages include the 100 history-filling iterations (sweeps grow linearly with the history: ~450 µs each at
 full history, see `probes_r{rr}.md`).
 """
 i = table.index("\n| kernel |")
 with open(os.path.join(dst, f"rocprof_r{rr}_summary.md"), "w") as f:
     f.write(table[:i] + note + table[i:])
-print("serial conv avg", round(s_avg, 1), "overlap", round(o_avg, 1), "bench under rocprof", under["roofline"]["avg_launch_ms"], "graph", graph["value"], graph["roofline"]["frac"])
+print("serial conv avg", round(s_avg, 1), "bench under rocprof", under["roofline"]["avg_launch_ms"], "graph", graph["value"], graph["roofline"]["frac"])
 for l in open(os.path.join(src, "sizes_lbfgs.jsonl")):
     d = json.loads(l)
     print(d["config"]["image_size"], d["value"], d["roofline"]["frac"])
