@@ -91,6 +91,16 @@ int maua_conv3x3_x6(const float* x, const void* bank, const float* bias, const f
                     int cin, int h, int w, int cout, int pad, int relu, int accumulate, void* workspace,
                     size_t workspace_bytes, maua_stream_t stream);
 
+/* The image layer in the same exact bf16x6 arithmetic without the general kernel's padding: a 3x3 stride-1 convolution that consumes
+ * 1-3 channels (`nn.Conv2d(3, 64, 3, padding=1)` + `nn.ReLU`, models.py:129-130: conv1_1) with K = the 9 cin (channel, tap) pairs in two
+ * K = 16 matrix steps, filters in registers, pixels gathered from the image - bound by writing the activation (conv_img.hip).
+ * Bank: maua_conv_image_bank_bytes(cout, cin) bytes, packed from the OIHW weights AND the bias (nullable) once per weight set: the bias
+ * rides in the first unused pair of the padded K against a pixel value of 1.  Forward only. */
+size_t maua_conv_image_bank_bytes(int cout, int cin);
+int maua_conv_pack_filters_image(const float* w_oihw, const float* bias, void* bank, int cout, int cin, maua_stream_t stream);
+int maua_conv3x3_image(const float* x, const void* bank, float* y, int n, int cin, int h, int w, int cout, int pad, int relu,
+                       maua_stream_t stream);
+
 /* ---- the same convolution on the fp16 matrix cores: a power-of-two-scaled fp32 value as two fp16 parts (22 of 24
  *      significant bits, representation error 7e-8 of the result: below fp32 accumulation noise), three MFMAs per
  *      product block (conv_x3.hip).  Filters are scaled once per layer by `w_scale` (a power of two with

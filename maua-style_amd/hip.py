@@ -46,6 +46,9 @@ SIGNATURES = {
     "maua_conv_x3_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "maua_conv3x3_x3": (c_i, [c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "maua_conv3x3_x6": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
+    "maua_conv_image_bank_bytes": (c_sz, [c_i, c_i]),
+    "maua_conv_pack_filters_image": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p]),
+    "maua_conv3x3_image": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "maua_relu_fwd": (c_i, [c_p, c_i64, c_p]),
     "maua_relu_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_p]),
     "maua_pool_out_size": (c_i, [c_i, c_i, c_i, c_i]),
@@ -450,6 +453,27 @@ def conv1x1_x3(x, w_rowmajor, bias=None, relu=False, out=None, out_relu_mask=Non
 
 def conv_x6_workspace_bytes(n, cin, h, w, cout, pad):
     return lib().maua_conv_x6_workspace_bytes(n, cin, h, w, cout, pad)
+
+
+
+def conv_pack_filters_image(w, bias=None):
+    """OIHW 3x3 weights (and the bias) of a layer that consumes 1-3 channels -> the bank of conv3x3_image (bf16 triples in MFMA lane
+    order; the bias as one more filter column)."""
+    cout, cin = w.shape[:2]
+    bank = torch.empty(lib().maua_conv_image_bank_bytes(cout, cin), dtype=torch.uint8, device=w.device)
+    _check(lib().maua_conv_pack_filters_image(_ptr(_f32(w, "w").contiguous()), _ptr(bias), bank.data_ptr(), cout, cin, _stream()),
+           "maua_conv_pack_filters_image")
+    return bank
+
+
+def conv3x3_image(x, bank, cout, pad, relu, out=None):
+    """The image layer (1-3 input channels) in exact bf16x6 arithmetic, forward; the bias is part of the bank."""
+    n, cin, h, w = x.shape
+    if out is None:
+        out = torch.empty(n, cout, h + 2 * pad - 2, w + 2 * pad - 2, device=x.device, dtype=torch.float32)
+    _check(lib().maua_conv3x3_image(_ptr(_f32(x, "x")), bank.data_ptr(), _ptr(out), n, cin, h, w, cout, pad, int(relu), _stream()),
+           "maua_conv3x3_image")
+    return out
 
 
 def conv3x3_x6(x, bank, bias, cout, pad, relu, out=None, out_relu_mask=None, accumulate=False, workspace=None):

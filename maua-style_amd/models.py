@@ -53,6 +53,13 @@ def _x3w_enabled():
     return os.environ.get("MAUA_CONV_X3W", "1") == "1"
 
 
+def _image_kernel_enabled():
+    """MAUA_CONV_IMAGE: "1" (default) = a 3x3 layer that consumes at most three channels (conv1_1) runs conv_img.hip in the forward pass;
+    "0" = conv_x6.hip's general kernel with the image as one 8-channel chunk (the same bf16x6 products, other summation order)."""
+    import os
+    return os.environ.get("MAUA_CONV_IMAGE", "1") == "1"
+
+
 def _wino_min_channels():
     """MAUA_CONV_WINO=<cin>: 3x3 layers that consume at least that many channels (a multiple of 16) run conv_wino.hip - Winograd
     F(2x2, 3x3) on the fp16x3 split - wherever a plain launch is asked for (the pool- and Gram-fused launches stay on conv_x3w).  Off by
@@ -100,6 +107,9 @@ def conv3x3_mfma(x, mod, backward, out=None, out_relu_mask=None, relu=False, acc
         bf, bb, wsc = mod.banks3()
         return hip.conv3x3_x3(x, bb if backward else bf, wsc, bias, cout, p, relu, out=out, out_relu_mask=out_relu_mask,
                               accumulate=accumulate, workspace=workspace)
+    if not backward and consumed <= 3 and out_relu_mask is None and not accumulate and _image_kernel_enabled():
+        # the image layer: the 27 (channel, tap) pairs as K, no LDS - bound by writing the activation (conv_img.hip; same bf16x6 products)
+        return hip.conv3x3_image(x, mod.bank_image(), cout, p, relu, out=out)
     bf, bb = mod.banks6()
     return hip.conv3x3_x6(x, bb if backward else bf, bias, cout, p, relu, out=out, out_relu_mask=out_relu_mask,
                           accumulate=accumulate, workspace=workspace)
@@ -218,6 +228,15 @@ class Conv2d(nn.Conv2d):
             self._banks = hip.conv_pack_filters(self.weight.detach().contiguous())
             self._bank_key = key
         return self._banks
+
+    def bank_image(self):
+        """The bank of hip.conv3x3_image (layers that consume 1-3 channels)."""
+        b = self.bias_device()
+        key = (self.weight.data_ptr(), self.weight._version, self.weight.device, None if b is None else (b.data_ptr(), b._version))
+        if getattr(self, "_bank_img_key", None) != key:
+            self._bank_img = hip.conv_pack_filters_image(self.weight.detach().contiguous(), b)
+            self._bank_img_key = key
+        return self._bank_img
 
     def banks6(self):
         """bf16x3 pre-split banks (forward, backward-data) of the fp32-accurate bf16 path, 3x3 filters only."""

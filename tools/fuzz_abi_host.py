@@ -47,7 +47,8 @@ def main():
                  L.maua_conv_x6_bank_bytes(cout, cin), L.maua_conv_x3_bank_bytes(cout, cin), L.maua_conv_x3w_bank_bytes(cout, cin),
                  L.maua_conv_kxk_x3_bank_bytes(cout, cin, k), L.maua_gram_workspace_bytes(cin, h * w if abs(h * w) < 1 << 40 else 1),
                  L.maua_reduce_workspace_bytes(h * w), L.maua_lbfgs_state_bytes(h * w, rng.choice([1, 5, 100, 254, 255, 0, -1])),
-                 L.maua_channel_stats_workspace_bytes(h, w), L.maua_loss_ledger_bytes(n, cin), L.maua_conv_wino_bank_bytes(cout, cin)]
+                 L.maua_channel_stats_workspace_bytes(h, w), L.maua_loss_ledger_bytes(n, cin), L.maua_conv_wino_bank_bytes(cout, cin),
+                 L.maua_conv_image_bank_bytes(cout, cin)]
         assert all(s >= 0 for s in sizes)
         if min(n, cin, cout, h, w) <= 0:
             assert sizes[1] == 0 and sizes[2] == 0 and sizes[3] == 0, (n, cin, cout, h, w, sizes)
@@ -58,6 +59,7 @@ def main():
         L.maua_conv_wino_supported(cin, h, w, pad)
         assert L.maua_conv_x3w_split(n, cin, h, w, cout, pad) >= 0 and L.maua_conv_x3w_dmat_bank_bytes(cin) >= 0
         L.maua_conv_pack_dmat_x3w(None, cin, None, None, None)
+        L.maua_conv_pack_filters_image(None, None, None, cout, cin, None)
         # compute entry points: null pointers and bad dims must be refused with a negative code before any launch; good
         # arguments reach the launch (a HIP error on this GPU-less box, or 0 on a GPU box where P would fault - so only
         # argument sets that fail validation use P there)
@@ -73,6 +75,7 @@ def main():
                                       cout, pad, ptr, ws_bytes, None),
             L.maua_conv3x3_x3(ptr, ptr, 1.0, ptr, None, ptr, n, cin, h, w, cout, pad, 1, 0, ptr, ws_bytes, None),
             L.maua_conv3x3_x6(ptr, ptr, ptr, None, ptr, n, cin, h, w, cout, pad, 1, 0, ptr, ws_bytes, None),
+            L.maua_conv3x3_image(ptr, ptr, ptr, n, cin, h, w, cout, pad, 1, None),
             L.maua_conv2d_fwd(ptr, None, ptr, ptr, ptr, n, cin, h, w, cout, k, k, stride, pad, 1, 0, ptr, ws_bytes, None),
             L.maua_conv2d_bwd_data(ptr, None, ptr, ptr, None, ptr, n, cin, h, w, cout, k, k, stride, pad, 0, ptr, ws_bytes, None),
             L.maua_conv_kxk_x3(ptr, ptr, 1.0, ptr, None, ptr, n, cin, h, w, cout, k, pad, 1, 0, ptr, ws_bytes, None),
@@ -101,7 +104,7 @@ def main():
             L.maua_lbfgs_iterate(ptr, ptr, ptr, None, h * w, rng.choice([1, 100, 254, 255]), 1.0, -1.0, -1.0, None),
         ]
         if min(n, cin, cout, h, w) <= 0:  # (the 1x1 entry takes the product h * w, which two negative extents make positive)
-            assert all(rc < 0 for rc in rcs[:10]), (n, cin, cout, h, w, rcs)
+            assert all(rc < 0 for rc in rcs[:11]), (n, cin, cout, h, w, rcs)
         checked += len(rcs) + len(sizes)
     L.maua_set_split_batch_hint(1)
     print(f"fuzz_abi_host: {n_cases} cases, {checked} calls, no sanitizer report, return codes consistent")
