@@ -81,7 +81,8 @@ conv_direct_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ m
 // lane = column, four output rows per thread, the left/right taps come from the neighbouring lanes through DPP
 // wave shifts (lanes 0 and 63 are halo), the 27 filter values of a channel are wave-uniform (scalar registers).
 // ---------------------------------------------------------------------------------------------------------
-constexpr int FO_R = 4, FO_TW = 62;
+constexpr int FO_TW = 62;
+typedef float fo_f2 __attribute__((ext_vector_type(2)));
 
 __device__ inline float lane_from_left(float v) {  // lane i <- lane i-1  (wave_shr:1)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
@@ -93,7 +94,7 @@ __device__ inline float lane_from_right(float v) {  // lane i <- lane i+1  (wave
 // KS4 (small images: a 256 x 256 plane is 80 workgroups of the plain form on 256 CUs, each walking all 64 channels): the four waves of
 // a workgroup share ONE strip of FO_R rows and take a quarter of the input channels each; waves 1-3 leave their sums in LDS and wave 0
 // adds them in wave order (fixed order).  Four times the workgroups, a quarter of the dependent channel steps per wave.
-template <int CO, bool MASK, bool KS4 = false>
+template <int CO, bool MASK, bool KS4 = false, int FO_R = KS4 ? 8 : 4>  // rows per thread: 4 (plain: 83.7 vs 89.6 us at 1024^2 with 8), 8 (KS4: 31.5 vs 34.9 us at 512^2)
 __global__ void __launch_bounds__(256)
 conv3x3_few_out_kernel(ConvArgs p, const float* __restrict__ wbank) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -138,21 +139,30 @@ conv3x3_few_out_kernel(ConvArgs p, const float* __restrict__ wbank) {
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int c = 0; c < CO; ++c) wv[t][c] = wbank[((int64_t)t * p.Cin + ci) * CO + c];
+        // packed fp32 FMAs (v_pk_fma_f32: two rows per instruction, the filter value broadcast from a scalar register): tap row ky takes
+        // input rows (2 p + ky, 2 p + ky + 1) to output rows (2 p, 2 p + 1) - 54 packed instructions per channel instead of 108 FMAs
+        float lf[FO_R + 2], rg[FO_R + 2];
 #pragma unroll
         for (int r = 0; r < FO_R + 2; ++r) {
-            const float mid = cur[r], lft = lane_from_left(mid), rgt = lane_from_right(mid);
+            lf[r] = lane_from_left(cur[r]);
+            rg[r] = lane_from_right(cur[r]);
+        }
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int orow = r - ky;  // input row r feeds output row r - ky through tap row ky
-                if (orow < 0 || orow >= FO_R) continue;
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int pr = 0; pr < FO_R / 2; ++pr) {
+                const fo_f2 l2 = {lf[2 * pr + ky], lf[2 * pr + ky + 1]}, m2 = {cur[2 * pr + ky], cur[2 * pr + ky + 1]},
+                            r2 = {rg[2 * pr + ky], rg[2 * pr + ky + 1]};
 #pragma unroll
                 for (int c = 0; c < CO; ++c) {
-                    acc[orow][c] = fmaf(lft, wv[ky * 3 + 0][c], acc[orow][c]);
-                    acc[orow][c] = fmaf(mid, wv[ky * 3 + 1][c], acc[orow][c]);
-                    acc[orow][c] = fmaf(rgt, wv[ky * 3 + 2][c], acc[orow][c]);
+                    fo_f2 a2 = {acc[2 * pr][c], acc[2 * pr + 1][c]};
+                    a2 = __builtin_elementwise_fma(l2, (fo_f2){wv[ky * 3 + 0][c], wv[ky * 3 + 0][c]}, a2);
+                    a2 = __builtin_elementwise_fma(m2, (fo_f2){wv[ky * 3 + 1][c], wv[ky * 3 + 1][c]}, a2);
+                    a2 = __builtin_elementwise_fma(r2, (fo_f2){wv[ky * 3 + 2][c], wv[ky * 3 + 2][c]}, a2);
+                    acc[2 * pr][c] = a2.x;
+                    acc[2 * pr + 1][c] = a2.y;
                 }
             }
-        }
         if ((ci & 7) == 7 || ci + 1 == ci_end) {  // two-level accumulation like the MFMA kernels
 #pragma unroll
             for (int r = 0; r < FO_R; ++r)
@@ -290,7 +300,7 @@ int conv_splitk_finish_pool(const ConvArgs& a, int n, int ksplit, hipStream_t st
 }
 
 int conv3x3_few_out(const ConvArgs& a, int n, hipStream_t stream) {
-    dim3 grid((unsigned)((a.OW + FO_TW - 1) / FO_TW), (unsigned)((a.OH + 4 * FO_R - 1) / (4 * FO_R)), (unsigned)n);
+    dim3 grid((unsigned)((a.OW + FO_TW - 1) / FO_TW), (unsigned)((a.OH + 4 * 4 - 1) / (4 * 4)), (unsigned)n);  // (4 waves x 4 rows)
     // channel quarters per wave where the plain grid leaves most of the chip idle (the planned frames per launch count, not this
     // launch's: a frame's bits do not depend on how many others share its launch)
     static const int ks4_below = [] {
@@ -298,7 +308,7 @@ int conv3x3_few_out(const ConvArgs& a, int n, hipStream_t stream) {
         return e ? atoi(e) : 1024;
     }();
     const bool ks4 = (int64_t)grid.x * grid.y * split_batch_hint() < ks4_below && a.Cin % 32 == 0;
-    if (ks4) grid.y = (unsigned)((a.OH + FO_R - 1) / FO_R);
+    if (ks4) grid.y = (unsigned)((a.OH + 8 - 1) / 8);  // (one strip of 8 rows per workgroup)
 #define MAUA_FO(CO_)                                                                                            \
     case CO_:                                                                                                   \
         if (ks4 && a.mask) hipLaunchKernelGGL((conv3x3_few_out_kernel<CO_, true, true>), grid, dim3(256), 0, stream, a, a.w);  \
