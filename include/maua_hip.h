@@ -100,6 +100,13 @@ size_t maua_conv_image_bank_bytes(int cout, int cin);
 int maua_conv_pack_filters_image(const float* w_oihw, const float* bias, void* bank, int cout, int cin, maua_stream_t stream);
 int maua_conv3x3_image(const float* x, const void* bank, float* y, int n, int cin, int h, int w, int cout, int pad, int relu,
                        maua_stream_t stream);
+/* The same launch (one image, 64 output channels, ReLU) which also leaves the Gram matrix of the activation it writes
+ * (`torch.mm(x, x.T)` of loss.GramMatrix.forward, loss.py:91, on relu1_1) as split-K slabs: maua_conv_image_gram_slabs(h, w, pad) slabs of
+ * 64 x 64 floats in `gram_slabs` (the layout of maua_gram_partial's workspace for C = 64: upper channel blocks filled), one per
+ * workgroup, to be folded and finished by maua_gram_partial_batch / maua_gram_finish_mse_batch with that slab count - the 268 MB of
+ * relu1_1 at 1024 x 1024 are not read back for it.  The activation is bit-identical to maua_conv3x3_image's. */
+int maua_conv_image_gram_slabs(int h, int w, int pad);
+int maua_conv3x3_image_gram(const float* x, const void* bank, float* y, float* gram_slabs, int cin, int h, int w, int pad, maua_stream_t stream);
 
 /* ---- the same convolution on the fp16 matrix cores: a power-of-two-scaled fp32 value as two fp16 parts (22 of 24
  *      significant bits, representation error 7e-8 of the result: below fp32 accumulation noise), three MFMAs per
@@ -295,12 +302,15 @@ int maua_gram_partial(const float* f, float* row_mean_out, int c, int64_t hw, in
                       maua_stream_t stream);
 /* maua_gram_partial (center = 0) for up to 8 layers at once - at most two partial launches (the layers of one 64-channel tile; the others)
  * and one first-level fold instead of one to two launches per layer; every layer keeps the plan of its own call: the same slabs, bit for
- * bit.  Host arrays of `count` entries. */
+ * bit.  Host arrays of `count` entries.  slab_counts (nullable; also the last array of maua_gram_finish_mse_batch): an entry > 0 says that
+ * the layer's workspace already holds that many 64 x 64 slabs (C <= 64: maua_conv3x3_image_gram) - no partial launch for it, only the
+ * fold, and the finishing launch adds that many. */
 int maua_gram_partial_batch(int count, const float* const* fs, const int* cs, const int64_t* hws, void* const* workspaces,
-                            const size_t* workspace_bytes, maua_stream_t stream);
+                            const size_t* workspace_bytes, const int* slab_counts, maua_stream_t stream);
 int maua_gram_finish_mse_batch(int count, const void* const* workspaces, float* const* grams, const float* const* targets,
                                float* const* dmats, const int* cs, const int64_t* hws, const float* scales, const float* loss_scales,
-                               const float* grad_scales, double* const* ledgers, const int* slots, maua_stream_t stream);
+                               const float* grad_scales, double* const* ledgers, const int* slots, const int* slab_counts,
+                               maua_stream_t stream);
 int maua_loss_ledger_sum(double* ledger, int frames, int slots, float* losses, float* totals, maua_stream_t stream);
 /* The same launch, which also leaves every filled record's loss BEFORE its rounding to fp32 in losses_f64[frames][slots]
  * (`mod.loss` of optim.py:207-211 as a double; slots whose record is empty are not written): full-size derivative tests

@@ -72,11 +72,19 @@ struct ImgArgs {
     const float* x;
     const unsigned char* bank;
     float* y;
+    float* gram_slabs;  // GRAM: gridDim.x slabs of 64 x 64 floats
     int n, cin, H, W, cout, OH, OW, pad, relu;
     int blocks_x;      // 32-pixel blocks per output row
     int64_t blocks;    // n * OH * blocks_x
 };
 
+// GRAM (single image, one 64-channel tile, ReLU): every workgroup also leaves the 64 x 64 partial sum of Y Y^T over ITS pixels (Y = the
+// activation it writes) as one split-K slab of gram.hip's finishing kernels - the Gram matrix of relu1_1 without reading the 268 MB
+// back.  The product needs the tile with channels on the lanes and pixels in the registers: exchanging the two operands of the same
+// matrix instructions yields exactly that (24 more instructions on a kernel bound by its stores), and an accumulator tile whose
+// ROW index is summed over is its own operand (cdna_hip_programming.md, 'an accumulator tile as the next MFMA's operand'): no LDS, no
+// lane movement.  bf16 triples again (no scales), fp32 sums over the wave's ~10 blocks, the four waves added in wave order.
+template <bool GRAM>
 __global__ void __launch_bounds__(256, CI_OCC) conv_image_kernel(ImgArgs p) {
     const int lane = threadIdx.x & 63;
     const int nl = lane & 31, kg = lane >> 5;
@@ -115,8 +123,15 @@ __global__ void __launch_bounds__(256, CI_OCC) conv_image_kernel(ImgArgs p) {
     const int wid = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
     const int per = (int)((p.blocks + nw - 1) / nw);
     const int b0 = wid * per, b1 = (int)(p.blocks < (int64_t)b0 + per ? p.blocks : (int64_t)b0 + per);
-    if (b0 >= b1) return;
-    int bx = b0 % p.blocks_x, oy = (b0 / p.blocks_x) % p.OH, img = (b0 / p.blocks_x) / p.OH;
+    ci_f32x16 gsum[3];  // GRAM: channel blocks (0,0), (0,1), (1,1) of the partial Gram matrix
+    if constexpr (GRAM) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gsum[q][r] = 0.f;
+    }
+    if (!GRAM && b0 >= b1) return;
+    int bx = b0 < b1 ? b0 % p.blocks_x : 0, oy = b0 < b1 ? (b0 / p.blocks_x) % p.OH : 0, img = b0 < b1 ? (b0 / p.blocks_x) / p.OH : 0;
     auto gather = [&](float (&v)[2][8], int gi, int gy, int gb) {
         const int ox = gb * 32 + nl;
         const float* __restrict__ xin = p.x + (int64_t)gi * p.cin * plane;
@@ -142,7 +157,7 @@ __global__ void __launch_bounds__(256, CI_OCC) conv_image_kernel(ImgArgs p) {
         }
     };
     float v[2][8], vn[2][8];
-    gather(v, img, oy, bx);
+    if (b0 < b1) gather(v, img, oy, bx);
     for (int b = b0; b < b1; ++b) {
         bx = __builtin_amdgcn_readfirstlane(bx);  // (wave-uniform by construction; said so, the descriptor below stays scalar)
         oy = __builtin_amdgcn_readfirstlane(oy);
@@ -207,6 +222,53 @@ __global__ void __launch_bounds__(256, CI_OCC) conv_image_kernel(ImgArgs p) {
                 if (p.relu) o = o > 0.f ? o : 0.f;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rs, voff, (int)(cr * out_plane * 4), 0);
             }
+        if constexpr (GRAM) {
+            ci_f32x16 xt[2];  // the tile transposed: lane = channel (of the block), register = pixel
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xt[blk][r] = 0.f;
+#pragma unroll
+            for (int step = 0; step < 2; ++step) {
+                const ci_bf16x8 b0v = __builtin_bit_cast(ci_bf16x8, bp[step][0]), b1v = __builtin_bit_cast(ci_bf16x8, bp[step][1]),
+                                b2v = __builtin_bit_cast(ci_bf16x8, bp[step][2]);
+#define CI_PAIR_T(AP, BV)                                                                                       \
+    xt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BV, a[0][step][AP], xt[0], 0, 0, 0);                         \
+    xt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BV, a[1][step][AP], xt[1], 0, 0, 0);
+                CI_PAIR_T(2, b0v) CI_PAIR_T(1, b1v) CI_PAIR_T(0, b2v) CI_PAIR_T(1, b0v) CI_PAIR_T(0, b1v) CI_PAIR_T(0, b0v)
+#undef CI_PAIR_T
+            }
+            // ReLU, pixels past the end of the row out, bf16 triples: registers 8 s ... 8 s + 7 are the fragment of K step s
+            ci_u32x4 fr[2][2][3];  // [channel block][K step][part]
+            const int px0 = bx * 32 + 4 * kg;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int sK = 0; sK < 2; ++sK)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int r0i = 8 * sK + 2 * q, r1i = r0i + 1;
+                        float x0 = xt[blk][r0i], x1 = xt[blk][r1i];
+                        x0 = (x0 > 0.f && px0 + (r0i & 3) + 8 * (r0i >> 2) < p.OW) ? x0 : 0.f;
+                        x1 = (x1 > 0.f && px0 + (r1i & 3) + 8 * (r1i >> 2) < p.OW) ? x1 : 0.f;
+                        const unsigned h = ci_cvt_pk(x0, x1);
+                        const float e0 = x0 - __builtin_bit_cast(float, h << 16), e1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+                        const unsigned m = ci_cvt_pk(e0, e1);
+                        const unsigned l = ci_cvt_pk(e0 - __builtin_bit_cast(float, m << 16), e1 - __builtin_bit_cast(float, m & 0xffff0000u));
+                        fr[blk][sK][0][q] = h;
+                        fr[blk][sK][1][q] = m;
+                        fr[blk][sK][2][q] = l;
+                    }
+#pragma unroll
+            for (int sK = 0; sK < 2; ++sK) {
+#define CI_G(PA, PB)                                                                                                                        \
+    gsum[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ci_bf16x8, fr[0][sK][PA]), __builtin_bit_cast(ci_bf16x8, fr[0][sK][PB]), gsum[0], 0, 0, 0); \
+    gsum[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ci_bf16x8, fr[0][sK][PA]), __builtin_bit_cast(ci_bf16x8, fr[1][sK][PB]), gsum[1], 0, 0, 0); \
+    gsum[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ci_bf16x8, fr[1][sK][PA]), __builtin_bit_cast(ci_bf16x8, fr[1][sK][PB]), gsum[2], 0, 0, 0);
+                CI_G(2, 0) CI_G(1, 1) CI_G(0, 2) CI_G(1, 0) CI_G(0, 1) CI_G(0, 0)
+#undef CI_G
+            }
+        }
 #pragma unroll
         for (int step = 0; step < 2; ++step)
 #pragma unroll
@@ -214,6 +276,32 @@ __global__ void __launch_bounds__(256, CI_OCC) conv_image_kernel(ImgArgs p) {
         bx = nbx;
         oy = noy;
         img = nimg;
+    }
+    if constexpr (GRAM) {
+        // waves 1-3 leave their sums in LDS, wave 0 adds them in wave order and writes the workgroup's slab: element (row co_i, column co_j)
+        // of the 64 x 64 tile, upper channel blocks only (gram.hip's finishing kernels read the lower triangle from the upper one)
+        __shared__ float red[3][3][16][64];
+        const int wave = threadIdx.x >> 6;
+        if (wave > 0) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[wave - 1][q][r][lane] = gsum[q][r];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+        float* __restrict__ slab = p.gram_slabs + (int64_t)blockIdx.x * 64 * 64;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int bi = q == 2 ? 1 : 0, bj = q == 0 ? 0 : 1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float g = gsum[q][r];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) g += red[w][q][r][lane];
+                slab[(bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg) * 64 + bj * 32 + nl] = g;
+            }
+        }
     }
 }
 
@@ -235,13 +323,11 @@ int maua_conv_pack_filters_image(const float* w_oihw, const float* bias, void* b
     return check_launch("pack_image_kernel");
 }
 
-int maua_conv3x3_image(const float* x, const void* bank, float* y, int n, int cin, int h, int w, int cout, int pad, int relu,
-                       maua_stream_t stream) {
+static int conv_image_fill(ImgArgs& p, const float* x, const void* bank, float* y, int n, int cin, int h, int w, int cout, int pad, int relu) {
     MAUA_REQUIRE(x && bank && y, MAUA_E_INVAL, "conv3x3_image: null pointer");
     MAUA_REQUIRE(conv_dims_ok(n, cin, h, w, cout, pad) && pad <= 2 && cin <= 3, MAUA_E_INVAL, "conv3x3_image: bad dims (1-3 input channels)");
     MAUA_REQUIRE(h + 2 * pad >= 3 && w + 2 * pad >= 3, MAUA_E_UNSUPPORTED, "conv3x3_image: input smaller than the filter");
     MAUA_REQUIRE((int64_t)cin * h * w < (1ll << 31), MAUA_E_UNSUPPORTED, "conv3x3_image: image too large");
-    ImgArgs p{};
     p.x = x;
     p.bank = (const unsigned char*)bank;
     p.y = y;
@@ -257,9 +343,36 @@ int maua_conv3x3_image(const float* x, const void* bank, float* y, int n, int ci
     p.blocks_x = (p.OW + 31) / 32;
     p.blocks = (int64_t)n * p.OH * p.blocks_x;
     MAUA_REQUIRE(p.blocks < (1ll << 31) && (int64_t)64 * p.OH * p.OW < (1ll << 30), MAUA_E_UNSUPPORTED, "conv3x3_image: plane too large");
-    const int64_t want = (p.blocks + 3) / 4;  // workgroups of four waves, a block per wave at least; at most three per CU (what the registers allow)
-    const unsigned gx = (unsigned)(want < 256 * CI_OCC ? (want > 0 ? want : 1) : 256 * CI_OCC);
-    hipLaunchKernelGGL(conv_image_kernel, dim3(gx, (unsigned)((cout + 63) / 64)), dim3(256), 0, (hipStream_t)stream, p);
+    return MAUA_OK;
+}
+// workgroups of four waves, a block per wave at least; at most CI_OCC per CU (what the registers allow)
+static unsigned conv_image_grid(int64_t blocks) {
+    const int64_t want = (blocks + 3) / 4;
+    return (unsigned)(want < 256 * CI_OCC ? (want > 0 ? want : 1) : 256 * CI_OCC);
+}
+
+int maua_conv3x3_image(const float* x, const void* bank, float* y, int n, int cin, int h, int w, int cout, int pad, int relu,
+                       maua_stream_t stream) {
+    ImgArgs p{};
+    const int rc = conv_image_fill(p, x, bank, y, n, cin, h, w, cout, pad, relu);
+    if (rc) return rc;
+    hipLaunchKernelGGL(conv_image_kernel<false>, dim3(conv_image_grid(p.blocks), (unsigned)((cout + 63) / 64)), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("conv_image_kernel");
+}
+
+int maua_conv_image_gram_slabs(int h, int w, int pad) {
+    if (h <= 0 || w <= 0 || pad < 0 || pad > 2 || h + 2 * pad < 3 || w + 2 * pad < 3) return 0;
+    const int64_t oh = h + 2 * pad - 2, ow = w + 2 * pad - 2;
+    return (int)conv_image_grid(oh * ((ow + 31) / 32));
+}
+
+int maua_conv3x3_image_gram(const float* x, const void* bank, float* y, float* gram_slabs, int cin, int h, int w, int pad, maua_stream_t stream) {
+    MAUA_REQUIRE(gram_slabs, MAUA_E_INVAL, "conv3x3_image_gram: null slabs");
+    ImgArgs p{};
+    const int rc = conv_image_fill(p, x, bank, y, 1, cin, h, w, 64, pad, 1);
+    if (rc) return rc;
+    p.gram_slabs = gram_slabs;
+    hipLaunchKernelGGL(conv_image_kernel<true>, dim3(conv_image_grid(p.blocks), 1), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("conv_image_kernel");
 }
 

@@ -819,14 +819,17 @@ int maua_gram_partial(const float* f, float* row_mean_out, int c, int64_t hw, in
 }
 
 int maua_gram_partial_batch(int count, const float* const* fs, const int* cs, const int64_t* hws, void* const* workspaces,
-                            const size_t* workspace_bytes, maua_stream_t stream) {
+                            const size_t* workspace_bytes, const int* slab_counts, maua_stream_t stream) {
     MAUA_REQUIRE(count > 0 && count <= GB_MAX && fs && cs && hws && workspaces && workspace_bytes, MAUA_E_INVAL,
                  "gram_partial_batch: bad args (at most %d layers per call)", GB_MAX);
     for (int i = 0; i < count; ++i) {
-        MAUA_REQUIRE(fs[i] && workspaces[i] && cs[i] > 0 && cs[i] <= (1 << 16) && hws[i] > 0 && hws[i] < (1ll << 30), MAUA_E_INVAL,
-                     "gram_partial_batch: bad args for layer %d", i);
-        MAUA_REQUIRE(workspace_bytes[i] >= maua_gram_workspace_bytes(cs[i], hws[i]), MAUA_E_WORKSPACE, "gram_partial_batch: workspace %zu < %zu (layer %d)",
-                     workspace_bytes[i], maua_gram_workspace_bytes(cs[i], hws[i]), i);
+        const int given = slab_counts ? slab_counts[i] : 0;  // > 0: the layer's slabs are in its workspace already (maua_conv3x3_image_gram)
+        MAUA_REQUIRE((fs[i] || given > 0) && workspaces[i] && cs[i] > 0 && cs[i] <= (1 << 16) && hws[i] > 0 && hws[i] < (1ll << 30) && given >= 0 &&
+                         given < (1 << 20),
+                     MAUA_E_INVAL, "gram_partial_batch: bad args for layer %d", i);
+        MAUA_REQUIRE(given == 0 || cs[i] <= GT, MAUA_E_UNSUPPORTED, "gram_partial_batch: ready slabs are for single-tile layers (layer %d)", i);
+        const size_t need = given > 0 ? (size_t)given * GT * GT * sizeof(float) : maua_gram_workspace_bytes(cs[i], hws[i]);
+        MAUA_REQUIRE(workspace_bytes[i] >= need, MAUA_E_WORKSPACE, "gram_partial_batch: workspace %zu < %zu (layer %d)", workspace_bytes[i], need, i);
     }
     static const bool use_x3 = [] {
         const char* e = getenv("MAUA_GRAM_X3");
@@ -834,6 +837,7 @@ int maua_gram_partial_batch(int count, const float* const* fs, const int* cs, co
     }();
     if (!use_x3) {  // (the fp32-MFMA comparison kernel has no batched form)
         for (int i = 0; i < count; ++i) {
+            MAUA_REQUIRE(!(slab_counts && slab_counts[i] > 0), MAUA_E_UNSUPPORTED, "gram_partial_batch: ready slabs need the fp16x3 kernels' fold");
             int rc = maua_gram_partial(fs[i], nullptr, cs[i], hws[i], 0, workspaces[i], workspace_bytes[i], stream);
             if (rc) return rc;
         }
@@ -856,6 +860,19 @@ int maua_gram_partial_batch(int count, const float* const* fs, const int* cs, co
             int npairs, ksplit;
             int64_t chunk;
             gram_plan(cs[i], hws[i], &npairs, &ksplit, &chunk);
+            if (slab_counts && slab_counts[i] > 0) {  // nothing to multiply: only the first-level fold of the slabs that are there
+                ksplit = slab_counts[i];
+                if (ksplit > 2 * GF_FOLD) {
+                    fold.partial[nfold] = (float*)workspaces[i];
+                    fold.ksplit[nfold] = ksplit;
+                    fold.npairs[nfold] = 1;
+                    const int groups = (ksplit + GF_FOLD - 1) / GF_FOLD;
+                    fold.max_groups = groups > fold.max_groups ? groups : fold.max_groups;
+                    fold_pairs = 1 > fold_pairs ? 1 : fold_pairs;
+                    ++nfold;
+                }
+                continue;
+            }
             b.f[nb] = fs[i];
             b.partial[nb] = (float*)workspaces[i];
             b.HW[nb] = hws[i];
@@ -892,7 +909,8 @@ int maua_gram_partial_batch(int count, const float* const* fs, const int* cs, co
 
 int maua_gram_finish_mse_batch(int count, const void* const* workspaces, float* const* grams, const float* const* targets,
                                float* const* dmats, const int* cs, const int64_t* hws, const float* scales, const float* loss_scales,
-                               const float* grad_scales, double* const* ledgers, const int* slots, maua_stream_t stream) {
+                               const float* grad_scales, double* const* ledgers, const int* slots, const int* slab_counts,
+                               maua_stream_t stream) {
     MAUA_REQUIRE(count > 0 && count <= GB_MAX && workspaces && grams && targets && dmats && cs && hws && scales && loss_scales &&
                      grad_scales && ledgers && slots,
                  MAUA_E_INVAL, "gram_finish_mse_batch: bad args (at most %d layers per call)", GB_MAX);
@@ -907,6 +925,10 @@ int maua_gram_finish_mse_batch(int count, const void* const* workspaces, float* 
         int npairs, ksplit;
         int64_t chunk;
         gram_plan(cs[i], hws[i], &npairs, &ksplit, &chunk);
+        if (slab_counts && slab_counts[i] > 0) {  // (slabs of maua_conv3x3_image_gram: their number is the launch's, not the plan's)
+            MAUA_REQUIRE(cs[i] <= GT && slab_counts[i] < (1 << 20), MAUA_E_UNSUPPORTED, "gram_finish_mse_batch: ready slabs are for single-tile layers");
+            ksplit = slab_counts[i];
+        }
         b.partial[i] = (const float*)workspaces[i];
         b.gram[i] = grams[i];
         b.target[i] = targets[i];

@@ -222,6 +222,23 @@ class StyleEngine:
                     if bank is not None:
                         self.fused_gram[id(s)] = (on_src[0], bank[0], bank[1])
         self.fused_style = {id(v[0]): v for v in self.fused_gram.values()}
+        # The image layer (conv1_1: 3 -> 64 channels on conv_img.hip) can leave the Gram slabs of its own output (relu1_1) next to the
+        # activation (hip.conv3x3_image_gram): that layer's partial kernel - a second pass over the largest activation of the network -
+        # disappears.  Single images whose Gram chains are batched behind the forward pass.  image_gram[conv step] = style step.
+        self.image_gram = {}
+        # (not for frames of a planned batch - batch_hint > 1: a frame's bits must not depend on how many others share its launches)
+        if B == 1 and self.batch_hint == 1 and self.ledger is not None and self.x6_fwd and os.environ.get("MAUA_IMAGE_GRAM", "1") != "0" and \
+                models_mod._image_kernel_enabled():
+            for s in self.steps:
+                if s.kind != "conv" or not s.relu or s.k != 3 or s.stride != 1 or s.mod.in_channels > 3 or s.mod.out_channels != 64 or \
+                        not self._x6_ok(s, 64):
+                    continue
+                on_dst = [t for t in self.steps if t.kind == "style" and t.src == s.dst]
+                if len(on_dst) == 1 and not on_dst[0].mod.use_covariance and hip.gram_mse_ledger_supported(64):
+                    h, w = shapes[s.src][2:]
+                    slabs = hip.conv_image_gram_slabs(h, w, s.pad)
+                    if 0 < slabs * 64 * 64 * 4 <= hip.gram_workspace_bytes(64, shapes[s.dst][2] * shapes[s.dst][3]):
+                        self.image_gram[id(s)] = (on_dst[0], slabs)
         self.gram, self.dmat, self.mean = {}, {}, {}
         self.gram_d, self.dmat_d, self.mean_d = {}, {}, {}
         ws = hip.reduce_workspace_bytes(max(t.numel() for t in self.gbuf.values()))
@@ -403,6 +420,16 @@ class StyleEngine:
         nbytes = (ob + ob + wbytes + ib) if backward else (ib + wbytes + ob)
         return flops, nbytes
 
+    def _image_gram_now(self, s, shape):
+        """Whether this evaluation's image-layer launch carries the Gram slabs of its style layer: the layer is active and its chain is
+        one of those batched behind the forward pass (no side stream, partial batch on)."""
+        st, _ = self.image_gram[id(s)]
+        return self.gram_batch_on and self.gram_partial_batch_on and not (self.style_aside and self.timer is None) and \
+            self._active(st, self.act[s.dst].shape)
+
+    def image_gram_slabs(self, style_step):
+        return next(n for st, n in self.image_gram.values() if st is style_step)
+
     def _x6_ok(self, s, produced_channels):
         """bf16x6 kernel: 3x3, stride 1, and enough produced channels to fill its 64-channel tile."""
         return self.use_x6 and s.k == 3 and s.stride == 1 and s.pad <= 2 and produced_channels > 32
@@ -414,6 +441,7 @@ class StyleEngine:
         hip.fill_(self.slots_all, 0.0)
         forked = False
         batch = []
+        emitted = set()  # style steps whose Gram slabs came out of the image layer's launch
         # ---------------- forward
         for s in self.steps:
             if s.kind == "conv":
@@ -422,6 +450,11 @@ class StyleEngine:
                     ps = self.fused_pool[id(s)]
                     self._timed("conv3x3_split_fwd", fl, nb, lambda: models_mod.conv3x3_relu_pool(
                         a[s.src], s.mod, a[ps.dst], self.pool_codes[id(ps)], workspace=self.ws))
+                elif id(s) in self.image_gram and self._image_gram_now(s, a[s.src].shape):
+                    st, _ = self.image_gram[id(s)]
+                    gws = self._gram_ws(st, 64, a[s.dst].shape[2] * a[s.dst].shape[3], x.device)
+                    self._timed("conv3x3_split_fwd", fl, nb, lambda: hip.conv3x3_image_gram(a[s.src], s.mod.bank_image(), s.pad, a[s.dst], gws))
+                    emitted.add(id(st))
                 elif self.x6_fwd and self._x6_ok(s, s.mod.out_channels):
                     self._timed("conv3x3_split_fwd", fl, nb, lambda: models_mod.conv3x3_mfma(
                         a[s.src], s.mod, False, out=a[s.dst], relu=s.relu, workspace=self.ws))
@@ -521,12 +554,14 @@ class StyleEngine:
                             # pass (hip.GramFinishBatch.run_partial: each alone is 10-25 us of latency on a part of the chip); the
                             # covariance form needs its row means first and keeps its own launches
                             later = self.gram_partial_batch_on and not s.mod.use_covariance
+                            assert later or id(s) not in emitted
                             if not later:
                                 self._timed("gram_fwd", 2 * c * c * (n // c), n * 4 + c * c * 4, lambda: hip.gram_partial(
                                     f, s.mod.use_covariance, self.mean[id(s)], gws))
                             batch.append(dict(step=s, workspace=gws, gram=self.gram[id(s)], target=s.mod.target, dmat=self.dmat[id(s)], c=c,
                                               hw=n // c, scale=1.0 / n, loss_scale=lw / (c * c), grad_scale=gw * 4.0 / (c * c) / n,
-                                              ledger=self.ledger[0], slot=s.slot, f=f if later else None))
+                                              ledger=self.ledger[0], slot=s.slot, f=f if later else None,
+                                              slabs=self.image_gram_slabs(s) if id(s) in emitted else 0))
                             continue
                         self._timed("gram_fwd", 2 * c * c * (n // c), n * 4 + c * c * 4, lambda: hip.gram_fwd_mse_ledger(
                             f, 1.0 / n, s.mod.use_covariance, self.gram[id(s)], self.mean[id(s)], s.mod.target, self.dmat[id(s)],
@@ -546,7 +581,7 @@ class StyleEngine:
                     grp = batch[k0:k0 + 8]
                     key = tuple((id(l["step"]), l["target"].data_ptr(), l["workspace"].data_ptr(), l["gram"].data_ptr(), l["dmat"].data_ptr(),
                                  l["ledger"].data_ptr(), l["slot"], l["loss_scale"], l["grad_scale"],
-                                 None if l["f"] is None else l["f"].data_ptr()) for l in grp)
+                                 None if l["f"] is None else l["f"].data_ptr(), l["slabs"]) for l in grp)
                     later = [l for l in grp if l["f"] is not None]
                     if later and len(later) != len(grp):  # (mixed Gram / covariance layers: the waiting ones one by one)
                         for l in later:

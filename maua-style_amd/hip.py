@@ -49,6 +49,8 @@ SIGNATURES = {
     "maua_conv_image_bank_bytes": (c_sz, [c_i, c_i]),
     "maua_conv_pack_filters_image": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p]),
     "maua_conv3x3_image": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "maua_conv_image_gram_slabs": (c_i, [c_i, c_i, c_i]),
+    "maua_conv3x3_image_gram": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "maua_relu_fwd": (c_i, [c_p, c_i64, c_p]),
     "maua_relu_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_p]),
     "maua_pool_out_size": (c_i, [c_i, c_i, c_i, c_i]),
@@ -93,8 +95,8 @@ SIGNATURES = {
     "maua_gram_mse_ledger_supported": (c_i, [c_i]),
     "maua_gram_fwd_mse_ledger": (c_i, [c_p, c_p, c_p, c_i, c_i64, c_f, c_i, c_p, c_p, c_f, c_f, c_p, c_i, c_p, c_sz, c_p]),
     "maua_gram_partial": (c_i, [c_p, c_p, c_i, c_i64, c_i, c_p, c_sz, c_p]),
-    "maua_gram_finish_mse_batch": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
-    "maua_gram_partial_batch": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "maua_gram_finish_mse_batch": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "maua_gram_partial_batch": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "maua_loss_ledger_sum": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p]),
     "maua_loss_ledger_sum_f64": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
     "maua_lbfgs_state_bytes": (c_sz, [c_i64, c_i]),
@@ -476,6 +478,21 @@ def conv3x3_image(x, bank, cout, pad, relu, out=None):
     return out
 
 
+def conv_image_gram_slabs(h, w, pad):
+    """Number of 64 x 64 slabs conv3x3_image_gram leaves for an h x w image."""
+    return int(lib().maua_conv_image_gram_slabs(int(h), int(w), int(pad)))
+
+
+def conv3x3_image_gram(x, bank, pad, out, gram_slabs):
+    """conv3x3_image (one image, 64 channels, ReLU) that also leaves the partial Gram matrices of its output as split-K slabs in
+    `gram_slabs` (a byte or float buffer of at least conv_image_gram_slabs(...) * 16 KiB)."""
+    n, cin, h, w = x.shape
+    assert n == 1 and gram_slabs.numel() * gram_slabs.element_size() >= conv_image_gram_slabs(h, w, pad) * 64 * 64 * 4
+    _check(lib().maua_conv3x3_image_gram(_ptr(_f32(x, "x")), bank.data_ptr(), _ptr(out), gram_slabs.data_ptr(), cin, h, w, pad, _stream()),
+           "maua_conv3x3_image_gram")
+    return out
+
+
 def conv3x3_x6(x, bank, bias, cout, pad, relu, out=None, out_relu_mask=None, accumulate=False, workspace=None):
     n, cin, h, w = x.shape
     if out is None:
@@ -610,7 +627,8 @@ class GramFinishBatch:
     fixed engine plan) and reused by every evaluation."""
 
     def __init__(self, layers):
-        """layers: list of dicts with workspace, gram, target, dmat, c, hw, scale, loss_scale, grad_scale, ledger (one frame's records), slot."""
+        """layers: list of dicts with workspace, gram, target, dmat, c, hw, scale, loss_scale, grad_scale, ledger (one frame's records), slot;
+        optional: f (the feature map, for run_partial), slabs (> 0: that many slabs are in the workspace already, conv3x3_image_gram)."""
         n = len(layers)
         self.n = n
         self.keep = layers  # (the tensors must outlive the addresses)
@@ -621,7 +639,7 @@ class GramFinishBatch:
             arr(ctypes.c_int, [int(l["c"]) for l in layers]), arr(ctypes.c_int64, [int(l["hw"]) for l in layers]),
             arr(ctypes.c_float, [float(l["scale"]) for l in layers]), arr(ctypes.c_float, [float(l["loss_scale"]) for l in layers]),
             arr(ctypes.c_float, [float(l["grad_scale"]) for l in layers]), arr(ctypes.c_void_p, [l["ledger"].data_ptr() for l in layers]),
-            arr(ctypes.c_int, [int(l["slot"]) for l in layers]))
+            arr(ctypes.c_int, [int(l["slot"]) for l in layers]), arr(ctypes.c_int, [int(l.get("slabs") or 0) for l in layers]))
 
         self.partial_args = (
             arr(ctypes.c_void_p, [_ptr(_f32(l["f"], "f")) if l.get("f") is not None else None for l in layers]), self.args[4], self.args[5],
@@ -630,11 +648,11 @@ class GramFinishBatch:
     def run_partial(self):
         """maua_gram_partial of every layer (each dict's "f" = its feature map) in at most three launches."""
         a = self.partial_args
-        _check(lib().maua_gram_partial_batch(self.n, a[0], a[1], a[2], a[3], a[4], _stream()), "maua_gram_partial_batch")
+        _check(lib().maua_gram_partial_batch(self.n, a[0], a[1], a[2], a[3], a[4], self.args[11], _stream()), "maua_gram_partial_batch")
 
     def run(self):
         a = self.args
-        _check(lib().maua_gram_finish_mse_batch(self.n, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], _stream()),
+        _check(lib().maua_gram_finish_mse_batch(self.n, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], _stream()),
                "maua_gram_finish_mse_batch")
 
 

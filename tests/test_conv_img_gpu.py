@@ -81,3 +81,32 @@ def test_image_layer_is_exactly_homogeneous_and_survives_extremes(hip):
     yb = hip.conv3x3_image((x * 1e30).cuda(), bank, 64, 1, False)
     torch.cuda.synchronize()
     assert torch.isfinite(yb).all() and rel_l2(yb.cpu(), ref) <= 3e-7
+
+
+@pytest.mark.parametrize("H,W", [(64, 64), (70, 97), (33, 31), (256, 256), (512, 384)])
+def test_image_layer_with_the_gram_matrix_along(hip, H, W):
+    """maua_conv3x3_image_gram: the activation bit-identical to maua_conv3x3_image, and the slabs' sum (upper channel blocks) = Y Y^T of
+    that activation in fp64 (reference: torch.mm(x, x.T), /root/reference/loss.py:91, on relu1_1)."""
+    x = rnd(1, 3, H, W, seed=11) * 40.0
+    w = rnd(64, 3, 3, 3, seed=12, scale=0.3)
+    b = rnd(64, seed=13, scale=5.0)
+    bank = hip.conv_pack_filters_image(w.cuda(), b.cuda())
+    y0 = hip.conv3x3_image(x.cuda(), bank, 64, 1, True)
+    n = hip.conv_image_gram_slabs(H, W, 1)
+    slabs = torch.full((n, 64, 64), float("nan"), device="cuda")
+    y1 = hip.conv3x3_image_gram(x.cuda(), bank, 1, torch.empty_like(y0), slabs)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    g = slabs.double().sum(0).cpu()
+    f = y0.double().cpu().reshape(64, -1)
+    ref = f @ f.t()
+    upper = torch.ones(64, 64, dtype=torch.bool).triu()
+    upper[32:, :32] = False
+    err = float((g - ref)[upper].norm() / ref[upper].norm())
+    assert err <= 3e-7, err
+    # the finishing kernels read the lower triangle of the diagonal blocks from the upper one: what is there must be finite at least
+    assert torch.isfinite(g[:32, :32]).all() and torch.isfinite(g[32:, 32:]).all() and torch.isfinite(g[:32, 32:]).all()
+    again = torch.empty_like(slabs)
+    hip.conv3x3_image_gram(x.cuda(), bank, 1, torch.empty_like(y0), again)
+    torch.cuda.synchronize()
+    assert torch.equal(again[:, :32], slabs[:, :32]) and torch.equal(again[:, 32:, 32:], slabs[:, 32:, 32:])

@@ -775,3 +775,28 @@ def test_pool_in_the_convolution_epilogue_changes_no_bit(weight_files, monkeypat
     assert res["0"][2] == 0 and res["1"][2] >= 2, (res["0"][2], res["1"][2])
     assert torch.isfinite(res["1"][1]).all()
     assert torch.equal(res["0"][0], res["1"][0]) and torch.equal(res["0"][1], res["1"][1])
+
+
+def test_gram_slabs_from_the_image_layer_change_nothing_but_rounding(weight_files, monkeypatch):
+    """relu1_1's Gram matrix from the slabs the image layer's own launch leaves (maua_conv3x3_image_gram, bf16 triples) against the
+    separate partial kernel over the written activation (fp16 pairs): every other loss bit-identical, relu1_1's loss and the pixel
+    gradient equal to fp32 rounding, and as close to the fp64 oracle's evaluation."""
+    import engine
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MAUA_IMAGE_GRAM", flag)
+        monkeypatch.setenv("MAUA_DEBUG_POISON", "1")
+        args = product_args(weight_files, S=256)
+        content, style, init = synth.images(256)
+        net, losses = build(args, content, [style], 256)
+        eng = engine.StyleEngine(net, losses)
+        slots, total, grad = eng.feval(init.cuda())
+        torch.cuda.synchronize()
+        res[flag] = (slots.clone().cpu(), float(total), grad.clone().cpu(), len(eng.image_gram))
+    assert res["0"][3] == 0 and res["1"][3] == 1
+    s0, s1 = res["0"][0], res["1"][0]
+    differing = [i for i in range(len(s0)) if s0[i] != s1[i]]
+    assert len(differing) <= 1, differing                                   # relu1_1's style loss only
+    assert torch.allclose(s0, s1, rtol=2e-6, atol=0)
+    assert rel_l2(res["1"][2], res["0"][2].double()) <= 2e-6
+    assert torch.isfinite(res["1"][2]).all()

@@ -31,4 +31,9 @@ for s in sizes:
     y = torch.empty(1, 64, s, s, device="cuda")
     t_img = timed(lambda: hip.conv3x3_image(x, bank, 64, 1, True, out=y))
     t_x6 = timed(lambda: hip.conv3x3_x6(x, bf, b, 64, 1, True, out=y))
-    print(f"{s}x{s}: conv_img {t_img:7.1f} us ({y.numel() * 4 / t_img / 1e6:.2f} TB/s written)   conv_x6 {t_x6:7.1f} us")
+    slabs = torch.empty(hip.conv_image_gram_slabs(s, s, 1), 64, 64, device="cuda")
+    t_g = timed(lambda: hip.conv3x3_image_gram(x, bank, 1, y, slabs))
+    ws = torch.empty(hip.gram_workspace_bytes(64, s * s), dtype=torch.uint8, device="cuda")
+    t_p = timed(lambda: hip.gram_partial(y, False, None, ws))
+    print(f"{s}x{s}: conv_img {t_img:7.1f} us ({y.numel() * 4 / t_img / 1e6:.2f} TB/s written)   conv_x6 {t_x6:7.1f} us   "
+          f"conv_img with the Gram slabs {t_g:7.1f} us   (separate Gram partial kernel of relu1_1: {t_p:7.1f} us)")
