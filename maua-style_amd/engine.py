@@ -421,11 +421,10 @@ class StyleEngine:
         return flops, nbytes
 
     def _image_gram_now(self, s, shape):
-        """Whether this evaluation's image-layer launch carries the Gram slabs of its style layer: the layer is active and its chain is
-        one of those batched behind the forward pass (no side stream, partial batch on)."""
+        """Whether this evaluation's image-layer launch carries the Gram slabs of its style layer: the layer is active (its fold and
+        finishing launches then run with the other layers' behind the forward pass, or - largest images - on the side stream)."""
         st, _ = self.image_gram[id(s)]
-        return self.gram_batch_on and self.gram_partial_batch_on and not (self.style_aside and self.timer is None) and \
-            self._active(st, self.act[s.dst].shape)
+        return self.gram_batch_on and self.gram_partial_batch_on and self._active(st, self.act[s.dst].shape)
 
     def image_gram_slabs(self, style_step):
         return next(n for st, n in self.image_gram.values() if st is style_step)
@@ -563,9 +562,22 @@ class StyleEngine:
                                               ledger=self.ledger[0], slot=s.slot, f=f if later else None,
                                               slabs=self.image_gram_slabs(s) if id(s) in emitted else 0))
                             continue
-                        self._timed("gram_fwd", 2 * c * c * (n // c), n * 4 + c * c * 4, lambda: hip.gram_fwd_mse_ledger(
-                            f, 1.0 / n, s.mod.use_covariance, self.gram[id(s)], self.mean[id(s)], s.mod.target, self.dmat[id(s)],
-                            lw / (c * c), gw * 4.0 / (c * c) / n, self.ledger[0], s.slot, workspace=wsb))
+                        if id(s) in emitted:  # (side stream: fold and finish the slabs the image layer's launch left)
+                            l = dict(step=s, workspace=self._gram_ws(s, c, n // c, f.device), gram=self.gram[id(s)], target=s.mod.target,
+                                     dmat=self.dmat[id(s)], c=c, hw=n // c, scale=1.0 / n, loss_scale=lw / (c * c), grad_scale=gw * 4.0 / (c * c) / n,
+                                     ledger=self.ledger[0], slot=s.slot, f=None, slabs=self.image_gram_slabs(s))
+                            key = (id(s), l["target"].data_ptr(), l["workspace"].data_ptr(), l["gram"].data_ptr(), l["dmat"].data_ptr(),
+                                   l["ledger"].data_ptr(), l["slot"], l["loss_scale"], l["grad_scale"], l["slabs"])
+                            fin = self._gram_batches.get(("img", id(s)))
+                            if fin is None or fin[0] != key:
+                                fin = (key, hip.GramFinishBatch([l]))
+                                self._gram_batches[("img", id(s))] = fin
+                            fin[1].run_partial()
+                            fin[1].run()
+                        else:
+                            self._timed("gram_fwd", 2 * c * c * (n // c), n * 4 + c * c * 4, lambda: hip.gram_fwd_mse_ledger(
+                                f, 1.0 / n, s.mod.use_covariance, self.gram[id(s)], self.mean[id(s)], s.mod.target, self.dmat[id(s)],
+                                lw / (c * c), gw * 4.0 / (c * c) / n, self.ledger[0], s.slot, workspace=wsb))
                         if id(s) in self.fused_style:
                             hip.conv_pack_dmat_x3w(self.dmat[id(s)], self.fused_style[id(s)][1][0], self.fused_style[id(s)][2])
                     continue
@@ -585,7 +597,10 @@ class StyleEngine:
                     later = [l for l in grp if l["f"] is not None]
                     if later and len(later) != len(grp):  # (mixed Gram / covariance layers: the waiting ones one by one)
                         for l in later:
-                            hip.gram_partial(l["f"], False, None, l["workspace"])
+                            if l["slabs"]:
+                                hip.GramFinishBatch([l]).run_partial()  # (slabs from the image layer: their fold only)
+                            else:
+                                hip.gram_partial(l["f"], False, None, l["workspace"])
                         later = []
                     fin = self._gram_batches.get(k0)
                     if fin is None or fin[0] != key:
