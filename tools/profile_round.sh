@@ -1,4 +1,5 @@
 set -x
+# (the *_clock.py tools below load diagnostic builds from tools/_build/: run tools/build_stamp_libs.sh in the container first, after any change to csrc/)
 R=$PWD; O=$R/gpurun_out/${ROUND_DIR:-r3fin}; mkdir -p $O
 python bench.py --steps 200 > $O/bench_graph.json 2> $O/bench_graph.err
 python bench.py --steps 100 --no_hip_graph --no_cpu_baseline --no_extra_sizes > $O/bench_eager.json 2>/dev/null
