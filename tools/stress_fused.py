@@ -1,4 +1,5 @@
-"""Run-to-run stability of the fused convolution launches (Gram backward in the K loop, ReLU + pool in the epilogue) and of the
+"""Run-to-run stability of the fused convolution launches (Gram backward in the K loop, ReLU + pool in the epilogue, pool backward in the
+staging, the image layer with its Gram slabs) and of the
 L-BFGS kernels: the same launch repeated many times while other work keeps the chip busy must give the same bits every time.
     python tools/stress_fused.py [REPEATS=200]"""
 import os
@@ -46,8 +47,36 @@ for (n, cin, c, H, W) in [(1, 64, 64, 256, 256), (1, 128, 128, 128, 160), (2, 12
         hip.conv3x3_x3w_relu_pool(x, bf, wsc2, bias, c, 1, p1, c1)
         if not (torch.equal(p0, p1) and torch.equal(c0, c1)):
             bad += 1
+    # backward straight from the pooled gradient (split-K form where the workspace allows it), with the Gram backward along
+    gp = torch.randn(n, cin, H // 2, W // 2, device="cuda", generator=g)
+    cg = torch.empty(n, cin, H // 2, W // 2, dtype=torch.uint8, device="cuda")
+    hip.pool2x2_fwd_codes(torch.relu(torch.randn(n, cin, H, W, device="cuda", generator=g)), torch.empty_like(gp), cg)
+    u0 = hip.conv3x3_x3w_unpool(gp, cg, True, bb, wsc, c, 1, out_relu_mask=f, dmat_bank=banks, dmat_inv_scale=inv, workspace=ws).clone()
+    for r in range(reps):
+        if r % 3 == 0:
+            with torch.cuda.stream(side):
+                noise_a @ noise_a
+        if not torch.equal(hip.conv3x3_x3w_unpool(gp, cg, True, bb, wsc, c, 1, out_relu_mask=f, dmat_bank=banks, dmat_inv_scale=inv, workspace=ws), u0):
+            bad += 1
     torch.cuda.synchronize()
     print(f"n={n} {cin}->{c} @{H}x{W}: {reps} repeats each, mismatches so far {bad}", flush=True)
+# the image layer with its Gram slabs: activation and slabs (what the finishing kernels read of them) the same every time
+img = torch.randn(1, 3, 200, 328, device="cuda", generator=g) * 50
+wi = torch.randn(64, 3, 3, 3, device="cuda", generator=g) * 0.3
+bank_i = hip.conv_pack_filters_image(wi, torch.randn(64, device="cuda", generator=g))
+ns = hip.conv_image_gram_slabs(200, 328, 1)
+y0, s0 = torch.empty(1, 64, 200, 328, device="cuda"), torch.zeros(ns, 64, 64, device="cuda")
+hip.conv3x3_image_gram(img, bank_i, 1, y0, s0)
+y1, s1 = torch.empty_like(y0), torch.zeros_like(s0)
+for r in range(reps):
+    if r % 3 == 0:
+        with torch.cuda.stream(side):
+            noise_a @ noise_a
+    hip.conv3x3_image_gram(img, bank_i, 1, y1, s1)
+    if not (torch.equal(y0, y1) and torch.equal(s0[:, :32], s1[:, :32]) and torch.equal(s0[:, 32:, 32:], s1[:, 32:, 32:])):
+        bad += 1
+torch.cuda.synchronize()
+print(f"image layer + Gram slabs: {reps} repeats, mismatches so far {bad}", flush=True)
 # L-BFGS: two states fed the same gradients must stay identical
 nvec = 3 * 256 * 256
 A = 10.0 ** (torch.rand(nvec, device="cuda", generator=g) * 6 - 3)
