@@ -159,6 +159,21 @@ def pmc_traffic(prefix):
                     "2 x TCC_EA0_RDREQ x 64 B (gfx950 correction, upper bound for 4 B/lane loads) + write requests"}
 
 
+def pmc_traffic_lbfgs():
+    """Memory-side bytes of one maua_lbfgs_iterate at full history (its five launches added up) from the committed PMC pass of
+    `bench.py --model nin` (profiles/pmc_r03_traffic_nin.json: tools/profile_round.sh, the last four launches of each kernel)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_r03_traffic_nin.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        kernels = json.load(f)["kernels"]
+    total = sum(2 * e["read_bytes_raw"] + e["write_bytes_raw"] for name, e in kernels.items() if name.startswith(("maua::lbfgs_pair", "maua::lbfgs_finish_dots", "maua::lbfgs_coeffs", "maua::lbfgs_combine")) and "read_bytes_raw" in e)
+    if not total:
+        return None
+    return {"bytes": round(total), "note": "per update (the five launches), from profiles/pmc_r03_traffic_nin.json (a separate rocprofv3 --pmc pass of "
+                                           "this command, last four launches of each kernel = full history): 2 x TCC_EA0_RDREQ x 64 B + write requests"}
+
+
 def _visible_gpus():
     """Device count WITHOUT initialising the GPU in this process (torch.cuda.device_count() does not, on this image)."""
     try:
@@ -594,8 +609,8 @@ def main():
                                                   "one maua_lbfgs_iterate bracketed together)",
                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                         "algorithmic_bytes_per_launch": lb_bytes, "avg_launch_ms": round(lb_ms, 4), "launches": len(lbfgs_events),
-                        "share_of_step": round(lb_ms / ms, 3), "traffic": None,
-                        "traffic_note": "no PMC pass committed for this workload",
+                        "share_of_step": round(lb_ms / ms, 3), "traffic": (pmc_traffic_lbfgs() or {}).get("bytes"),
+                        "traffic_note": (pmc_traffic_lbfgs() or {"note": "no PMC pass committed for this workload"})["note"],
                         "events_from": "second pass of K eager iterations (the timed region replays a hipGraph)",
                         "eager_ms_per_step_with_events": round(eager_ms, 4) if eager_ms is not None else None,
                         "matrix_kernels": None if conv_part is None else {

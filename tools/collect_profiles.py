@@ -36,8 +36,10 @@ for a, b in (("bench_graph.json", f"bench_r{rr}_final_1024_lbfgs.json"), ("bench
     with open(os.path.join(dst, b), "w") as f:
         f.write(json.dumps(last_json(os.path.join(src, a))) + "\n")
 for a, b in (("sizes_lbfgs.jsonl", f"bench_r{rr}_sizes_lbfgs.jsonl"), ("sizes_adam.jsonl", f"bench_r{rr}_sizes_adam.jsonl"),
-             ("configs.json", f"configs_r{rr}_final.json"), ("pmc_traffic.json", f"pmc_r{rr}_traffic.json")):
-    shutil.copy(os.path.join(src, a), os.path.join(dst, b))
+             ("configs.json", f"configs_r{rr}_final.json"), ("pmc_traffic.json", f"pmc_r{rr}_traffic.json"),
+             ("pmc_traffic_nin.json", f"pmc_r{rr}_traffic_nin.json")):
+    if os.path.exists(os.path.join(src, a)):
+        shutil.copy(os.path.join(src, a), os.path.join(dst, b))
 serial = os.path.join(src, "stats", "p_kernel_stats.csv")
 shutil.copy(serial, os.path.join(dst, f"rocprof_r{rr}_kernel_stats_1024_lbfgs.csv"))
 table = subprocess.run([sys.executable, os.path.join(REPO, "tools", "summarise_stats.py"), serial, "122", rr], capture_output=True, text=True, check=True).stdout

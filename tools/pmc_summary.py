@@ -1,6 +1,8 @@
 """Summarise rocprofv3 --pmc passes (counter_collection.csv) per kernel: average counter value per launch.
 
-    python tools/pmc_summary.py OUT.json DIR_OR_CSV [DIR_OR_CSV ...]
+    python tools/pmc_summary.py [--last N] OUT.json DIR_OR_CSV [DIR_OR_CSV ...]
+
+--last N: only the last N launches of every kernel count (a run that fills the L-BFGS history first: the sweeps at full history).
 
 Each pass is a separate `rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python3 bench.py ...` run
 (MI355X_MICROARCH.md, section HBM: FETCH_SIZE / WRITE_SIZE come from the L2's memory-side request counters; on gfx950
@@ -25,7 +27,11 @@ def short(name):
 
 
 def main():
-    out, srcs = sys.argv[1], sys.argv[2:]
+    argv = sys.argv[1:]
+    last = 0
+    if argv and argv[0] == "--last":
+        last, argv = int(argv[1]), argv[2:]
+    out, srcs = argv[0], argv[1:]
     files = []
     for s in srcs:
         files += [s] if s.endswith(".csv") else glob.glob(os.path.join(s, "**", "*counter_collection.csv"), recursive=True)
@@ -34,7 +40,15 @@ def main():
     for f in files:
         seen = set()
         with open(f, newline="") as fh:
-            for row in csv.DictReader(fh):
+            rows = list(csv.DictReader(fh))
+        if last:  # keep the rows of each kernel's last `last` dispatches
+            ids = defaultdict(set)
+            for row in rows:
+                ids[short(row["Kernel_Name"])].add(int(row["Dispatch_Id"]))
+            keep = {k: set(sorted(v)[-last:]) for k, v in ids.items()}
+            rows = [row for row in rows if int(row["Dispatch_Id"]) in keep[short(row["Kernel_Name"])]]
+        if True:
+            for row in rows:
                 k = short(row["Kernel_Name"])
                 a = acc[k][row["Counter_Name"]]
                 a[0] += float(row["Counter_Value"])

@@ -12,7 +12,11 @@ rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/pmc_b -o p -- $B > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $O/pmc_c -o p -- $B > /dev/null 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_d -o p -- $B > /dev/null 2>&1
+# BASELINE config 5: memory-side traffic of the L-BFGS sweeps at FULL history (the run fills it first; the last 4 launches count)
+rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d $O/pmc_nin -o p -- python3 $R/bench.py --model nin --steps 4 --warmup 1 --no_cpu_baseline --no_hip_graph --no_extra_sizes --no_exact_split --no_repeats > /dev/null 2>&1
 cd $R
+python tools/pmc_summary.py --last 4 $O/pmc_traffic_nin.json $O/pmc_nin > $O/pmc_summary_nin.txt 2>&1
+rm -rf $O/pmc_nin
 python tools/pmc_summary.py $O/pmc_traffic.json $O/pmc_a $O/pmc_b $O/pmc_c $O/pmc_d > $O/pmc_summary.txt 2>&1
 rm -rf $O/pmc_a $O/pmc_b $O/pmc_c $O/pmc_d
 for S in 256 512 724 1024 1448 2048; do python bench.py --size $S --steps 100 --no_cpu_baseline --no_extra_sizes 2>/dev/null >> $O/sizes_lbfgs.jsonl; done
