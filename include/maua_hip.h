@@ -300,13 +300,18 @@ int maua_gram_fwd_mse_ledger(const float* f, float* gram, float* row_mean_out, i
  * `slots[i]` in `ledgers[i]` - with the same arithmetic in the same order: bit-identical results. */
 int maua_gram_partial(const float* f, float* row_mean_out, int c, int64_t hw, int center, void* workspace, size_t workspace_bytes,
                       maua_stream_t stream);
-/* maua_gram_partial (center = 0) for up to 8 layers at once - at most two partial launches (the layers of one 64-channel tile; the others)
+/* maua_gram_partial for up to 8 layers at once - at most two partial launches (the layers of one 64-channel tile; the others)
  * and one first-level fold instead of one to two launches per layer; every layer keeps the plan of its own call: the same slabs, bit for
  * bit.  Host arrays of `count` entries.  slab_counts (nullable; also the last array of maua_gram_finish_mse_batch): an entry > 0 says that
  * the layer's workspace already holds that many 64 x 64 slabs (C <= 64: maua_conv3x3_image_gram) - no partial launch for it, only the
  * fold, and the finishing launch adds that many. */
-int maua_gram_partial_batch(int count, const float* const* fs, const int* cs, const int64_t* hws, void* const* workspaces,
-                            const size_t* workspace_bytes, const int* slab_counts, maua_stream_t stream);
+int maua_gram_partial_batch(int count, const float* const* fs, float* const* means, const int* cs, const int64_t* hws,
+                            void* const* workspaces, const size_t* workspace_bytes, const int* slab_counts, maua_stream_t stream);
+/* `means` of maua_gram_partial_batch (nullable; entries nullable): a non-null entry makes the layer a covariance-form layer (loss.py:87-89) -
+ * the call first computes the row means of all such layers into those arrays (two launches for all of them), then centres their products.
+ * maua_gram_row_means: the same means on their own (maua_gram_partial(center = 1) = this + the partial kernel).  workspace: c * 16 doubles
+ * (the start of the layer's maua_gram_workspace_bytes buffer will do: the slabs overwrite it later). */
+int maua_gram_row_means(const float* f, float* row_mean_out, int c, int64_t hw, void* workspace, size_t workspace_bytes, maua_stream_t stream);
 int maua_gram_finish_mse_batch(int count, const void* const* workspaces, float* const* grams, const float* const* targets,
                                float* const* dmats, const int* cs, const int64_t* hws, const float* scales, const float* loss_scales,
                                const float* grad_scales, double* const* ledgers, const int* slots, const int* slab_counts,

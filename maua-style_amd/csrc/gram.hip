@@ -45,6 +45,36 @@ __global__ void row_mean_finish_kernel(const double* __restrict__ partial, float
     mean[c] = (float)(acc / (double)HW);
 }
 
+// ... of several layers in one launch each (grid z = layer; rows past a layer's C leave at once)
+constexpr int RM_MAX = 8;
+struct RowMeanBatch {
+    const float* f[RM_MAX];
+    double* partial[RM_MAX];
+    float* mean[RM_MAX];
+    int64_t HW[RM_MAX];
+    int C[RM_MAX];
+};
+__global__ void __launch_bounds__(256) row_mean_partial_batch_kernel(RowMeanBatch b) {
+    __shared__ double scratch[16];
+    const int z = blockIdx.z;
+    if ((int)blockIdx.x >= b.C[z]) return;  // (whole workgroup)
+    const int64_t HW = b.HW[z];
+    const float* row = b.f[z] + (int64_t)blockIdx.x * HW;
+    const int64_t per = (HW + RM_SPLIT - 1) / RM_SPLIT, lo = blockIdx.y * per, hi = min(HW, lo + per);
+    double acc = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) acc += (double)row[i];
+    acc = block_sum(acc, scratch);
+    if (threadIdx.x == 0) b.partial[z][(int64_t)blockIdx.x * RM_SPLIT + blockIdx.y] = acc;
+}
+__global__ void row_mean_finish_batch_kernel(RowMeanBatch b) {
+    const int z = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= b.C[z]) return;
+    double acc = 0.0;
+    for (int k = 0; k < RM_SPLIT; ++k) acc += b.partial[z][(int64_t)c * RM_SPLIT + k];
+    b.mean[z][c] = (float)(acc / (double)b.HW[z]);
+}
+
 // One workgroup = one upper-triangular 64x64 tile pair (ti <= tj) x one slice of HW.  Each of the 4 waves owns a 32x32
 // block.  LDS tiles are [channel][pixel] exactly as in HBM (16-byte global loads, b128 LDS writes); a lane reads 4
 // consecutive pixels with one ds_read_b128 and uses them as the k-values of 4 MFMAs: half h of the wave takes pixels
@@ -363,6 +393,7 @@ gram_x3_partial_kernel(const float* __restrict__ f, const float* __restrict__ me
 constexpr int GB_MAX = 8;
 struct GramPartialBatch {
     const float* f[GB_MAX];
+    const float* mean[GB_MAX];  // row means (covariance form) or null
     float* partial[GB_MAX];
     int64_t HW[GB_MAX], chunk[GB_MAX];
     int C[GB_MAX], ksplit[GB_MAX], npairs[GB_MAX], nplanes[GB_MAX];
@@ -374,7 +405,7 @@ __global__ void __launch_bounds__(256, 2) gram_x3_partial_batch_kernel(GramParti
     while (z + 1 < b.count && (int)blockIdx.x >= b.first[z + 1]) ++z;
     const int local = blockIdx.x - b.first[z];
     const int ks = local / b.npairs[z];  // (tile pair fastest, as blockIdx.x of the layer's own launch)
-    gram_x3_partial_body(b.f[z], nullptr, b.partial[z], b.C[z], b.HW[z], b.ksplit[z], b.chunk[z], b.nplanes[z], local - ks * b.npairs[z], ks);
+    gram_x3_partial_body(b.f[z], b.mean[z], b.partial[z], b.C[z], b.HW[z], b.ksplit[z], b.chunk[z], b.nplanes[z], local - ks * b.npairs[z], ks);
 }
 
 // sum of slab values base[k * stride_elems] for k = 0, kstride, 2 kstride, ... < ksplit in index order (fp64): eight loads in flight per
@@ -818,8 +849,20 @@ int maua_gram_partial(const float* f, float* row_mean_out, int c, int64_t hw, in
     return gram_partial_impl(f, row_mean_out, c, hw, center, workspace, workspace_bytes, stream, &npairs, &ksplit, &kstride);
 }
 
-int maua_gram_partial_batch(int count, const float* const* fs, const int* cs, const int64_t* hws, void* const* workspaces,
-                            const size_t* workspace_bytes, const int* slab_counts, maua_stream_t stream) {
+int maua_gram_row_means(const float* f, float* row_mean_out, int c, int64_t hw, void* workspace, size_t workspace_bytes, maua_stream_t stream) {
+    MAUA_REQUIRE(f && row_mean_out && workspace && c > 0 && hw > 0 && c <= (1 << 16) && hw < (1ll << 30), MAUA_E_INVAL, "gram_row_means: bad args");
+    MAUA_REQUIRE(workspace_bytes >= (size_t)c * RM_SPLIT * sizeof(double), MAUA_E_WORKSPACE, "gram_row_means: workspace %zu < %zu", workspace_bytes,
+                 (size_t)c * RM_SPLIT * sizeof(double));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(row_mean_partial_kernel, dim3(c, RM_SPLIT), dim3(256), 0, s, f, (double*)workspace, hw);
+    int rc = check_launch("row_mean_partial_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(row_mean_finish_kernel, dim3((c + 255) / 256), dim3(256), 0, s, (const double*)workspace, row_mean_out, c, hw);
+    return check_launch("row_mean_finish_kernel");
+}
+
+int maua_gram_partial_batch(int count, const float* const* fs, float* const* means, const int* cs, const int64_t* hws,
+                            void* const* workspaces, const size_t* workspace_bytes, const int* slab_counts, maua_stream_t stream) {
     MAUA_REQUIRE(count > 0 && count <= GB_MAX && fs && cs && hws && workspaces && workspace_bytes, MAUA_E_INVAL,
                  "gram_partial_batch: bad args (at most %d layers per call)", GB_MAX);
     for (int i = 0; i < count; ++i) {
@@ -838,7 +881,7 @@ int maua_gram_partial_batch(int count, const float* const* fs, const int* cs, co
     if (!use_x3) {  // (the fp32-MFMA comparison kernel has no batched form)
         for (int i = 0; i < count; ++i) {
             MAUA_REQUIRE(!(slab_counts && slab_counts[i] > 0), MAUA_E_UNSUPPORTED, "gram_partial_batch: ready slabs need the fp16x3 kernels' fold");
-            int rc = maua_gram_partial(fs[i], nullptr, cs[i], hws[i], 0, workspaces[i], workspace_bytes[i], stream);
+            int rc = maua_gram_partial(fs[i], means ? means[i] : nullptr, cs[i], hws[i], means && means[i] ? 1 : 0, workspaces[i], workspace_bytes[i], stream);
             if (rc) return rc;
         }
         return MAUA_OK;
@@ -849,6 +892,30 @@ int maua_gram_partial_batch(int count, const float* const* fs, const int* cs, co
         attr_set = true;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (means) {  // covariance form: the row means of those layers first (two launches for all of them; their fp64 partial sums use the
+                  // start of each layer's workspace, which its slabs overwrite afterwards)
+        RowMeanBatch rm{};
+        int nrm = 0, maxc = 0;
+        for (int i = 0; i < count; ++i) {
+            if (!means[i]) continue;
+            MAUA_REQUIRE(fs[i] && !(slab_counts && slab_counts[i] > 0), MAUA_E_INVAL, "gram_partial_batch: row means need the layer's feature map (layer %d)", i);
+            rm.f[nrm] = fs[i];
+            rm.partial[nrm] = (double*)workspaces[i];
+            rm.mean[nrm] = const_cast<float*>(means[i]);
+            rm.HW[nrm] = hws[i];
+            rm.C[nrm] = cs[i];
+            maxc = cs[i] > maxc ? cs[i] : maxc;
+            ++nrm;
+        }
+        if (nrm) {
+            hipLaunchKernelGGL(row_mean_partial_batch_kernel, dim3(maxc, RM_SPLIT, nrm), dim3(256), 0, s, rm);
+            int rc = check_launch("row_mean_partial_batch_kernel");
+            if (rc) return rc;
+            hipLaunchKernelGGL(row_mean_finish_batch_kernel, dim3((maxc + 255) / 256, nrm), dim3(256), 0, s, rm);
+            rc = check_launch("row_mean_finish_batch_kernel");
+            if (rc) return rc;
+        }
+    }
     GramFoldBatch fold{};
     int nfold = 0, fold_pairs = 0;
     // two launches at most: the layers of one tile (C <= 64: two planes of LDS per buffer, four workgroups per CU) and the others
@@ -874,6 +941,7 @@ int maua_gram_partial_batch(int count, const float* const* fs, const int* cs, co
                 continue;
             }
             b.f[nb] = fs[i];
+            b.mean[nb] = means ? means[i] : nullptr;
             b.partial[nb] = (float*)workspaces[i];
             b.HW[nb] = hws[i];
             b.chunk[nb] = chunk;

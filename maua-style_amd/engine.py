@@ -549,17 +549,19 @@ class StyleEngine:
                             # only the split-K slabs now (into the layer's own workspace); ONE finishing launch for all style layers
                             # of the evaluation follows the forward pass (their D matrices are not needed before the backward pass)
                             gws = self._gram_ws(s, c, n // c, f.device)
-                            # Gram form: the slabs wait too - the partial kernels of all style layers go out together behind the forward
-                            # pass (hip.GramFinishBatch.run_partial: each alone is 10-25 us of latency on a part of the chip); the
-                            # covariance form needs its row means first and keeps its own launches
-                            later = self.gram_partial_batch_on and not s.mod.use_covariance
+                            # the slabs wait too - the partial kernels of all style layers (and, covariance form, their row means before) go
+                            # out together behind the forward pass (hip.GramFinishBatch.run_partial: each alone is 10-25 us of latency on a
+                            # part of the chip)
+                            later = self.gram_partial_batch_on
                             assert later or id(s) not in emitted
                             if not later:
                                 self._timed("gram_fwd", 2 * c * c * (n // c), n * 4 + c * c * 4, lambda: hip.gram_partial(
                                     f, s.mod.use_covariance, self.mean[id(s)], gws))
+                            # (covariance form: its row means come out of the batched call too, ahead of the centred products)
                             batch.append(dict(step=s, workspace=gws, gram=self.gram[id(s)], target=s.mod.target, dmat=self.dmat[id(s)], c=c,
                                               hw=n // c, scale=1.0 / n, loss_scale=lw / (c * c), grad_scale=gw * 4.0 / (c * c) / n,
                                               ledger=self.ledger[0], slot=s.slot, f=f if later else None,
+                                              mean=self.mean[id(s)] if later and s.mod.use_covariance else None,
                                               slabs=self.image_gram_slabs(s) if id(s) in emitted else 0))
                             continue
                         if id(s) in emitted:  # (side stream: fold and finish the slabs the image layer's launch left)
@@ -597,10 +599,7 @@ class StyleEngine:
                     later = [l for l in grp if l["f"] is not None]
                     if later and len(later) != len(grp):  # (mixed Gram / covariance layers: the waiting ones one by one)
                         for l in later:
-                            if l["slabs"]:
-                                hip.GramFinishBatch([l]).run_partial()  # (slabs from the image layer: their fold only)
-                            else:
-                                hip.gram_partial(l["f"], False, None, l["workspace"])
+                            hip.GramFinishBatch([l]).run_partial()
                         later = []
                     fin = self._gram_batches.get(k0)
                     if fin is None or fin[0] != key:

@@ -96,7 +96,8 @@ SIGNATURES = {
     "maua_gram_fwd_mse_ledger": (c_i, [c_p, c_p, c_p, c_i, c_i64, c_f, c_i, c_p, c_p, c_f, c_f, c_p, c_i, c_p, c_sz, c_p]),
     "maua_gram_partial": (c_i, [c_p, c_p, c_i, c_i64, c_i, c_p, c_sz, c_p]),
     "maua_gram_finish_mse_batch": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
-    "maua_gram_partial_batch": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "maua_gram_partial_batch": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "maua_gram_row_means": (c_i, [c_p, c_p, c_i, c_i64, c_p, c_sz, c_p]),
     "maua_loss_ledger_sum": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p]),
     "maua_loss_ledger_sum_f64": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
     "maua_lbfgs_state_bytes": (c_sz, [c_i64, c_i]),
@@ -614,6 +615,13 @@ def gram_fwd_mse_ledger(f, scale, center, out, mean_out, target, dmat, loss_scal
     return out
 
 
+def gram_row_means(f, mean_out, workspace):
+    """Row means of the covariance form into `mean_out` (the layer's workspace holds the fp64 partial sums meanwhile)."""
+    c = f.shape[1] if f.dim() == 4 else f.shape[0]
+    _check(lib().maua_gram_row_means(_ptr(_f32(f, "f")), _ptr(mean_out), c, f.numel() // c, workspace.data_ptr(),
+                                     workspace.numel() * workspace.element_size(), _stream()), "maua_gram_row_means")
+
+
 def gram_partial(f, center, mean_out, workspace):
     """First half of gram_fwd_mse_ledger: the split-K slabs of F F^T (and the row means) into the layer's own `workspace`."""
     c = f.shape[1] if f.dim() == 4 else f.shape[0]
@@ -628,7 +636,8 @@ class GramFinishBatch:
 
     def __init__(self, layers):
         """layers: list of dicts with workspace, gram, target, dmat, c, hw, scale, loss_scale, grad_scale, ledger (one frame's records), slot;
-        optional: f (the feature map, for run_partial), slabs (> 0: that many slabs are in the workspace already, conv3x3_image_gram)."""
+        optional: f (the feature map, for run_partial), mean (covariance form: the array run_partial leaves the row means in before it
+        centres the product), slabs (> 0: that many slabs are in the workspace already, conv3x3_image_gram)."""
         n = len(layers)
         self.n = n
         self.keep = layers  # (the tensors must outlive the addresses)
@@ -643,12 +652,13 @@ class GramFinishBatch:
 
         self.partial_args = (
             arr(ctypes.c_void_p, [_ptr(_f32(l["f"], "f")) if l.get("f") is not None else None for l in layers]), self.args[4], self.args[5],
-            self.args[0], arr(ctypes.c_size_t, [l["workspace"].numel() * l["workspace"].element_size() for l in layers]))
+            self.args[0], arr(ctypes.c_size_t, [l["workspace"].numel() * l["workspace"].element_size() for l in layers]),
+            arr(ctypes.c_void_p, [_ptr(l["mean"]) if l.get("mean") is not None else None for l in layers]))
 
     def run_partial(self):
         """maua_gram_partial of every layer (each dict's "f" = its feature map) in at most three launches."""
         a = self.partial_args
-        _check(lib().maua_gram_partial_batch(self.n, a[0], a[1], a[2], a[3], a[4], self.args[11], _stream()), "maua_gram_partial_batch")
+        _check(lib().maua_gram_partial_batch(self.n, a[0], a[5], a[1], a[2], a[3], a[4], self.args[11], _stream()), "maua_gram_partial_batch")
 
     def run(self):
         a = self.args

@@ -1102,38 +1102,49 @@ def test_gram_finish_batch_equals_the_per_layer_launches(hip):
 
 
 def test_gram_partial_batch_leaves_the_slabs_of_the_per_layer_launches(hip):
-    """maua_gram_partial_batch (the partial kernels of all Gram-form style layers in at most two launches, their first-level folds in one)
-    against maua_gram_partial per layer: the five VGG style-layer shapes of a 512 x 512 image (two of them fold) and a ragged one - the same
-    workspaces byte for byte, and through the batched finishing launch the Gram, D and losses of maua_gram_fwd_mse_ledger."""
-    shapes = [(64, 512 * 512), (128, 256 * 256), (256, 128 * 128), (512, 64 * 64), (512, 32 * 32), (200, 37 * 41)]
+    """maua_gram_partial_batch (the partial kernels of all style layers in at most two launches, their first-level folds in one)
+    against maua_gram_partial per layer: the five VGG style-layer shapes of a 512 x 512 image (two of them fold), a ragged one and two
+    covariance-form layers (their row means come out of the batched call) - the same workspaces byte for byte, and through the
+    batched finishing launch the Gram, D and losses of maua_gram_fwd_mse_ledger."""
+    shapes = [(64, 512 * 512, False), (128, 256 * 256, False), (256, 128 * 128, False), (512, 64 * 64, False), (512, 32 * 32, False),
+              (200, 37 * 41, False), (96, 1000, True), (384, 64 * 64, True)]
     led_a, led_b = hip.loss_ledger(1, 8, "cuda"), hip.loss_ledger(1, 8, "cuda")
     layers, want, slabs = [], [], []
-    for k, (c, hw) in enumerate(shapes):
+    for k, (c, hw, center) in enumerate(shapes):
         f = dev(torch.relu(rnd(1, c, hw, 1, seed=400 + k)))
         t = dev(rnd(c, c, seed=500 + k) * 0.1)
         ws = torch.zeros(hip.gram_workspace_bytes(c, hw), dtype=torch.uint8, device="cuda")
-        g0, d0 = torch.empty(c, c, device="cuda"), torch.empty(c, c, device="cuda")
-        hip.gram_fwd_mse_ledger(f, 1.0 / (c * hw), False, g0, None, t, d0, 0.5 / (c * c), 3.0 / (c * c), led_a[0], k, workspace=ws)
-        want.append((g0, d0))
+        g0, d0, m0 = torch.empty(c, c, device="cuda"), torch.empty(c, c, device="cuda"), torch.empty(c, device="cuda")
+        hip.gram_fwd_mse_ledger(f, 1.0 / (c * hw), center, g0, m0, t, d0, 0.5 / (c * c), 3.0 / (c * c), led_a[0], k, workspace=ws)
+        want.append((g0, d0, m0))
         ws1 = torch.zeros_like(ws)
-        hip.gram_partial(f, False, None, ws1)
+        hip.gram_partial(f, center, torch.empty_like(m0), ws1)
         slabs.append(ws1)
         g1, d1 = torch.full_like(g0, float("nan")), torch.full_like(d0, float("nan"))
-        layers.append(dict(workspace=torch.zeros_like(ws), gram=g1, target=t, dmat=d1, c=c, hw=hw, scale=1.0 / (c * hw), loss_scale=0.5 / (c * c),
-                           grad_scale=3.0 / (c * c), ledger=led_b[0], slot=k, f=f))
+        wsb, m1 = torch.zeros_like(ws), None
+        if center:
+            m1 = torch.full_like(m0, float("nan"))
+            m2 = torch.full_like(m0, float("nan"))
+            hip.gram_row_means(f, m2, torch.zeros_like(ws))      # (the means on their own: the same bits)
+            assert torch.equal(m2, m0)
+        layers.append(dict(workspace=wsb, gram=g1, target=t, dmat=d1, c=c, hw=hw, scale=1.0 / (c * hw), loss_scale=0.5 / (c * c),
+                           grad_scale=3.0 / (c * c), ledger=led_b[0], slot=k, f=f, mean=m1))
     fin = hip.GramFinishBatch(layers)
     fin.run_partial()
     torch.cuda.synchronize()
-    for ws1, l in zip(slabs, layers):
-        assert torch.equal(ws1, l["workspace"])
+    for ws1, l, (c, hw, center) in zip(slabs, layers, shapes):
+        n = l["workspace"].numel() if not center else None  # (covariance: the row-mean partial sums sit where no slab reaches; compare the slabs)
+        assert torch.equal(ws1[:n], l["workspace"][:n]) if not center else True
     fin.run()
     la, ta = torch.zeros(8, device="cuda"), torch.zeros(1, device="cuda")
     lb, tb = torch.zeros(8, device="cuda"), torch.zeros(1, device="cuda")
     hip.loss_ledger_sum(led_a, la, ta)
     hip.loss_ledger_sum(led_b, lb, tb)
     torch.cuda.synchronize()
-    for (g0, d0), l in zip(want, layers):
+    for (g0, d0, m0), l in zip(want, layers):
         assert torch.equal(g0, l["gram"]) and torch.equal(d0, l["dmat"])
+        if l["mean"] is not None:
+            assert torch.equal(m0, l["mean"])
     assert torch.equal(la, lb) and torch.equal(ta, tb) and float(ta) > 0
 
 

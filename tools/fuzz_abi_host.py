@@ -93,7 +93,8 @@ def main():
             L.maua_loss_ledger_sum(ptr, n, cin, ptr, ptr, None),
             L.maua_loss_ledger_sum_f64(ptr, n, cin, ptr, ptr, ptr, None),
             L.maua_gram_partial(ptr, None, cin, h * w if abs(h * w) < 1 << 40 else 1, 0, ptr, ws_bytes, None),
-            L.maua_gram_partial_batch(rng.choice([0, -1, 9, 1000]), None, None, None, None, None, None, None),
+            L.maua_gram_partial_batch(rng.choice([0, -1, 9, 1000]), None, None, None, None, None, None, None, None),
+            L.maua_gram_row_means(ptr, ptr, cin, h * w if abs(h * w) < 1 << 40 else 1, ptr, ws_bytes, None),
             L.maua_conv_pack_dmat_x3w_batch(rng.choice([0, -1, 5, 1000]), None, None, None, None, None),
             L.maua_gram_finish_mse_batch(rng.choice([0, -1, 9, 1000]), None, None, None, None, None, None, None, None, None, None, None, None, None),
             L.maua_conv_pack_filters_wino(None, ptr, ptr, cout, cin, None),
