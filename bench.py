@@ -93,7 +93,7 @@ def cpu_baseline(S, optimizer, iters=5, repeats=3, model="vgg19"):
     import synth
     from oracle import OracleNet, build_spec
     from oracle.style_oracle import _LbfgsState, _lbfgs_step
-    nproc, model = _host_description()
+    nproc, cpu_model = _host_description()
     cfg = ap.Namespace(model_file="vgg19", pooling="max", content_layers="relu4_2",
                        style_layers="relu1_1,relu2_1,relu3_1,relu4_1,relu5_1", tv_weight=1e-3, temporal_weight=50.0,
                        content_weight=5.0, style_weight=100.0, use_covariance=False, normalize_gradients=True,
@@ -130,7 +130,7 @@ def cpu_baseline(S, optimizer, iters=5, repeats=3, model="vgg19"):
         times.append(time.perf_counter() - t0)
     dt = statistics.median(times)
     return {"value": round(iters / dt, 5), "unit": "iterations/s", "cores": best[1], "threads_used": best[1], "nproc": nproc,
-            "cpu_model": model, "kind": "port", "thread_sweep_s_per_feval": sweep,
+            "cpu_model": cpu_model, "model": model, "kind": "port", "thread_sweep_s_per_feval": sweep,
             "sample": f"{iters} L-BFGS iterations of the CPU oracle at {S}x{S} (the benchmarked size, no scaling), median of "
                       f"{repeats} runs: {dt:.2f} s on {best[1]} threads ({nproc} logical CPUs)"}
 

@@ -25,10 +25,11 @@ def init(backend=None):
     """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun's env).
     Returns (rank, local_rank, world).  One process per GPU; the device is chosen before any collective.
 
-    Two timeouts.  The default group - rendezvous, the start-up broadcast, the benchmark's barriers - gives up after
-    MAUA_DIST_TIMEOUT_S (default 600 s): a rank that died at start-up must not leave the others holding their GPUs.  Ranks
-    that finish uneven shards of a long job meet in `end_of_job_barrier`, on a second group with MAUA_DIST_JOB_TIMEOUT_S
-    (default one week)."""
+    Two timeouts.  The default group - rendezvous, the FIRST broadcast of a job, the benchmark's barriers - gives up after
+    MAUA_DIST_TIMEOUT_S (default 600 s): a rank that died at start-up must not leave the others holding their GPUs.  Every
+    collective that ranks reach after uneven amounts of work - vid_img's per-scale weight broadcast from the second scale on,
+    `gather_frames`, `end_of_job_barrier` - runs on a second group with MAUA_DIST_JOB_TIMEOUT_S (default one week).  Only rank
+    `src` needs a device-resident copy per group: RCCL creates the second communicator lazily at its first collective."""
     global _LONG_GROUP
     rank, local_rank, world = env_rank()
     if world > 1 and not td.is_initialized():
@@ -80,15 +81,22 @@ def shard_owner(index, n_items, world):
     raise IndexError(index)
 
 
-def broadcast_tensors(tensors, src=0):
-    """Broadcast a list of same-dtype tensors as ONE flat buffer (one collective instead of one per layer)."""
+def job_group():
+    """The long-timeout communicator (None outside a multi-rank job): for collectives that ranks reach after uneven amounts of
+    work - anything past the start-up phase of a sharded job."""
+    return _LONG_GROUP
+
+
+def broadcast_tensors(tensors, src=0, group=None):
+    """Broadcast a list of same-dtype tensors as ONE flat buffer (one collective instead of one per layer).  `group`: the
+    communicator (default group = short timeout; `job_group()` for a collective in the middle of a long job)."""
     if not (td.is_available() and td.is_initialized()):
         return  # (a one-rank group still runs the collective: the code path of the 8-GPU job on a 1-GPU box)
     tensors = [t for t in tensors if t is not None and t.numel() > 0]
     if not tensors:
         return
     flat = torch.cat([t.detach().reshape(-1) for t in tensors])
-    td.broadcast(flat, src=src)
+    td.broadcast(flat, src=src, group=group)
     off = 0
     with torch.no_grad():
         for t in tensors:
@@ -97,9 +105,11 @@ def broadcast_tensors(tensors, src=0):
             off += n
 
 
-def broadcast_network(net, src=0):
-    """Rank `src`'s conv weights/biases -> every rank (51.8 MB for VGG-19 through conv5_1)."""
-    broadcast_tensors([p.data for p in net.parameters()], src)
+def broadcast_network(net, src=0, mid_job=False):
+    """Rank `src`'s conv weights/biases -> every rank (51.8 MB for VGG-19 through conv5_1).  `mid_job`: the ranks arrive after
+    uneven shards of work (vid_img rebuilds the network per image size; a resumed rank may be a whole scale ahead of rank 0),
+    so the collective runs on the long-timeout group - the 10-minute default group is for start-up only."""
+    broadcast_tensors([p.data for p in net.parameters()], src, group=_LONG_GROUP if mid_job else None)
 
 
 def broadcast_style_targets(net, src=0):

@@ -99,6 +99,11 @@ class StyleEngine:
             elif isinstance(m, models_mod.ReLU):
                 s = _Step("relu", m)
                 s.src = s.dst = act
+                # (a stand-alone ReLU rewrites its activation in place.  Loss terms read their source activation AFTER the whole forward
+                #  pass - deferred Gram partial launches, the backward pass's D . F - so a loss module in front of it on the same
+                #  activation would see the rewritten values; the reference's autograd refuses that layout too)
+                if any(t.kind in ("style", "content") and t.src == act for t in steps):
+                    raise UnsupportedNet("in-place ReLU over an activation a loss module reads")
             elif isinstance(m, models_mod._Pool2d):
                 s = _Step("pool", m)
                 s.k, s.stride = models_mod._as_int(m.kernel_size), models_mod._as_int(m.stride)
@@ -228,7 +233,7 @@ class StyleEngine:
         self.image_gram = {}
         # (not for frames of a planned batch - batch_hint > 1: a frame's bits must not depend on how many others share its launches)
         if B == 1 and self.batch_hint == 1 and self.ledger is not None and self.x6_fwd and os.environ.get("MAUA_IMAGE_GRAM", "1") != "0" and \
-                models_mod._image_kernel_enabled():
+                os.environ.get("MAUA_GRAM_X3", "1") != "0" and models_mod._image_kernel_enabled():  # (ready slabs are folded by the fp16x3 route only)
             for s in self.steps:
                 if s.kind != "conv" or not s.relu or s.k != 3 or s.stride != 1 or s.mod.in_channels > 3 or s.mod.out_channels != 64 or \
                         not self._x6_ok(s, 64):
@@ -590,38 +595,33 @@ class StyleEngine:
                 if id(s) in self.fused_style:
                     hip.conv_pack_dmat_x3w(self.dmat[id(s)], self.fused_style[id(s)][1][0], self.fused_style[id(s)][2])
         if batch:  # the finishing pass of every style layer's Gram / loss chain in one launch (groups of eight), then the D banks
-            if batch:
-                for k0 in range(0, len(batch), 8):
-                    grp = batch[k0:k0 + 8]
-                    key = tuple((id(l["step"]), l["target"].data_ptr(), l["workspace"].data_ptr(), l["gram"].data_ptr(), l["dmat"].data_ptr(),
-                                 l["ledger"].data_ptr(), l["slot"], l["loss_scale"], l["grad_scale"],
-                                 None if l["f"] is None else l["f"].data_ptr(), l["slabs"]) for l in grp)
-                    later = [l for l in grp if l["f"] is not None]
-                    if later and len(later) != len(grp):  # (mixed Gram / covariance layers: the waiting ones one by one)
-                        for l in later:
-                            hip.GramFinishBatch([l]).run_partial()
-                        later = []
-                    fin = self._gram_batches.get(k0)
-                    if fin is None or fin[0] != key:
-                        fin = (key, hip.GramFinishBatch(grp))
-                        self._gram_batches[k0] = fin
-                    if later:
-                        self._timed("gram_fwd", sum(2 * l["c"] * l["c"] * l["hw"] for l in grp), sum(l["c"] * l["hw"] * 4 for l in grp), fin[1].run_partial)
-                    self._timed("gram_fwd", 0, sum(l["c"] * l["c"] * 8 for l in grp), fin[1].run)
-                packs = [(l["dmat"], self.fused_style[id(l["step"])][1][0], self.fused_style[id(l["step"])][2]) for l in batch
-                         if id(l["step"]) in self.fused_style]
-                if os.environ.get("MAUA_DMAT_PACK_BATCH", "1") == "0":
-                    for d, b, i in packs:
-                        hip.conv_pack_dmat_x3w(d, b, i)
-                    packs = []
-                for k0 in range(0, len(packs), 4):  # the one-tap banks of the fused layers' D matrices, one launch
-                    grp = packs[k0:k0 + 4]
-                    key = tuple((d.data_ptr(), b.data_ptr(), i.data_ptr()) for d, b, i in grp)
-                    pk = self._gram_batches.get(("pack", k0))
-                    if pk is None or pk[0] != key:
-                        pk = (key, hip.DmatPackBatch(grp))
-                        self._gram_batches[("pack", k0)] = pk
-                    pk[1].run()
+            for k0 in range(0, len(batch), 8):
+                grp = batch[k0:k0 + 8]
+                key = tuple((id(l["step"]), l["target"].data_ptr(), l["workspace"].data_ptr(), l["gram"].data_ptr(), l["dmat"].data_ptr(),
+                             l["ledger"].data_ptr(), l["slot"], l["loss_scale"], l["grad_scale"],
+                             None if l["f"] is None else l["f"].data_ptr(), l["slabs"]) for l in grp)
+                later = self.gram_partial_batch_on  # (then every entry waits with its feature map; otherwise none does)
+                fin = self._gram_batches.get(k0)
+                if fin is None or fin[0] != key:
+                    fin = (key, hip.GramFinishBatch(grp))
+                    self._gram_batches[k0] = fin
+                if later:
+                    self._timed("gram_fwd", sum(2 * l["c"] * l["c"] * l["hw"] for l in grp), sum(l["c"] * l["hw"] * 4 for l in grp), fin[1].run_partial)
+                self._timed("gram_fwd", 0, sum(l["c"] * l["c"] * 8 for l in grp), fin[1].run)
+            packs = [(l["dmat"], self.fused_style[id(l["step"])][1][0], self.fused_style[id(l["step"])][2]) for l in batch
+                     if id(l["step"]) in self.fused_style]
+            if os.environ.get("MAUA_DMAT_PACK_BATCH", "1") == "0":
+                for d, b, i in packs:
+                    hip.conv_pack_dmat_x3w(d, b, i)
+                packs = []
+            for k0 in range(0, len(packs), 4):  # the one-tap banks of the fused layers' D matrices, one launch
+                grp = packs[k0:k0 + 4]
+                key = tuple((d.data_ptr(), b.data_ptr(), i.data_ptr()) for d, b, i in grp)
+                pk = self._gram_batches.get(("pack", k0))
+                if pk is None or pk[0] != key:
+                    pk = (key, hip.DmatPackBatch(grp))
+                    self._gram_batches[("pack", k0)] = pk
+                pk[1].run()
         # ---------------- backward
         # Gradient buffers of fused conv+ReLU activations are kept PRE-MASKED: the last kernel that writes g[k] (the
         # backward of the consumer, or the last loss term attached to k) zeroes it where a[k] <= 0, so no backward-data

@@ -85,10 +85,6 @@ SIGNATURES = {
     "maua_conv_pack_dmat_x3w_batch": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p]),
     "maua_conv3x3_x3w_gram": (c_i, [c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "maua_conv3x3_x3w_unpool": (c_i, [c_p, c_p, c_i, c_p, c_f, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
-    "maua_conv_wino_bank_bytes": (c_sz, [c_i, c_i]),
-    "maua_conv_pack_filters_wino": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p]),
-    "maua_conv_wino_supported": (c_i, [c_i, c_i, c_i, c_i]),
-    "maua_conv3x3_wino": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "maua_loss_ledger_bytes": (c_sz, [c_i, c_i]),
     "maua_mse_fwd_bwd_ledger": (c_i, [c_p, c_p, c_p, c_i64, c_f, c_f, c_i, c_i, c_p, c_i, c_p]),
     "maua_tv_fwd_bwd_ledger": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_i, c_p]),
@@ -377,31 +373,6 @@ def conv3x3_x3w_unpool(pooled_x, codes, honour_relu_bit, bank, w_scale, cout, pa
                                          dmat_bank.data_ptr() if dmat_bank is not None else None,
                                          _ptr(dmat_inv_scale) if dmat_inv_scale is not None else None, _ptr(out), n, cin, h, w, cout, pad,
                                          wp, wn, _stream()), "maua_conv3x3_x3w_unpool")
-    return out
-
-
-def conv_pack_filters_wino(w):
-    """OIHW 3x3 weights -> (forward bank, backward-data bank) for conv_wino.hip: G g G^T in fp64, pre-split fp16 pairs in MFMA
-    lane order, the power-of-two scale in the bank's header (no host synchronisation)."""
-    cout, cin = w.shape[:2]
-    wc = _f32(w, "w").contiguous()
-    bf = torch.empty(lib().maua_conv_wino_bank_bytes(cout, cin), dtype=torch.uint8, device=w.device)
-    bb = torch.empty(lib().maua_conv_wino_bank_bytes(cin, cout), dtype=torch.uint8, device=w.device)
-    _check(lib().maua_conv_pack_filters_wino(_ptr(wc), bf.data_ptr(), bb.data_ptr(), cout, cin, _stream()),
-           "maua_conv_pack_filters_wino")
-    return bf, bb
-
-
-def conv_wino_supported(cin, h, w, pad):
-    return bool(lib().maua_conv_wino_supported(int(cin), int(h), int(w), int(pad)))
-
-
-def conv3x3_wino(x, bank, bias, cout, pad, relu, out=None, out_relu_mask=None, accumulate=False):
-    n, cin, h, w = x.shape
-    if out is None:
-        out = torch.empty(n, cout, h + 2 * pad - 2, w + 2 * pad - 2, device=x.device, dtype=torch.float32)
-    _check(lib().maua_conv3x3_wino(_ptr(_f32(x, "x")), bank.data_ptr(), _ptr(bias), _ptr(out_relu_mask), _ptr(out), n, cin, h, w,
-                                   cout, pad, int(relu), int(accumulate), _stream()), "maua_conv3x3_wino")
     return out
 
 

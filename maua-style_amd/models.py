@@ -60,16 +60,6 @@ def _image_kernel_enabled():
     return os.environ.get("MAUA_CONV_IMAGE", "1") == "1"
 
 
-def _wino_min_channels():
-    """MAUA_CONV_WINO=<cin>: 3x3 layers that consume at least that many channels (a multiple of 16) run conv_wino.hip - Winograd
-    F(2x2, 3x3) on the fp16x3 split - wherever a plain launch is asked for (the pool- and Gram-fused launches stay on conv_x3w).  Off by
-    default: parity-green but slower than conv_x3w (profiles/probes_r03.md section 1); the switch exists so that the whole-network and
-    trajectory tests can be run on it."""
-    import os
-    v = os.environ.get("MAUA_CONV_WINO", "")
-    return int(v) if v.isdigit() and int(v) > 0 else None
-
-
 _X3W_MIN_PIXELS = None
 
 
@@ -92,10 +82,6 @@ def conv3x3_mfma(x, mod, backward, out=None, out_relu_mask=None, relu=False, acc
     else:
         cout, p, bias = mod.out_channels, pad, mod.bias_device()
     consumed = mod.out_channels if backward else mod.in_channels
-    wino = _wino_min_channels()
-    if wino is not None and _x3_enabled() and consumed >= wino and hip.conv_wino_supported(consumed, x.shape[2], x.shape[3], p):
-        bf, bb = mod.banks_wino()
-        return hip.conv3x3_wino(x, bb if backward else bf, bias, cout, p, relu, out=out, out_relu_mask=out_relu_mask, accumulate=accumulate)
     if _x3_enabled() and _x3w_enabled() and x.shape[2] * x.shape[3] >= _x3w_min_pixels() and \
             hip.conv_x3w_supported(consumed, x.shape[2], x.shape[3], p):
         bf, bb, wsc = mod.banks3w()
@@ -262,14 +248,6 @@ class Conv2d(nn.Conv2d):
             self._banks3w = hip.conv_pack_filters_x3w(self.weight.detach().contiguous())
             self._bank3w_key = key
         return self._banks3w
-
-    def banks_wino(self):
-        """Winograd-domain banks of conv_wino.hip (forward, backward-data): G g G^T in fp64, fp16 pairs in MFMA lane order."""
-        key = (self.weight.data_ptr(), self.weight._version, self.weight.device)
-        if getattr(self, "_bankw_key", None) != key:
-            self._banksw = hip.conv_pack_filters_wino(self.weight.detach().contiguous())
-            self._bankw_key = key
-        return self._banksw
 
     def banks_kxk(self):
         """fp16x2 pre-split, pre-scaled banks (forward, backward-data, filter scale) of the k x k fp16x3 kernel."""

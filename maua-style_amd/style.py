@@ -371,7 +371,8 @@ def vid_img(args):
 
         optim.set_model_args(args, current_size)
         net, losses = models.load_model(args)
-        dist.broadcast_network(net, src=0)
+        # (first scale: start-up, short timeout; later scales: a rank that skipped finished frames waits here for hours)
+        dist.broadcast_network(net, src=0, mid_job=size_n > 0)
         batch = frames_per_batch(current_size, args)
 
         for pass_n in range(passes):

@@ -267,3 +267,29 @@ def test_bench_refuses_more_ranks_than_devices(tmp_path):
                          text=True, env=env, timeout=300, cwd=str(tmp_path))
     if torch.cuda.device_count() < 2:
         assert out.returncode == 2 and "device(s) visible" in out.stderr and not out.stdout.strip()
+
+
+def test_cpu_baseline_builds_the_model_it_is_asked_for(monkeypatch):
+    """bench.cpu_baseline(model="nin") must time the NIN + covariance oracle (a local named `model` used to shadow
+    the argument, so `--model nin` reported the VGG-19 oracle's time as its CPU baseline)."""
+    import importlib
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.syspath_prepend(repo)
+    bench = importlib.import_module("bench")
+    import oracle
+    seen = {}
+    real = oracle.build_spec
+
+    def spy(cfg):
+        seen["model_file"], seen["cov"], seen["style"] = cfg.model_file, cfg.use_covariance, cfg.style_layers
+        return real(cfg)
+    monkeypatch.setattr(oracle, "build_spec", spy)
+    threads = torch.get_num_threads()
+    try:
+        r = bench.cpu_baseline(96, "lbfgs", iters=1, repeats=1, model="nin")
+    finally:
+        torch.set_num_threads(threads)
+    assert seen == {"model_file": "nin", "cov": True, "style": "relu1,relu3,relu5,relu7,relu9,relu11"}
+    assert r["model"] == "nin" and r["kind"] == "port" and r["value"] > 0
+    assert r["cpu_model"] is None or "nin" not in str(r["cpu_model"]).lower()

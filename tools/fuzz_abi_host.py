@@ -47,7 +47,7 @@ def main():
                  L.maua_conv_x6_bank_bytes(cout, cin), L.maua_conv_x3_bank_bytes(cout, cin), L.maua_conv_x3w_bank_bytes(cout, cin),
                  L.maua_conv_kxk_x3_bank_bytes(cout, cin, k), L.maua_gram_workspace_bytes(cin, h * w if abs(h * w) < 1 << 40 else 1),
                  L.maua_reduce_workspace_bytes(h * w), L.maua_lbfgs_state_bytes(h * w, rng.choice([1, 5, 100, 254, 255, 0, -1])),
-                 L.maua_channel_stats_workspace_bytes(h, w), L.maua_loss_ledger_bytes(n, cin), L.maua_conv_wino_bank_bytes(cout, cin),
+                 L.maua_channel_stats_workspace_bytes(h, w), L.maua_loss_ledger_bytes(n, cin),
                  L.maua_conv_image_bank_bytes(cout, cin)]
         assert all(s >= 0 for s in sizes)
         if min(n, cin, cout, h, w) <= 0:
@@ -56,7 +56,6 @@ def main():
             assert sizes[6] == 0 and sizes[7] == 0 and sizes[8] == 0 and sizes[15] == 0, (cin, cout, sizes)
         L.maua_pool_out_size(h, rng.choice([2, 3, 0, -1]), rng.choice([2, 1, 0]), rng.randint(0, 1))
         L.maua_conv_x3w_supported(cin, h, w, pad)
-        L.maua_conv_wino_supported(cin, h, w, pad)
         assert L.maua_conv_x3w_split(n, cin, h, w, cout, pad) >= 0 and L.maua_conv_x3w_dmat_bank_bytes(cin) >= 0
         L.maua_conv_pack_dmat_x3w(None, cin, None, None, None)
         L.maua_conv_pack_filters_image(None, None, None, cout, cin, None)
@@ -67,7 +66,6 @@ def main():
         ws_bytes = rng.choice([0, 1 << 10, 1 << 30])
         ptr = P if no_gpu else None
         rcs = [
-            L.maua_conv3x3_wino(ptr, ptr, ptr, None, ptr, n, cin, h, w, cout, pad, 1, 0, None),
             L.maua_conv3x3_x3w(ptr, ptr, 1.0, ptr, None, ptr, n, cin, h, w, cout, pad, 1, 0, ptr, ws_bytes, None),
             L.maua_conv3x3_x3w_relu_pool(ptr, ptr, 1.0, ptr, ptr, ptr, n, cin, h, w, cout, pad, ptr, ws_bytes, None),
             L.maua_conv3x3_x3w_gram(ptr, ptr, 1.0, ptr, ptr, ptr, ptr, n, cin, h, w, cout, pad, 0, ptr, ws_bytes, None),
@@ -97,7 +95,6 @@ def main():
             L.maua_gram_row_means(ptr, ptr, cin, h * w if abs(h * w) < 1 << 40 else 1, ptr, ws_bytes, None),
             L.maua_conv_pack_dmat_x3w_batch(rng.choice([0, -1, 5, 1000]), None, None, None, None, None),
             L.maua_gram_finish_mse_batch(rng.choice([0, -1, 9, 1000]), None, None, None, None, None, None, None, None, None, None, None, None, None),
-            L.maua_conv_pack_filters_wino(None, ptr, ptr, cout, cin, None),
             L.maua_gram_mse_ledger_supported(cin),
             L.maua_tv_fwd_bwd(ptr, ptr, n, cin, h, w, 1.0, 0, ptr, ptr, ws_bytes, None),
             L.maua_resize_bilinear(ptr, ptr, n, h, w, cout, cin, 0.5, 0.5, None),

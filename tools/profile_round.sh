@@ -25,8 +25,8 @@ python tools/run_configs.py --configs 2,3,4,5,6 --out $O/configs.json > $O/confi
 python tools/x3w_clock.py 512 512 128 > $O/clock_conv4_2.txt 2>&1
 python tools/x3w_clock.py 64 64 1024 > $O/clock_conv1_2.txt 2>&1
 python tools/bench_x3w.py 1024 5 10 > $O/x3_vs_x3w.txt 2>&1
-python tools/bench_wino.py 1024 5 10 > $O/x3w_vs_wino.txt 2>&1
-python tools/wino_clock.py 512 512 128 > $O/clock_wino_conv4_2.txt 2>&1
+python tools/wino/bench_wino.py 1024 5 10 > $O/x3w_vs_wino.txt 2>&1
+python tools/wino/wino_clock.py 512 512 128 > $O/clock_wino_conv4_2.txt 2>&1
 python bench.py --model nin --steps 200 --no_cpu_baseline > $O/bench_nin.json 2>/dev/null
 python tools/lbfgs_clock.py 196608 100 > $O/clock_lbfgs.txt 2>&1
 python tools/bench_fused_gram.py 1024 20 > $O/fused_gram.txt 2>&1

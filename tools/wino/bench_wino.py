@@ -7,9 +7,11 @@ import sys
 import torch
 import torch.nn.functional as F
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [REPO, os.path.join(REPO, "maua-style_amd")]
 import hip  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import wino  # noqa: E402
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
@@ -28,13 +30,13 @@ for name, cin, cout, div in layers:
     w = torch.randn(cout, cin, 3, 3, device="cuda", generator=g) * (2.0 / (9 * cin)) ** 0.5
     b = torch.randn(cout, device="cuda", generator=g) * 0.1
     fw, bw, wsw = hip.conv_pack_filters_x3w(w)
-    fn_, bn_ = hip.conv_pack_filters_wino(w)
+    fn_, bn_ = wino.conv_pack_filters_wino(w)
     wsz = max(hip.conv_x3w_workspace_bytes(1, cin, H, H, cout, 1), 256)
     wsp = torch.empty(wsz, dtype=torch.uint8, device="cuda")
     yw = torch.empty(1, cout, H, H, device="cuda")
     yn = torch.empty(1, cout, H, H, device="cuda")
     runw = lambda: hip.conv3x3_x3w(x, fw, wsw, b, cout, 1, True, out=yw, workspace=wsp)
-    runn = lambda: hip.conv3x3_wino(x, fn_, b, cout, 1, True, out=yn)
+    runn = lambda: wino.conv3x3_wino(x, fn_, b, cout, 1, True, out=yn)
     runw()
     runn()
     torch.cuda.synchronize()
@@ -48,7 +50,7 @@ for name, cin, cout, div in layers:
     en = float((yn[:, :, :c, :c].cpu().double() - ref).norm() / ref.norm())
     gy = torch.randn(1, cout, H, H, device="cuda", generator=g) * (yw > 0)
     gxw = hip.conv3x3_x3w(gy, bw, wsw, None, cin, 1, False, workspace=wsp)
-    gxn = hip.conv3x3_wino(gy, bn_, None, cin, 1, False)
+    gxn = wino.conv3x3_wino(gy, bn_, None, cin, 1, False)
     torch.cuda.synchronize()
     relb = float((gxw.double() - gxn.double()).norm() / gxw.double().norm())
     times = {"x3w": [], "wino": []}

@@ -30,7 +30,8 @@
 
 #include <algorithm>
 
-#include "common.hpp"
+#include "../../maua-style_amd/csrc/common.hpp"
+#include "maua_wino.h"
 
 namespace maua {
 

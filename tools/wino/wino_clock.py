@@ -8,10 +8,12 @@ import sys
 
 import torch
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [REPO, os.path.join(REPO, "maua-style_amd")]
 os.environ.setdefault("MAUA_HIP_LIB", os.path.join(REPO, "tools", "_build", "libmaua_wnstamp.so"))
 import hip  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import wino  # noqa: E402
 
 cin, cout, H = (int(v) for v in sys.argv[1:4])
 L = hip.lib()
@@ -19,7 +21,7 @@ L.maua_wn_set_stamp_buffer.argtypes = [ctypes.c_void_p]
 L.maua_wn_set_stamp_buffer.restype = None
 x = torch.relu(torch.randn(1, cin, H, H, device="cuda"))
 w = torch.randn(cout, cin, 3, 3, device="cuda") * (2.0 / (9 * cin)) ** 0.5
-fw, bw = hip.conv_pack_filters_wino(w)
+fw, bw = wino.conv_pack_filters_wino(w)
 y = torch.empty(1, cout, H, H, device="cuda")
 tiles = ((H + 31) // 32) * ((H + 7) // 8)
 ncot = (cout + 63) // 64
@@ -27,12 +29,12 @@ nch = cin // 16
 blocks = ncot * tiles if ncot % 8 == 0 else (8 * ((tiles + 8 // ncot - 1) // (8 // ncot)) if ncot in (1, 2, 4) else ncot * tiles)
 stamps = torch.zeros(blocks * 8 * 64 * 8, dtype=torch.float32, device="cuda")
 for _ in range(20):  # warm: clocks settle under load
-    hip.conv3x3_wino(x, fw, None, cout, 1, True, out=y)
+    wino.conv3x3_wino(x, fw, None, cout, 1, True, out=y)
 torch.cuda.synchronize()
 L.maua_wn_set_stamp_buffer(stamps.data_ptr())
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-hip.conv3x3_wino(x, fw, None, cout, 1, True, out=y)
+wino.conv3x3_wino(x, fw, None, cout, 1, True, out=y)
 e1.record()
 torch.cuda.synchronize()
 L.maua_wn_set_stamp_buffer(None)
