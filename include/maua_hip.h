@@ -174,6 +174,22 @@ int maua_conv3x3_x3w_unpool(const float* pooled_x, const unsigned char* codes, i
                             const float* out_relu_mask, const void* dmat_bank, const float* dmat_inv_scale, float* y, int n, int cin,
                             int h, int w, int cout, int pad, void* workspace, size_t workspace_bytes, maua_stream_t stream);
 
+/* The same fp16x3 arithmetic on the third kernel structure (conv_x3q.hip, round 4): K chunks of 32 input channels on
+ * v_mfma_f32_16x16x32_f16 (one k-step = one tap x 32 channels), one workgroup of four waves per CU with all nine taps of a
+ * chunk resident in LDS.  Same layer arithmetic as maua_conv3x3_x3w - `nn.Conv2d(cin, c, 3)` + `nn.ReLU(inplace=True)`,
+ * models.py:129-130, and its backward-data pass - same arguments and flags, same split-K workspace protocol; needs
+ * cin % 32 == 0 and planes of at most 2^24 pixels (maua_conv_x3q_supported); bank layout
+ * [chunk32][cout tile][tap][part][octet 4][co][8 ch], same power-of-two filter scale as the other fp16x3 banks. */
+size_t maua_conv_x3q_bank_bytes(int cout_produced, int cin_consumed);
+int maua_conv_pack_filters_x3q(const float* w_oihw, void* bank_fwd, void* bank_bwd, int cout, int cin, float w_scale,
+                               maua_stream_t stream);
+int maua_conv_x3q_supported(int cin, int h, int w, int pad);
+size_t maua_conv_x3q_workspace_bytes(int n, int cin, int h, int w, int cout, int pad);
+int maua_conv_x3q_split(int n, int cin, int h, int w, int cout, int pad);
+int maua_conv3x3_x3q(const float* x, const void* bank, float w_scale, const float* bias, const float* out_relu_mask, float* y,
+                     int n, int cin, int h, int w, int cout, int pad, int relu, int accumulate, void* workspace,
+                     size_t workspace_bytes, maua_stream_t stream);
+
 /* ---- KS x KS stride-1 convolution in the same fp16x3 arithmetic (conv_kxk_x3.hip; KS = 5: NIN's conv2, models.py:86).
  *      Banks as for maua_conv_pack_filters_x3 with KS*KS taps; backward-data of a pad-p conv: bank_bwd, cin/cout exchanged,
  *      pad KS-1-p.  workspace (nullable) as for maua_conv3x3_x6: lets small output grids split the channel loop. ---- */

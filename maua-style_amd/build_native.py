@@ -20,6 +20,16 @@ def _sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def _file_flags(src):
+    """Extra compiler flags a source asks for in a `// hipcc-flags: ...` line among its first 60 lines (conv_x3q.hip: no SLP
+    vectorisation - packed fp32 instructions beside MFMAs cost more issue time than the two scalar ones they replace)."""
+    with open(src) as f:
+        for _, line in zip(range(60), f):
+            if line.startswith("// hipcc-flags:"):
+                return line.split(":", 1)[1].split()
+    return []
+
+
 def _digest():
     h = hashlib.sha256()
     inc = os.path.join(os.path.dirname(HERE), "include", "maua_hip.h")
@@ -56,7 +66,7 @@ def build(force=False, verbose=False, sanitize=False):
     for src in _sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj] + _file_flags(src)
         if sanitize:
             cmd[2:3] = SAN_FLAGS
         if verbose:

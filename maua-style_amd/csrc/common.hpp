@@ -120,6 +120,8 @@ int conv_splitk_finish_pool(const ConvArgs& a, int n, int ksplit, hipStream_t st
 int conv_x3_launch(const ConvArgs& a, int n, float w_scale, hipStream_t stream);  // conv_x3.hip  // y = act(bias + sum of a.ws partials) ...
 int conv_x3w_launch(const ConvArgs& a, int n, float w_scale, hipStream_t stream);  // conv_x3w.hip (16-channel chunks, a.Cin % 16 == 0)
 bool conv_x3w_supports(const ConvArgs& a);
+int conv_x3q_launch(const ConvArgs& a, int n, float w_scale, hipStream_t stream);  // conv_x3q.hip (32-channel chunks on 16x16x32, a.Cin % 32 == 0)
+bool conv_x3q_supports(const ConvArgs& a);
 int conv1x1_x3_launch(const ConvArgs& a, const float* xshift, int n, hipStream_t stream);  // conv1x1_x3.hip (a.w = [Cout][Cin], a.H*a.W pixels)
 size_t conv1x1_x3_workspace(int n, int cin, int64_t hw, int cout);
 int conv_mfma2_choose_split(const ConvArgs& a, int ks, int n);                     // 1 = no split  // 3x3, stride 1, Cout <= 4 (conv_direct.hip)

@@ -79,6 +79,12 @@ SIGNATURES = {
     "maua_set_split_batch_hint": (None, [c_i]),
     "maua_get_split_batch_hint": (c_i, []),
     "maua_conv_x3w_split": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    "maua_conv_x3q_bank_bytes": (c_sz, [c_i, c_i]),
+    "maua_conv_pack_filters_x3q": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_p]),
+    "maua_conv_x3q_supported": (c_i, [c_i, c_i, c_i, c_i]),
+    "maua_conv_x3q_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    "maua_conv_x3q_split": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    "maua_conv3x3_x3q": (c_i, [c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "maua_conv3x3_x3w_relu_pool": (c_i, [c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "maua_conv_x3w_dmat_bank_bytes": (c_sz, [c_i]),
     "maua_conv_pack_dmat_x3w": (c_i, [c_p, c_i, c_p, c_p, c_p]),
@@ -297,6 +303,43 @@ def conv3x3_x3w(x, bank, w_scale, bias, cout, pad, relu, out=None, out_relu_mask
     wp, wn = _ws_args(workspace, conv_x3w_workspace_bytes(n, cin, h, w, cout, pad) if workspace is None else 0, x.device)
     _check(lib().maua_conv3x3_x3w(_ptr(_f32(x, "x")), bank.data_ptr(), float(w_scale), _ptr(bias), _ptr(out_relu_mask), _ptr(out), n,
                                   cin, h, w, cout, pad, int(relu), int(accumulate), wp, wn, _stream()), "maua_conv3x3_x3w")
+    return out
+
+
+def conv_pack_filters_x3q(w):
+    """OIHW 3x3 weights -> (forward bank, backward-data bank, w_scale) for conv_x3q.hip (32-channel chunks; same split and
+    the same power-of-two filter scale as conv_pack_filters_x3)."""
+    import math
+    cout, cin = w.shape[:2]
+    m = float(w.abs().max())
+    w_scale = 2.0 ** (5 - math.floor(math.log2(m))) if m > 0 and math.isfinite(m) else 1.0
+    wc = _f32(w, "w").contiguous()
+    bf = torch.empty(lib().maua_conv_x3q_bank_bytes(cout, cin), dtype=torch.uint8, device=w.device)
+    bb = torch.empty(lib().maua_conv_x3q_bank_bytes(cin, cout), dtype=torch.uint8, device=w.device)
+    _check(lib().maua_conv_pack_filters_x3q(_ptr(wc), bf.data_ptr(), bb.data_ptr(), cout, cin, w_scale, _stream()),
+           "maua_conv_pack_filters_x3q")
+    return bf, bb, w_scale
+
+
+def conv_x3q_supported(cin, h, w, pad):
+    return bool(lib().maua_conv_x3q_supported(int(cin), int(h), int(w), int(pad)))
+
+
+def conv_x3q_workspace_bytes(n, cin, h, w, cout, pad):
+    return lib().maua_conv_x3q_workspace_bytes(n, cin, h, w, cout, pad)
+
+
+def conv_x3q_split(n, cin, h, w, cout, pad):
+    return int(lib().maua_conv_x3q_split(int(n), int(cin), int(h), int(w), int(cout), int(pad)))
+
+
+def conv3x3_x3q(x, bank, w_scale, bias, cout, pad, relu, out=None, out_relu_mask=None, accumulate=False, workspace=None):
+    n, cin, h, w = x.shape
+    if out is None:
+        out = torch.empty(n, cout, h + 2 * pad - 2, w + 2 * pad - 2, device=x.device, dtype=torch.float32)
+    wp, wn = _ws_args(workspace, conv_x3q_workspace_bytes(n, cin, h, w, cout, pad) if workspace is None else 0, x.device)
+    _check(lib().maua_conv3x3_x3q(_ptr(_f32(x, "x")), bank.data_ptr(), float(w_scale), _ptr(bias), _ptr(out_relu_mask), _ptr(out), n,
+                                  cin, h, w, cout, pad, int(relu), int(accumulate), wp, wn, _stream()), "maua_conv3x3_x3q")
     return out
 
 
