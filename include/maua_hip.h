@@ -189,6 +189,17 @@ int maua_conv_x3q_split(int n, int cin, int h, int w, int cout, int pad);
 int maua_conv3x3_x3q(const float* x, const void* bank, float w_scale, const float* bias, const float* out_relu_mask, float* y,
                      int n, int cin, int h, int w, int cout, int pad, int relu, int accumulate, void* workspace,
                      size_t workspace_bytes, maua_stream_t stream);
+/* ... with ReLU and the 2x2 / 2 max pool behind the layer in the epilogue (`nn.MaxPool2d(2, 2)`, models.py:120): arguments, outputs
+ * (pooled map + decision bytes in the octet-interleaved layout) and split-K behaviour of maua_conv3x3_x3w_relu_pool. */
+int maua_conv3x3_x3q_relu_pool(const float* x, const void* bank, float w_scale, const float* bias, float* pooled, unsigned char* codes,
+                               int n, int cin, int h, int w, int cout, int pad, void* workspace, size_t workspace_bytes,
+                               maua_stream_t stream);
+/* ... as the backward-data pass that stages its input straight from the POOLED map's gradient and the pool's decision bytes
+ * (maua_conv3x3_x3w_unpool without the Gram term: the deep layers it serves - conv3_4, conv4_4 - carry no style loss on their input).
+ * Bit-identical to maua_pool2x2_bwd_codes followed by maua_conv3x3_x3q. */
+int maua_conv3x3_x3q_unpool(const float* pooled_x, const unsigned char* codes, int honour_relu_bit, const void* bank, float w_scale,
+                            const float* out_relu_mask, float* y, int n, int cin, int h, int w, int cout, int pad, void* workspace,
+                            size_t workspace_bytes, maua_stream_t stream);
 
 /* ---- KS x KS stride-1 convolution in the same fp16x3 arithmetic (conv_kxk_x3.hip; KS = 5: NIN's conv2, models.py:86).
  *      Banks as for maua_conv_pack_filters_x3 with KS*KS taps; backward-data of a pad-p conv: bank_bwd, cin/cout exchanged,

@@ -43,6 +43,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 constexpr int XQ_COT = 64;
 constexpr int XQ_ROWS = 16, XQ_PR = 18, XQ_PC = 34;
@@ -132,7 +133,10 @@ __global__ void pack_x3q_kernel(const float* __restrict__ w, unsigned short* __r
     } while (0)
 #endif
 
-template <bool ACC, bool OM>
+// POOL: the epilogue applies ReLU and the 2x2 / 2 max pool that follows (conv_x3w.hip): `y` is the pooled map, p.pool_codes its decision
+// bytes.  UNPOOL: `x` is the POOLED map of a 2x2 / 2 max pool and p.in_codes its decision bytes; the input the convolution sees is the
+// pool's backward pass over them (pool2x2_bwd_codes_kernel's arithmetic), rebuilt while staging - the full-size gradient never exists.
+template <bool ACC, bool OM, bool POOL = false, bool UNPOOL = false>
 __global__ void __launch_bounds__(XQ_THREADS, 2) conv_x3q_kernel(ConvArgs p, float w_inv_scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Pl = smem;                    // [part][octet][pos][16 B]
@@ -150,7 +154,11 @@ __global__ void __launch_bounds__(XQ_THREADS, 2) conv_x3q_kernel(ConvArgs p, flo
     const int ntile = gridDim.y;
     const int in_plane = p.H * p.W;
     const int64_t out_plane = (int64_t)p.OH * p.OW;
-    const float* __restrict__ xin = p.x + (int64_t)n * p.Cin * in_plane;
+    const int st_w = UNPOOL ? p.W >> 1 : p.W;                              // row pitch and plane of the array the patch is staged from
+    const int st_plane = UNPOOL ? (p.H >> 1) * (p.W >> 1) : in_plane;
+    const float* __restrict__ xin = p.x + (int64_t)n * p.Cin * st_plane;
+    const unsigned char* __restrict__ xcodes = UNPOOL ? p.in_codes + (int64_t)n * p.Cin * st_plane : nullptr;
+    const unsigned code_mask = (unsigned)p.in_code_mask;
     // XCD-aware tile order (conv_x6.hip): XCD k owns the k-th contiguous band of tiles
     const int tiles_total = p.tiles_x * ((p.OH + XQ_ROWS - 1) / XQ_ROWS);
     const int per_xcd = (tiles_total + 7) >> 3;
@@ -158,38 +166,103 @@ __global__ void __launch_bounds__(XQ_THREADS, 2) conv_x3q_kernel(ConvArgs p, flo
     if (tile >= min(((int)(blockIdx.x & 7) + 1) * per_xcd, tiles_total)) return;  // whole workgroup leaves
     const int x0 = (tile % p.tiles_x) * 32, y0 = (tile / p.tiles_x) * XQ_ROWS;
 
-    // Staging items of this thread: item k = (octet, position) number tid + 256 k.  voff = byte offset of the item's first
+    // Staging items of this thread: item k = (octet, position) number tid + 512 k.  voff = byte offset of the item's first
     // channel from the chunk's first plane; out-of-image positions and items past the end get an offset beyond the buffer's
     // range, for which a buffer load returns 0 (no selects on the values).
-    unsigned voff[XQ_NI], lds_w[XQ_NI];
+    //
+    // UNPOOL: two items per thread, and they are POOLED elements - (octet, pooled row, pooled column) number tid + 512 k of the 4 x 10 x 18
+    // pooled elements whose 2x2 windows cover the 18 x 34 patch.  The thread loads an element's eight channels and their eight decision
+    // bytes (one 8-byte load from the [octet][pooled pixel][8] layout), splits the eight values once, and writes each of the window's
+    // four corners that lies inside the patch: channel c's halves where the byte names that corner, zero elsewhere - the patch in LDS
+    // is bit for bit what staging pool2x2_bwd_codes_kernel's output would have left.
+    constexpr int NI = UNPOOL ? 2 : XQ_NI;
+    unsigned voff[NI], lds_w[NI];
+    unsigned vcode[NI], inmask[NI];  // UNPOOL: offset of the item's decision bytes; bit q = corner q (2 dy + dx) is a patch position
+    if constexpr (UNPOOL) {
+        constexpr int PR = XQ_ROWS / 2 + 2, PCW = 18;  // pooled rows / columns under the patch (any pad in 0 ... 2)
 #pragma unroll
-    for (int k = 0; k < XQ_NI; ++k) {
-        const int idx = tid + XQ_THREADS * k;
-        const int o = idx / XQ_NPOS;
-        const int pos = idx - o * XQ_NPOS;
-        const int r = pos / XQ_PC, c = pos - r * XQ_PC;
-        const int iy = y0 + r - p.pad, ix = x0 + c - p.pad;
-        const bool ok = idx < XQ_ITEMS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        voff[k] = ok ? (unsigned)(o * 8 * in_plane + iy * p.W + ix) * 4u : 0x80000000u;
-        lds_w[k] = idx < XQ_ITEMS ? (unsigned)(o * XQ_PLANE + pos * 16) : (unsigned)(XQ_NPOS_PAD - 1) * 16u;  // (items past the end: a padding slot)
+        for (int k = 0; k < NI; ++k) {
+            const int idx = tid + XQ_THREADS * k;
+            const int o = idx / (PR * PCW);
+            const int rem = idx - o * PR * PCW;
+            const int pr = rem / PCW, pc = rem - pr * PCW;
+            const int ppy = ((y0 - p.pad) >> 1) + pr, ppx = ((x0 - p.pad) >> 1) + pc;  // (arithmetic shifts: floor for the -1 / -2 of the first tiles)
+            const bool item = idx < 4 * PR * PCW;
+            const bool ok = item && ppy >= 0 && ppy < (p.H >> 1) && ppx >= 0 && ppx < st_w;
+            const int pidx = ppy * st_w + ppx;
+            voff[k] = ok ? (unsigned)(o * 8 * st_plane + pidx) * 4u : 0x80000000u;
+            vcode[k] = ok ? (unsigned)(o * st_plane + pidx) * 8u : 0x80000000u;
+            const int r0 = 2 * ppy - (y0 - p.pad), c0 = 2 * ppx - (x0 - p.pad);  // patch position of the window's first corner (-1 ... )
+            inmask[k] = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = r0 + (q >> 1), c = c0 + (q & 1);
+                if (item && r >= 0 && r < XQ_PR && c >= 0 && c < XQ_PC) inmask[k] |= 1u << q;
+            }
+            lds_w[k] = (unsigned)(o * XQ_PLANE + (r0 * XQ_PC + c0) * 16);  // (of corner 0; only ever used plus a corner's offset, for corners inside)
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int idx = tid + XQ_THREADS * k;
+            const int o = idx / XQ_NPOS;
+            const int pos = idx - o * XQ_NPOS;
+            const int r = pos / XQ_PC, c = pos - r * XQ_PC;
+            const int iy = y0 + r - p.pad, ix = x0 + c - p.pad;
+            const bool ok = idx < XQ_ITEMS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            voff[k] = ok ? (unsigned)(o * 8 * in_plane + iy * p.W + ix) * 4u : 0x80000000u;
+            lds_w[k] = idx < XQ_ITEMS ? (unsigned)(o * XQ_PLANE + pos * 16) : (unsigned)(XQ_NPOS_PAD - 1) * 16u;  // (items past the end: a padding slot)
+            vcode[k] = inmask[k] = 0;
+        }
     }
-    const unsigned range = (unsigned)in_plane * 128u;  // 32 planes from the chunk's first one: the range check sees the vector offset only
-    float rp[XQ_NI][8];   // the next chunk's patch: raw values
+    const unsigned range = (unsigned)st_plane * 128u;  // 32 planes from the chunk's first one: the range check sees the vector offset only
+    float rp[NI][8];       // the next chunk's patch: raw values, then (in place) the packed fp16 halves [0..3] high, [4..7] low
+    u32x2 cd[NI];          // UNPOOL: the items' decision bytes
+    unsigned sel2[NI][4];  // UNPOOL: the decisions two per register (16-bit lanes, channels 2 i and 2 i + 1), ReLU bit masked as asked
+    struct PatchSrc {
+        __amdgpu_buffer_rsrc_t x, codes;
+    };
     auto patch_rsrc = [&](int ch) {
         asm volatile("" : "+s"(ch));
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin + (int64_t)ch * 32 * in_plane), 0, range, 0x00020000);
+        PatchSrc r;
+        r.x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin + (int64_t)ch * 32 * st_plane), 0, range, 0x00020000);
+        r.codes = r.x;
+        if constexpr (UNPOOL)
+            r.codes = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(xcodes + (int64_t)ch * 32 * st_plane), 0, range >> 2, 0x00020000);
+        return r;
     };
-    auto load_patch_part = [&](const __amdgpu_buffer_rsrc_t rs, int c_lo, int c_hi) {
+    // channels [c_lo, c_hi) of every item (UNPOOL: the decision bytes come with channel 0)
+    auto load_patch_part = [&](const PatchSrc& rs, int c_lo, int c_hi) {
+        if constexpr (UNPOOL) {
+            if (c_lo == 0) {
+#pragma unroll
+                for (int k = 0; k < NI; ++k) cd[k] = __builtin_amdgcn_raw_buffer_load_b64(rs.codes, vcode[k], 0, 0);
+            }
+        }
 #pragma unroll
         for (int c = c_lo; c < c_hi; ++c)
 #pragma unroll
-            for (int k = 0; k < XQ_NI; ++k)
-                rp[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[k], c * in_plane * 4, 0));
+            for (int k = 0; k < NI; ++k)
+                rp[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs.x, voff[k], c * st_plane * 4, 0));
     };
     auto publish_max = [&]() {
+        if constexpr (UNPOOL) {
+            // A value counts (for the chunk's scale, and at all) where its byte names a corner that is a patch position - bit 2 of the
+            // byte, kept by code_mask = 7, names none.  What another tile's patch holds of this window is that tile's business.
+            const unsigned m2 = code_mask * 0x00010001u;
+#pragma unroll
+            for (int k = 0; k < NI; ++k)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    sel2[k][i] = __builtin_amdgcn_perm(0u, cd[k][i >> 1], (i & 1) ? 0x0c030c02u : 0x0c010c00u) & m2;
+                    const unsigned s0 = sel2[k][i] & 0xffffu, s1 = sel2[k][i] >> 16;
+                    rp[k][2 * i] = ((inmask[k] >> s0) & 1u) ? rp[k][2 * i] : 0.f;
+                    rp[k][2 * i + 1] = ((inmask[k] >> s1) & 1u) ? rp[k][2 * i + 1] : 0.f;
+                }
+        }
         float m = 0.f;
 #pragma unroll
-        for (int k = 0; k < XQ_NI; ++k)
+        for (int k = 0; k < NI; ++k)
 #pragma unroll
             for (int c = 0; c < 8; ++c) m = fmaxf(m, fabsf(rp[k][c]));
         m = wave_max_nonneg(m);
@@ -208,6 +281,7 @@ __global__ void __launch_bounds__(XQ_THREADS, 2) conv_x3q_kernel(ConvArgs p, flo
     // the packed low parts): high parts x sx rounded to nearest, low parts = the (exact) remainders rounded to nearest.  x sx is exact
     // (a power of two), so fma(x, sx, -h) is the remainder without an intermediate product: one mixed-precision FMA per half.
     auto split_item = [&](int k) {
+        if (k >= NI) return;
 #pragma unroll
         for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(rp[k][c]));  // (pinned between the fences of its step: see the fold)
         unsigned hu[4], lu[4];
@@ -228,8 +302,28 @@ __global__ void __launch_bounds__(XQ_THREADS, 2) conv_x3q_kernel(ConvArgs p, flo
         for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(rp[k][c]));
     };
     auto store_patch = [&]() {
+        if constexpr (UNPOOL) {
 #pragma unroll
-        for (int k = 0; k < XQ_NI; ++k) {
+            for (int k = 0; k < NI; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if ((inmask[k] >> q) & 1u) {
+                        const unsigned dst = lds_w[k] + (unsigned)(((q >> 1) * XQ_PC + (q & 1)) * 16);
+                        u32x4 h, l;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {  // dword i of corner q's vector: the halves of the channels whose byte names q
+                            const unsigned t = sel2[k][i] ^ ((unsigned)q * 0x00010001u);                        // 16-bit lane == 0 where it does
+                            const unsigned keep = ((t & 0xffffu) ? 0u : 0xffffu) | ((t >> 16) ? 0u : 0xffff0000u);
+                            h[i] = __builtin_bit_cast(unsigned, rp[k][i]) & keep;
+                            l[i] = __builtin_bit_cast(unsigned, rp[k][4 + i]) & keep;
+                        }
+                        *reinterpret_cast<u32x4*>(Pl + dst) = h;
+                        *reinterpret_cast<u32x4*>(Pl + 4 * XQ_PLANE + dst) = l;
+                    }
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
             const u32x4 h = {__builtin_bit_cast(unsigned, rp[k][0]), __builtin_bit_cast(unsigned, rp[k][1]), __builtin_bit_cast(unsigned, rp[k][2]),
                              __builtin_bit_cast(unsigned, rp[k][3])};
             const u32x4 l = {__builtin_bit_cast(unsigned, rp[k][4]), __builtin_bit_cast(unsigned, rp[k][5]), __builtin_bit_cast(unsigned, rp[k][6]),
@@ -349,7 +443,7 @@ __global__ void __launch_bounds__(XQ_THREADS, 2) conv_x3q_kernel(ConvArgs p, flo
         inv_cur = chunk_scale() * w_inv_scale;
         inv_next = inv_cur;
 #pragma unroll
-        for (int k = 0; k < XQ_NI; ++k) split_item(k);
+        for (int k = 0; k < NI; ++k) split_item(k);
         store_patch();
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -374,7 +468,7 @@ __global__ void __launch_bounds__(XQ_THREADS, 2) conv_x3q_kernel(ConvArgs p, flo
     for (int ch = ch_begin; ch < nchunks; ++ch) {
         const bool more = ch + 1 < nchunks;
         const bool later = ch > ch_begin;
-        const __amdgpu_buffer_rsrc_t rs = patch_rsrc(more ? ch + 1 : ch);
+        const PatchSrc rs = patch_rsrc(more ? ch + 1 : ch);
         XQ_MARK(0);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -445,7 +539,46 @@ __global__ void __launch_bounds__(XQ_THREADS, 2) conv_x3q_kernel(ConvArgs p, flo
         d_[4] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_s_memrealtime());
     }
 #endif
-    // epilogue: lane holds pixel column 16 (g & 1) + px of row y0 + 2 wr + (g >> 1); register r of group i is output channel 32 wc + 16 i + 4 oct + r
+    // epilogue: lane holds pixel column 16 (g & 1) + px of row y0 + 2 wave + (g >> 1); register r of group i is output channel 16 i + 4 oct + r
+    if constexpr (POOL) if (p.ksplit <= 1) {
+        // ReLU + the 2x2 / 2 max pool behind it: a wave's two rows and neighbouring lanes are exactly the windows, so the full-size
+        // activation never goes to memory - only the pooled map and one decision byte per window (what pool2x2_fwd_codes_kernel
+        // leaves: position of the first maximum in scan order, bit 2 = the maximum is <= 0; bytes laid out [octet of channels][pooled
+        // pixel][8 channels], Cout % 8 == 0): the lane's four consecutive channels of a group are one dword of that layout.
+        const int PW = p.OW >> 1;
+        const int64_t pplane = (int64_t)(p.OH >> 1) * PW;
+        float* __restrict__ py = p.y + (int64_t)n * p.Cout * pplane;
+        unsigned char* __restrict__ pc = p.pool_codes + (int64_t)n * p.Cout * pplane;
+        const int oy = y0 + 2 * wave;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {  // column half of the tile
+            const int oxx = x0 + 16 * h + px;
+            const bool store = (lane & 1) == 0 && oy + 1 < p.OH && oxx + 1 < p.OW;  // (even extents: a window is inside or outside)
+            const int64_t ppix = (int64_t)(oy >> 1) * PW + (oxx >> 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int cq = co0 + 16 * i + 4 * oct;
+                unsigned pk = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float a = master[i][h][r], c = master[i][2 + h][r];
+                    a = a > 0.f ? a : 0.f;
+                    c = c > 0.f ? c : 0.f;
+                    const float b = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x101, 0xf, 0xf, false));  // row_shl:1
+                    const float d = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c), 0x101, 0xf, 0xf, false));
+                    float m = a;
+                    unsigned arg = 0;
+                    if (b > m) { m = b; arg = 1; }
+                    if (c > m) { m = c; arg = 2; }
+                    if (d > m) { m = d; arg = 3; }
+                    pk |= (arg | (m > 0.f ? 0u : 4u)) << (8 * r);
+                    if (store && cq < p.Cout) py[(int64_t)(cq + r) * pplane + ppix] = m;
+                }
+                if (store && cq < p.Cout) *reinterpret_cast<unsigned*>(pc + ((int64_t)(cq >> 3) * pplane + ppix) * 8 + (cq & 7)) = pk;
+            }
+        }
+        return;
+    }
     float* __restrict__ yout = p.y + (int64_t)n * p.Cout * out_plane;
     const float* __restrict__ om = p.omask ? p.omask + (int64_t)n * p.Cout * out_plane : nullptr;
     const bool full = co0 + XQ_COT <= p.Cout;
@@ -468,31 +601,34 @@ __global__ void __launch_bounds__(XQ_THREADS, 2) conv_x3q_kernel(ConvArgs p, flo
         XQ_FENCE();  // (one pixel group at a time: hoisting the next group's loads costs registers the wave does not have)
         if (!pvalid) continue;
         const int cl = co0 + 4 * oct;  // the lane's first output channel
-        const int64_t lane_off = (int64_t)cl * out_plane + opix;
+        int64_t lane_off = (int64_t)cl * out_plane + opix;
+        // (an address the compiler cannot form before this point: the previous contents and the mask are loop-invariant loads of
+        //  `restrict` arrays, and hoisted above the K loop they would cost 32 registers the wave does not have)
+        if constexpr (ACC || OM) asm volatile("" : "+v"(lane_off));
         float* __restrict__ yl = yout + lane_off;
         const float* __restrict__ oml = OM ? om + lane_off : nullptr;
-        float prev[16], msk[16];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {  // (ACC / OM: one channel group at a time, for the same reason)
+            if constexpr (ACC || OM) XQ_FENCE();
+            float prev[4], msk[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int cr = i * 16 + r;
                 const bool cv = full || cl + cr < p.Cout;
-                prev[i * 4 + r] = 0.f;
-                msk[i * 4 + r] = 1.f;
-                if constexpr (ACC) if (cv) prev[i * 4 + r] = yl[(int64_t)cr * out_plane];
-                if constexpr (OM) if (cv) msk[i * 4 + r] = oml[(int64_t)cr * out_plane];
+                prev[r] = 0.f;
+                msk[r] = 1.f;
+                if constexpr (ACC) if (cv) prev[r] = yl[(int64_t)cr * out_plane];
+                if constexpr (OM) if (cv) msk[r] = oml[(int64_t)cr * out_plane];
             }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int cr = i * 16 + r;
-                float v = master[i][g][r] + prev[i * 4 + r];
+                float v = master[i][g][r] + prev[r];
                 if (p.relu) v = v > 0.f ? v : 0.f;
-                v = msk[i * 4 + r] > 0.f ? v : 0.f;
+                v = msk[r] > 0.f ? v : 0.f;
                 if (full || cl + cr < p.Cout) yl[(int64_t)cr * out_plane] = v;
             }
+        }
     }
 }
 
@@ -531,14 +667,17 @@ static float* g_xq_stamp = nullptr;
 extern "C" void maua_xq_set_stamp_buffer(float* buf) { g_xq_stamp = buf; }
 #endif
 
-template <bool ACC, bool OM>
-static int xq_allow_lds() {  // once per instantiation: the kernel's dynamic LDS is above the default limit
-    static const hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3q_kernel<ACC, OM>), hipFuncAttributeMaxDynamicSharedMemorySize, XQ_LDS_BYTES);
+template <bool ACC, bool OM, bool POOL, bool UNPOOL>
+static int xq_launch_one(const ConvArgs& p, dim3 grid, float w_inv, hipStream_t stream) {
+    // once per instantiation: the kernel's 150 KiB of dynamic LDS are above the default limit
+    static const hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3q_kernel<ACC, OM, POOL, UNPOOL>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, XQ_LDS_BYTES);
     if (rc != hipSuccess) {
         set_error("conv_x3q: hipFuncSetAttribute: %s", hipGetErrorString(rc));
         return (int)rc;
     }
-    return MAUA_OK;
+    hipLaunchKernelGGL((conv_x3q_kernel<ACC, OM, POOL, UNPOOL>), grid, dim3(XQ_THREADS), XQ_LDS_BYTES, stream, p, w_inv);
+    return check_launch("conv_x3q_kernel");
 }
 
 int conv_x3q_launch(const ConvArgs& a, int n, float w_scale, hipStream_t stream) {
@@ -555,20 +694,16 @@ int conv_x3q_launch(const ConvArgs& a, int n, float w_scale, hipStream_t stream)
     const bool acc = ks == 1 && a.accumulate != 0, om = ks == 1 && a.omask != nullptr;
     const float w_inv = 1.f / w_scale;
     int rc;
-#define XQ_LAUNCH(...)                                                                             \
-    do {                                                                                           \
-        rc = xq_allow_lds<__VA_ARGS__>();                                                          \
-        if (rc) return rc;                                                                         \
-        hipLaunchKernelGGL((conv_x3q_kernel<__VA_ARGS__>), grid, dim3(XQ_THREADS), XQ_LDS_BYTES, stream, p, w_inv); \
-    } while (0)
-    if (acc && om) XQ_LAUNCH(true, true);
-    else if (acc) XQ_LAUNCH(true, false);
-    else if (om) XQ_LAUNCH(false, true);
-    else XQ_LAUNCH(false, false);
-#undef XQ_LAUNCH
-    rc = check_launch("conv_x3q_kernel");
+    if (a.pool_codes && ks == 1) rc = xq_launch_one<false, false, true, false>(p, grid, w_inv, stream);
+    else if (a.in_codes && om) rc = xq_launch_one<false, true, false, true>(p, grid, w_inv, stream);
+    else if (a.in_codes) rc = xq_launch_one<false, false, false, true>(p, grid, w_inv, stream);
+    else if (acc && om) rc = xq_launch_one<true, true, false, false>(p, grid, w_inv, stream);
+    else if (acc) rc = xq_launch_one<true, false, false, false>(p, grid, w_inv, stream);
+    else if (om) rc = xq_launch_one<false, true, false, false>(p, grid, w_inv, stream);
+    else rc = xq_launch_one<false, false, false, false>(p, grid, w_inv, stream);
     if (rc || ks == 1) return rc;
-    return conv_splitk_finish(a, n, ks, stream);
+    // (a split channel loop leaves partial sums: the ReLU + pool of a pooling launch then happen in the pass that adds them)
+    return a.pool_codes ? conv_splitk_finish_pool(a, n, ks, stream) : conv_splitk_finish(a, n, ks, stream);
 }
 
 }  // namespace maua
@@ -633,9 +768,9 @@ int maua_conv_x3q_split(int n, int cin, int h, int w, int cout, int pad) {
     return x3q_choose_split(a, n);
 }
 
-int maua_conv3x3_x3q(const float* x, const void* bank, float w_scale, const float* bias, const float* out_relu_mask, float* y,
-                     int n, int cin, int h, int w, int cout, int pad, int relu, int accumulate, void* workspace,
-                     size_t workspace_bytes, maua_stream_t stream) {
+static int conv3x3_x3q_entry(const float* x, const void* bank, float w_scale, const float* bias, const float* out_relu_mask, float* y, int n,
+                             int cin, int h, int w, int cout, int pad, int relu, int accumulate, void* workspace, size_t workspace_bytes,
+                             maua_stream_t stream, const unsigned char* in_codes = nullptr, int in_code_mask = 0) {
     MAUA_REQUIRE(x && bank && y && w_scale > 0.f, MAUA_E_INVAL, "conv3x3_x3q: bad args");
     MAUA_REQUIRE(conv_dims_ok(n, cin, h, w, cout, pad) && pad <= 2, MAUA_E_INVAL, "conv3x3_x3q: bad dims");
     MAUA_REQUIRE(h + 2 * pad >= 3 && w + 2 * pad >= 3, MAUA_E_UNSUPPORTED, "conv3x3_x3q: input smaller than the filter");
@@ -655,8 +790,54 @@ int maua_conv3x3_x3q(const float* x, const void* bank, float w_scale, const floa
     a.relu = relu;
     a.accumulate = accumulate;
     MAUA_REQUIRE(conv_x3q_supports(a), MAUA_E_UNSUPPORTED, "conv3x3_x3q: needs cin %% 32 == 0 and a plane of at most 2^24 pixels");
+    if (in_codes) {
+        MAUA_REQUIRE(h % 2 == 0 && w % 2 == 0 && !accumulate, MAUA_E_UNSUPPORTED, "conv3x3_x3q_unpool: needs an even input plane, no accumulation");
+        a.in_codes = in_codes;
+        a.in_code_mask = in_code_mask;
+    }
     a.ws = (workspace && workspace_bytes >= maua_conv_x3q_workspace_bytes(n, cin, h, w, cout, pad)) ? (float*)workspace : nullptr;
     return conv_x3q_launch(a, n, w_scale, (hipStream_t)stream);
+}
+
+int maua_conv3x3_x3q(const float* x, const void* bank, float w_scale, const float* bias, const float* out_relu_mask, float* y,
+                     int n, int cin, int h, int w, int cout, int pad, int relu, int accumulate, void* workspace,
+                     size_t workspace_bytes, maua_stream_t stream) {
+    return conv3x3_x3q_entry(x, bank, w_scale, bias, out_relu_mask, y, n, cin, h, w, cout, pad, relu, accumulate, workspace, workspace_bytes,
+                             stream);
+}
+
+int maua_conv3x3_x3q_relu_pool(const float* x, const void* bank, float w_scale, const float* bias, float* pooled, unsigned char* codes,
+                               int n, int cin, int h, int w, int cout, int pad, void* workspace, size_t workspace_bytes,
+                               maua_stream_t stream) {
+    MAUA_REQUIRE(x && bank && pooled && codes && w_scale > 0.f, MAUA_E_INVAL, "conv3x3_x3q_relu_pool: bad args");
+    MAUA_REQUIRE(conv_dims_ok(n, cin, h, w, cout, pad) && pad <= 2, MAUA_E_INVAL, "conv3x3_x3q_relu_pool: bad dims");
+    ConvArgs a{};
+    a.x = x;
+    a.w6 = bank;
+    a.bias = bias;
+    a.y = pooled;
+    a.pool_codes = codes;
+    a.Cin = cin;
+    a.H = h;
+    a.W = w;
+    a.Cout = cout;
+    a.OH = h + 2 * pad - 2;
+    a.OW = w + 2 * pad - 2;
+    a.pad = pad;
+    a.relu = 1;
+    MAUA_REQUIRE(a.OH >= 2 && a.OW >= 2 && a.OH % 2 == 0 && a.OW % 2 == 0 && cout % 8 == 0 && conv_x3q_supports(a), MAUA_E_UNSUPPORTED,
+                 "conv3x3_x3q_relu_pool: needs an even output plane, cin %% 32 == 0, cout %% 8 == 0");
+    // without a workspace: one pass over the channels, the epilogue holds complete sums and pools them itself
+    a.ws = (workspace && workspace_bytes >= maua_conv_x3q_workspace_bytes(n, cin, h, w, cout, pad)) ? (float*)workspace : nullptr;
+    return conv_x3q_launch(a, n, w_scale, (hipStream_t)stream);
+}
+
+int maua_conv3x3_x3q_unpool(const float* pooled_x, const unsigned char* codes, int honour_relu_bit, const void* bank, float w_scale,
+                            const float* out_relu_mask, float* y, int n, int cin, int h, int w, int cout, int pad, void* workspace,
+                            size_t workspace_bytes, maua_stream_t stream) {
+    MAUA_REQUIRE(codes, MAUA_E_INVAL, "conv3x3_x3q_unpool: null decision bytes");
+    return conv3x3_x3q_entry(pooled_x, bank, w_scale, nullptr, out_relu_mask, y, n, cin, h, w, cout, pad, 0, 0, workspace, workspace_bytes, stream,
+                             codes, honour_relu_bit ? 7 : 3);
 }
 
 }  // extern "C"

@@ -85,6 +85,8 @@ SIGNATURES = {
     "maua_conv_x3q_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "maua_conv_x3q_split": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "maua_conv3x3_x3q": (c_i, [c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
+    "maua_conv3x3_x3q_relu_pool": (c_i, [c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
+    "maua_conv3x3_x3q_unpool": (c_i, [c_p, c_p, c_i, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "maua_conv3x3_x3w_relu_pool": (c_i, [c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "maua_conv_x3w_dmat_bank_bytes": (c_sz, [c_i]),
     "maua_conv_pack_dmat_x3w": (c_i, [c_p, c_i, c_p, c_p, c_p]),
@@ -340,6 +342,30 @@ def conv3x3_x3q(x, bank, w_scale, bias, cout, pad, relu, out=None, out_relu_mask
     wp, wn = _ws_args(workspace, conv_x3q_workspace_bytes(n, cin, h, w, cout, pad) if workspace is None else 0, x.device)
     _check(lib().maua_conv3x3_x3q(_ptr(_f32(x, "x")), bank.data_ptr(), float(w_scale), _ptr(bias), _ptr(out_relu_mask), _ptr(out), n,
                                   cin, h, w, cout, pad, int(relu), int(accumulate), wp, wn, _stream()), "maua_conv3x3_x3q")
+    return out
+
+
+def conv3x3_x3q_relu_pool(x, bank, w_scale, bias, cout, pad, pooled, codes, workspace=None):
+    """conv + bias + ReLU + 2x2 / 2 max pool on conv_x3q.hip: writes `pooled` and the pool's decision bytes only (conv3x3_x3w_relu_pool's
+    contract)."""
+    n, cin, h, w = x.shape
+    wp, wn = (workspace.data_ptr(), workspace.numel() * workspace.element_size()) if workspace is not None else (None, 0)
+    _check(lib().maua_conv3x3_x3q_relu_pool(_ptr(_f32(x, "x")), bank.data_ptr(), float(w_scale), _ptr(bias), _ptr(pooled),
+                                            codes.data_ptr(), n, cin, h, w, cout, pad, wp, wn, _stream()), "maua_conv3x3_x3q_relu_pool")
+    return pooled
+
+
+def conv3x3_x3q_unpool(pooled_x, codes, honour_relu_bit, bank, w_scale, cout, pad, out=None, out_relu_mask=None, workspace=None):
+    """Backward-data pass on conv_x3q.hip staged straight from the pooled map's gradient and the pool's decision bytes
+    (conv3x3_x3w_unpool's contract, without the Gram term)."""
+    n, cin, hp, wp_ = pooled_x.shape
+    h, w = 2 * hp, 2 * wp_
+    if out is None:
+        out = torch.empty(n, cout, h + 2 * pad - 2, w + 2 * pad - 2, device=pooled_x.device, dtype=torch.float32)
+    wp, wn = _ws_args(workspace, conv_x3q_workspace_bytes(n, cin, h, w, cout, pad) if workspace is None else 0, pooled_x.device)
+    _check(lib().maua_conv3x3_x3q_unpool(_ptr(_f32(pooled_x, "pooled_x")), codes.data_ptr(), int(bool(honour_relu_bit)), bank.data_ptr(),
+                                         float(w_scale), _ptr(out_relu_mask) if out_relu_mask is not None else None, _ptr(out), n, cin, h, w,
+                                         cout, pad, wp, wn, _stream()), "maua_conv3x3_x3q_unpool")
     return out
 
 

@@ -1,0 +1,275 @@
+"""conv_x3q.hip - the 32-channel-chunk kernel on v_mfma_f32_16x16x32_f16 (round 4) - against the fp64 arithmetic of the reference's
+layers, directly, and bit for bit against the launches its fused variants replace.
+
+Reference arithmetic: `nn.Conv2d(cin, c, 3, padding=1)` + `nn.ReLU(inplace=True)` (/root/reference/models.py:129-130) and the
+backward-data pass autograd derives from it; fused variants: `nn.MaxPool2d(2, 2)` (models.py:120) behind the layer, and that pool's
+backward pass in front of the layer's backward-data pass.
+
+Every case calls through the C ABI (maua_conv3x3_x3q / _relu_pool / _unpool) and compares with `F.conv2d(...double())`:
+contractions <= 2e-6 rel-L2 (measured 1.5-1.9e-7: the fp32 CPU convolution's own distance from fp64), selections bit-exact.  Shapes
+cover the channel counts the engine routes here (256, 512) and the others the kernel accepts (32 ... 128), ragged planes
+(H % 16 != 0, W % 32 != 0, odd extents), ragged output-channel tiles (Cout % 64 != 0), batches, both paddings, and every flag of the
+entry point, in the one-pass and in the split-K form.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import planar_codes, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+BAR = 2e-6
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import hip as h
+    h.lib()
+    return h
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def one_pass_ws():
+    """A workspace too small for split-K slabs: the entry point then makes one pass over the channels."""
+    return torch.empty(16, dtype=torch.uint8, device="cuda")
+
+
+# cin, cout, H, W, n, pad
+X3Q_CASES = [
+    (32, 64, 16, 32, 1, 1),        # one chunk, one tile
+    (32, 200, 70, 97, 2, 1),       # one chunk, ragged cout tile, ragged plane, batch
+    (64, 64, 64, 64, 1, 1),
+    (64, 128, 67, 100, 1, 1),
+    (64, 200, 66, 65, 1, 0),       # no padding (backward-data pads by 2)
+    (128, 128, 64, 96, 2, 1),
+    (128, 256, 75, 64, 1, 1),
+    (256, 256, 64, 64, 1, 1),      # conv3_2..4
+    (256, 512, 65, 70, 1, 1),      # conv4_1
+    (256, 200, 45, 45, 2, 1),      # the deep plane of a 724-px image
+    (512, 512, 64, 64, 1, 1),      # conv4_2..4 / conv5_1
+    (512, 512, 72, 97, 1, 1),
+    (512, 192, 90, 91, 2, 1),      # conv4 of a 724 / 1448-px image: odd plane
+    (512, 64, 130, 97, 1, 0),
+]
+
+
+@pytest.mark.parametrize("cin,cout,H,W,n,pad", X3Q_CASES)
+def test_conv3x3_x3q_forward_and_backward(hip, cin, cout, H, W, n, pad):
+    """Forward with bias + ReLU and backward-data with the ReLU mask of the layer's input, each in whatever form the cost
+    model picks for the geometry AND forced into one pass over the channels."""
+    assert hip.conv_x3q_supported(cin, H, W, pad)
+    x = torch.relu(rnd(n, cin, H, W, seed=1))                       # post-ReLU activations: half the values are zero
+    w = rnd(cout, cin, 3, 3, seed=2, scale=math.sqrt(2.0 / (9 * cin)))
+    b = rnd(cout, seed=3, scale=0.1)
+    ref = torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=pad))
+    bank_f, bank_b, wsc = hip.conv_pack_filters_x3q(dev(w))
+    assert math.log2(wsc) == int(math.log2(wsc)) and 32 <= float(w.abs().max()) * wsc < 64
+    y = hip.conv3x3_x3q(dev(x), bank_f, wsc, dev(b), cout, pad, True)
+    y1 = hip.conv3x3_x3q(dev(x), bank_f, wsc, dev(b), cout, pad, True, workspace=one_pass_ws())
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape
+    assert rel_l2(y.cpu(), ref) <= BAR and rel_l2(y1.cpu(), ref) <= BAR
+    assert torch.equal(y == 0, y1 == 0) or float(((y == 0) != (y1 == 0)).sum()) <= 1e-5 * y.numel()
+    # backward-data: the gradient arrives masked (half zeros), the result is masked by the layer's input
+    gy = rnd(*ref.shape, seed=4) * (ref > 0)
+    refb = torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), padding=pad) * (x > 0)
+    assert hip.conv_x3q_supported(cout, ref.shape[2], ref.shape[3], 2 - pad) == (cout % 32 == 0)
+    if cout % 32:
+        return
+    gx = hip.conv3x3_x3q(dev(gy), bank_b, wsc, None, cin, 2 - pad, False, out_relu_mask=dev(x))
+    gx1 = hip.conv3x3_x3q(dev(gy), bank_b, wsc, None, cin, 2 - pad, False, out_relu_mask=dev(x), workspace=one_pass_ws())
+    torch.cuda.synchronize()
+    assert gx.shape == x.shape
+    assert rel_l2(gx.cpu(), refb) <= BAR and rel_l2(gx1.cpu(), refb) <= BAR
+    assert torch.equal(gx == 0, dev(x) == 0) or float(((gx == 0) != (dev(x) == 0)).sum()) <= 1e-4 * gx.numel()
+
+
+@pytest.mark.parametrize("cin,cout,H,W,n", [(64, 64, 66, 97, 2), (256, 200, 64, 64, 1), (512, 512, 64, 64, 1), (512, 128, 16, 16, 2)])
+@pytest.mark.parametrize("bias", [False, True])
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("accumulate", [False, True])
+@pytest.mark.parametrize("masked", [False, True])
+def test_conv3x3_x3q_every_flag_in_both_forms(hip, cin, cout, H, W, n, bias, relu, accumulate, masked):
+    """y = [mask > 0] * relu?(conv(x) + bias? + y_before?) for all sixteen flag combinations, one-pass and split-K (the 512-channel
+    cases split), bit-identical reruns."""
+    x = rnd(n, cin, H, W, seed=11)
+    w = rnd(cout, cin, 3, 3, seed=12, scale=math.sqrt(2.0 / (9 * cin)))
+    b = rnd(cout, seed=13, scale=0.1) if bias else None
+    base = rnd(n, cout, H, W, seed=14)
+    mask = rnd(n, cout, H, W, seed=15)
+    ref = F.conv2d(x.double(), w.double(), b.double() if bias else None, padding=1)
+    if accumulate:
+        ref = ref + base.double()
+    if relu:
+        ref = torch.relu(ref)
+    if masked:
+        ref = ref * (mask > 0)
+    bank_f, _, wsc = hip.conv_pack_filters_x3q(dev(w))
+    outs = []
+    for ws in (None, one_pass_ws(), None):
+        y = hip.conv3x3_x3q(dev(x), bank_f, wsc, dev(b) if bias else None, cout, 1, relu, out=dev(base.clone()),
+                            out_relu_mask=dev(mask) if masked else None, accumulate=accumulate, workspace=ws)
+        outs.append(y)
+    torch.cuda.synchronize()
+    for y in outs:
+        assert rel_l2(y.cpu(), ref) <= BAR
+    assert torch.equal(outs[0], outs[2])
+    if cin == 512:
+        assert hip.conv_x3q_split(n, cin, H, W, cout, 1) > 1          # these geometries do exercise the slabs
+
+
+@pytest.mark.parametrize("kind", ["wide_range", "tiny", "huge", "zeros", "one_hot", "hot_channel"])
+@pytest.mark.parametrize("cin", [64, 512])
+def test_conv3x3_x3q_scaling_survives_extreme_inputs(hip, kind, cin):
+    """fp16 has 5 exponent bits: the per-workgroup, per-32-channel power-of-two scaling must keep every magnitude usable."""
+    cout, H, W = 64, 72, 80
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(1, cin, H, W, generator=g)
+    if kind == "wide_range":
+        x = x * torch.exp(torch.randn(1, cin, H, W, generator=g) * 4.0) * 1e-6 * (torch.rand(1, cin, H, W, generator=g) > 0.5)
+    elif kind == "tiny":
+        x = x * 1e-30
+    elif kind == "huge":
+        x = x * 1e30
+    elif kind == "zeros":
+        x = torch.zeros_like(x)
+    elif kind == "one_hot":
+        x = torch.zeros_like(x)
+        x[0, 17, 20, 21] = 3.0e-12
+    elif kind == "hot_channel":
+        x[0, 5] *= 1e6                                              # one chunk 10^6 above the other chunks of the same tile
+    w = rnd(cout, cin, 3, 3, seed=2, scale=math.sqrt(2.0 / (9 * cin)))
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    bank_f, _, wsc = hip.conv_pack_filters_x3q(dev(w))
+    y = hip.conv3x3_x3q(dev(x), bank_f, wsc, None, cout, 1, False)
+    y4 = hip.conv3x3_x3q(dev(x * 4.0), bank_f, wsc, None, cout, 1, False)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+    if kind == "zeros":
+        assert float(y.abs().max()) == 0.0
+    else:
+        assert rel_l2(y.cpu(), ref) <= BAR
+        if kind != "huge":
+            assert torch.equal(y4, y * 4.0)                         # exact homogeneity under power-of-two scaling
+
+
+def test_conv3x3_x3q_index_exact(hip):
+    """Inputs that encode (channel, row, column) and one-tap selector filters: every output must be the EXACT input value the tap
+    names (22 significant bits are enough for these integers) - a wrong lane, octet, row or half of the fp16 pair shows as a wrong
+    integer, not as a rounding error."""
+    cin, cout, H, W = 64, 128, 40, 70
+    c = torch.arange(cin).view(cin, 1, 1).float()
+    yy = torch.arange(H).view(1, H, 1).float()
+    xx = torch.arange(W).view(1, 1, W).float()
+    x = (c + 100 * yy + 10000 * xx).unsqueeze(0)
+    for tap in range(9):
+        w = torch.zeros(cout, cin, 3, 3)
+        for co in range(cout):
+            w[co, (co * 7 + tap) % cin, tap // 3, tap % 3] = 1.0
+        bank_f, _, wsc = hip.conv_pack_filters_x3q(dev(w))
+        y = hip.conv3x3_x3q(dev(x), bank_f, wsc, None, cout, 1, False)
+        torch.cuda.synchronize()
+        assert torch.equal(y.cpu(), F.conv2d(x, w, padding=1)), tap
+
+
+@pytest.mark.parametrize("n,cin,cout,H,W", [(1, 256, 256, 64, 64), (1, 512, 512, 64, 96), (2, 128, 200, 66, 70), (1, 64, 64, 130, 96)])
+def test_x3q_conv_relu_pool_in_one_launch(hip, n, cin, cout, H, W):
+    """maua_conv3x3_x3q_relu_pool (conv3_4 / conv4_4 shapes among them): bit for bit maua_conv3x3_x3q + maua_pool2x2_fwd_codes in the
+    one-pass and the split-K form, and max_pool2d(relu(conv2d)) in fp64 to 2e-6 with decision bytes that name a maximum of the fp64
+    window."""
+    x = torch.relu(rnd(n, cin, H, W, seed=21))
+    w = rnd(cout, cin, 3, 3, seed=22, scale=math.sqrt(2.0 / (9 * cin)))
+    b = rnd(cout, seed=23, scale=0.1)
+    full = torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))
+    ref, _ = F.max_pool2d(full, 2, 2, return_indices=True)
+    bank_f, _, wsc = hip.conv_pack_filters_x3q(dev(w))
+    for ws in (one_pass_ws(), torch.empty(max(hip.conv_x3q_workspace_bytes(n, cin, H, W, cout, 1), 16), dtype=torch.uint8, device="cuda")):
+        pooled = torch.full((n, cout, H // 2, W // 2), float("nan"), device="cuda")
+        codes = torch.full((n, cout, H // 2, W // 2), 255, dtype=torch.uint8, device="cuda")
+        hip.conv3x3_x3q_relu_pool(dev(x), bank_f, wsc, dev(b), cout, 1, pooled, codes, workspace=ws)
+        act = hip.conv3x3_x3q(dev(x), bank_f, wsc, dev(b), cout, 1, True, workspace=ws)
+        pooled2 = torch.empty_like(pooled)
+        codes2 = torch.empty_like(codes)
+        hip.pool2x2_fwd_codes(act, pooled2, codes2)
+        torch.cuda.synchronize()
+        assert torch.equal(pooled, pooled2) and torch.equal(codes, codes2)
+    assert rel_l2(pooled.cpu(), ref) <= BAR
+    codes = planar_codes(codes.cpu())
+    assert int(codes.max()) <= 7
+    clear_sign = ref.abs() > 1e-5
+    assert torch.equal(((codes & 4) != 0)[clear_sign], (ref <= 0)[clear_sign])
+    pos = (codes & 3).long()
+    oh, ow = H // 2, W // 2
+    rows = (torch.arange(oh)[:, None] * 2 + pos // 2)
+    cols = (torch.arange(ow)[None, :] * 2 + pos % 2)
+    picked = full[torch.arange(n)[:, None, None, None], torch.arange(cout)[None, :, None, None], rows, cols]
+    assert float((picked - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+# channels of the gradient (= couts of the layer), channels produced, full-size H, W, images
+UNPOOL_CASES = [
+    (64, 64, 128, 96, 1),
+    (128, 128, 64, 64, 2),
+    (256, 256, 66, 70, 1),         # conv3_4's channels, ragged tiles (even plane)
+    (512, 512, 64, 64, 1),         # conv4_4: split-K at this size
+    (32, 200, 18, 260, 1),         # ragged cout tile of the produced gradient
+]
+
+
+@pytest.mark.parametrize("cg,c,H,W,n", UNPOOL_CASES)
+@pytest.mark.parametrize("relu_bit", [True, False])
+def test_x3q_backward_pass_straight_from_the_pooled_gradient(hip, cg, c, H, W, n, relu_bit):
+    """maua_conv3x3_x3q_unpool against maua_pool2x2_bwd_codes followed by maua_conv3x3_x3q: the same bits (one-pass and split-K forms,
+    with and without the ReLU mask of the produced gradient), and against autograd's arithmetic in fp64
+    (max_pool2d backward + threshold_backward + conv_transpose2d, /root/reference/models.py:120,129-130)."""
+    act = torch.relu(rnd(n, cg, H, W, seed=31))
+    act[:, :, :4, :4] = 0.0                                            # all-zero windows: bit 2 of their bytes
+    gp = rnd(n, cg, H // 2, W // 2, seed=32)
+    w = rnd(cg, c, 3, 3, seed=33, scale=math.sqrt(2.0 / (9 * c)))
+    fmap = torch.relu(rnd(n, c, H, W, seed=34))
+    _, bb, wsc = hip.conv_pack_filters_x3q(dev(w))
+    pooled = torch.empty(n, cg, H // 2, W // 2, device="cuda")
+    codes = torch.empty(n, cg, H // 2, W // 2, dtype=torch.uint8, device="cuda")
+    hip.pool2x2_fwd_codes(dev(act), pooled, codes)
+    full = hip.pool2x2_bwd_codes(dev(gp), codes, torch.empty(n, cg, H, W, device="cuda"), relu_bit)
+    a64 = act.double().requires_grad_(True)
+    F.max_pool2d(a64, 2, 2).backward(gp.double())
+    gfull = a64.grad * (act > 0) if relu_bit else a64.grad
+    assert torch.equal(full.cpu().double(), gfull)                     # (routing only: exact)
+    ref = F.conv_transpose2d(gfull, w.double(), padding=1)
+    for mask in (None, dev(fmap)):
+        for ws in (None, one_pass_ws()):
+            two = hip.conv3x3_x3q(full, bb, wsc, None, c, 1, False, out_relu_mask=mask, workspace=ws)
+            one = hip.conv3x3_x3q_unpool(dev(gp), codes, relu_bit, bb, wsc, c, 1, out_relu_mask=mask, workspace=ws)
+            torch.cuda.synchronize()
+            assert torch.equal(one, two), (mask is not None, ws is not None)
+        assert rel_l2(one.cpu(), ref * (fmap > 0) if mask is not None else ref) <= BAR
+
+
+def test_x3q_agrees_with_x3w_to_rounding(hip):
+    """The two structures compute the same sums in different orders: their results differ by fp32 rounding only (<= 4e-7), and each
+    is as close to fp64 as the other (the engine mixes them layer by layer)."""
+    cin, cout, H, W = 512, 512, 96, 96
+    x = torch.relu(rnd(1, cin, H, W, seed=51))
+    w = rnd(cout, cin, 3, 3, seed=52, scale=math.sqrt(2.0 / (9 * cin)))
+    fq, _, wsq = hip.conv_pack_filters_x3q(dev(w))
+    fw, _, wsw = hip.conv_pack_filters_x3w(dev(w))
+    assert wsq == wsw
+    yq = hip.conv3x3_x3q(dev(x), fq, wsq, None, cout, 1, False)
+    yw = hip.conv3x3_x3w(dev(x), fw, wsw, None, cout, 1, False)
+    torch.cuda.synchronize()
+    ref = F.conv2d(x[:, :, :34, :34].double(), w.double(), padding=1)[:, :, :32, :32]
+    eq, ew = rel_l2(yq[:, :, :32, :32].cpu(), ref), rel_l2(yw[:, :, :32, :32].cpu(), ref)
+    assert rel_l2(yq.cpu(), yw.cpu().double()) <= 4e-7
+    assert eq <= 1.25 * ew + 1e-8 and eq <= 3e-7

@@ -68,7 +68,7 @@ for name, cin, cout, div in layers:
     med = {k: sorted(v)[len(v) // 2] for k, v in times.items()}
     for k in tot:
         tot[k] += med[k] * mult.get(name, 1)
-    print(f"{name} {cin:4d}->{cout:4d} @{H:4d}: x3w {med['x3w']:7.1f} us ({fl / med['x3w'] / 1e6:6.1f} TF)  x3q {med['x3q']:7.1f} us "
+    print(f"{os.environ.get('TAG', '')}{name} {cin:4d}->{cout:4d} @{H:4d}: x3w {med['x3w']:7.1f} us ({fl / med['x3w'] / 1e6:6.1f} TF)  x3q {med['x3q']:7.1f} us "
           f"({fl / med['x3q'] / 1e6:6.1f} TF)  ratio {med['x3w'] / med['x3q']:.3f}  split {hip.conv_x3q_split(1, cin, H, H, cout, 1)} | "
           f"x3q vs x3w fwd {rel:.1e} bwd {relb:.1e} | vs fp64 crop: fp32-CPU {e32:.1e} x3w {ew:.1e} x3q {eq:.1e}", flush=True)
 print(f"sum over the 12 3x3 layers (fwd geometry): x3w {tot['x3w'] / 1e3:.3f} ms  x3q {tot['x3q'] / 1e3:.3f} ms  ratio {tot['x3w'] / tot['x3q']:.3f}")
