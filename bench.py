@@ -135,20 +135,42 @@ def cpu_baseline(S, optimizer, iters=5, repeats=3, model="vgg19"):
                       f"{repeats} runs: {dt:.2f} s on {best[1]} threads ({nproc} logical CPUs)"}
 
 
+def accuracy_probe():
+    """Measured in THIS run (nothing quoted from elsewhere): the timed convolution kernels on a conv4_2-shaped layer (512 -> 512 channels,
+    128 x 128, post-ReLU-like input, seeded) against `F.conv2d` in fp64 on a 32 x 32 output crop, next to the same crop computed by
+    the reference's own arithmetic (fp32 `F.conv2d` on the CPU).  rel-L2 errors; the fp16x3 claim is "as close to fp64 as fp32"."""
+    import torch.nn.functional as F
+    import hip
+    g = torch.Generator().manual_seed(11)
+    cin = cout = 512
+    x = torch.relu(torch.randn(1, cin, 128, 128, generator=g))
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    ref = F.conv2d(x[:, :, :34, :34].double(), w.double(), padding=1)[:, :, :32, :32]
+    rel = lambda y: float((y.double() - ref).norm() / ref.norm())
+    out = {"layer": "3x3, 512 -> 512 channels, 128 x 128 (conv4_2's shape), seeded post-ReLU-like input, 32 x 32 output crop vs fp64",
+           "fp32_cpu_conv": rel(F.conv2d(x[:, :, :34, :34], w, padding=1)[:, :, :32, :32])}
+    xd, wd = x.cuda(), w.cuda()
+    for name, pack, run in (("conv_x3w", hip.conv_pack_filters_x3w, hip.conv3x3_x3w), ("conv_x3q", hip.conv_pack_filters_x3q, hip.conv3x3_x3q)):
+        bank, _, wsc = pack(wd)
+        out[name] = rel(run(xd, bank, wsc, None, cout, 1, False)[:, :, :32, :32].cpu())
+    return {k: (round(v, 10) if isinstance(v, float) else v) for k, v in out.items()}
+
+
 def pmc_traffic(prefix):
     """HBM-side bytes per launch of the dominant kernel from the committed PMC pass (profiles/pmc_r02_traffic.json, written
     by tools/pmc_summary.py from separate `rocprofv3 --pmc` runs of this same command).  Reads: request counters x 64 B,
     doubled as MI355X_MICROARCH.md prescribes for gfx950 (our own calibration, profiles/pmc_r01_calibration.json: x2.0
     for 16 B/lane streams, x1.2-1.6 for 4 B/lane patterns, so this is an upper bound); writes are exact."""
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    path = next((os.path.join(here, f) for f in ("pmc_r03_traffic.json", "pmc_r02_traffic.json") if os.path.exists(os.path.join(here, f))), None)
+    path = next((os.path.join(here, f) for f in ("pmc_r04_traffic.json", "pmc_r03_traffic.json", "pmc_r02_traffic.json")
+                 if os.path.exists(os.path.join(here, f))), None)
     if path is None:
         return None
     with open(path) as f:
         kernels = json.load(f)["kernels"]
     n = rd = wr = 0
     for name, e in kernels.items():
-        if name.startswith(prefix) and "read_bytes_raw" in e:
+        if name.startswith(tuple(prefix) if isinstance(prefix, (tuple, list)) else prefix) and "read_bytes_raw" in e:
             n += e["launches_seen"]
             rd += e["read_bytes_raw"] * e["launches_seen"]
             wr += e["write_bytes_raw"] * e["launches_seen"]
@@ -272,7 +294,7 @@ def start_exact_split_child(argv_size, steps, warmup, history, optimizer):
         env.pop(k, None)
     return subprocess.Popen([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--size", str(argv_size), "--steps", str(steps),
                              "--warmup", str(warmup), "--history", str(history), "--optimizer", optimizer, "--no_cpu_baseline",
-                             "--no_extra_sizes", "--no_exact_split", "--no_repeats", "--_wait_for_go"], env=env, stdin=subprocess.PIPE,
+                             "--no_extra_sizes", "--no_exact_split", "--no_repeats", "--no_accuracy_probe", "--_wait_for_go"], env=env, stdin=subprocess.PIPE,
                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
 
 
@@ -379,6 +401,7 @@ def main():
     ap.add_argument("--extra_sizes", default=None, help="comma-separated image sizes for `extra.other_sizes` (default: 512,256 next to a 1024 run)")
     ap.add_argument("--no_exact_split", action="store_true", help="skip the bf16x6 (MAUA_CONV_X3=0) figure in `extra`")
     ap.add_argument("--no_repeats", action="store_true", help="skip the repeated timed regions in `extra.repeats`")
+    ap.add_argument("--no_accuracy_probe", action="store_true", help="skip the in-run fp64 check of the timed convolution kernels")
     ap.add_argument("--repeats", type=int, default=5, help="further K-step regions timed after the headline one")
     ap.add_argument("--allow_fewer", action="store_true", help="with fewer than --gpus devices visible: run on those and report it")
     ap.add_argument("--requested_gpus", type=int, default=None, help=argparse.SUPPRESS)
@@ -516,7 +539,8 @@ def main():
     conv = [(fl, e0.elapsed_time(e1)) for tag, fl, nb, e0, e1 in timer if tag.startswith(dominant)]
     roofline = None
     x3w = x6 and models._x3_enabled() and models._x3w_enabled()
-    pmc = pmc_traffic((("maua::conv_x3w_kernel<" if x3w else "maua::conv_x3_kernel<") if models._x3_enabled() else
+    x3q = x3w and models._x3q_min_channels() > 0
+    pmc = pmc_traffic(((("maua::conv_x3w_kernel<", "maua::conv_x3q_kernel<") if x3w else "maua::conv_x3_kernel<") if models._x3_enabled() else
                        "maua::conv_x6_kernel<") if x6 else "maua::conv_mfma2_kernel<") if S == 1024 else None
     if conv:
         tot_fl, tot_ms = sum(c[0] for c in conv), sum(c[1] for c in conv)
@@ -534,15 +558,16 @@ def main():
         per_product = 3 if x3 else X6_MFMAS_PER_PRODUCT
         peak = BF16_MFMA_PEAK_TFLOPS / per_product if x6 else FP32_MFMA_PEAK_TFLOPS
         roofline = {"bound": "mfma",
-                    "kernel": (("conv_x3w_kernel (3x3 conv fwd + bwd-data, fp16x3, 16-channel chunks)" if x3w else
+                    "kernel": ((("conv_x3w_kernel + conv_x3q_kernel (3x3 conv fwd + bwd-data, fp16x3: 16-channel chunks on 32x32x16 MFMAs below "
+                                 f"{models._x3q_min_channels()} consumed channels, 32-channel chunks on 16x16x32 MFMAs from there)" if x3q else
+                                 "conv_x3w_kernel (3x3 conv fwd + bwd-data, fp16x3, 16-channel chunks)") if x3w else
                                 "conv_x3_kernel (3x3 conv fwd + bwd-data, fp16x3)") if x3 else
                                "conv_x6_kernel (3x3 conv fwd + bwd-data, bf16x6)") if x6 else "conv_mfma2_kernel (fwd + bwd-data)",
                     "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     "peak_note": (f"algorithmic fp32-equivalent FLOPs; peak = 2500 TFLOP/s dense {'fp16' if x3 else 'bf16'} / "
                                   f"{per_product} MFMAs per product block; 16-bit multiply-accumulate work = achieved x {per_product}"
-                                  + ("; every tap is a full K=16 MFMA step (16-channel chunks), so that is also the matrix-pipe time; "
-                                     "the kernel is power-bound: in-kernel clock 1.56 GHz under this load (profiles/probes_r02.md), "
-                                     "i.e. 1.63 PFLOP/s of fp16 MFMA at the clock the chip holds" if x3w else
+                                  + ("; every tap is a full-K MFMA step, so that is also the matrix-pipe time; the kernels are power-bound "
+                                     "(in-kernel clock stamps: profiles/probes_r02.md, probes_r04.md)" if x3w else
                                      f"; matrix-pipe time = achieved x {per_product} x 10/9 (the ninth tap's K=8 MFMA holds the pipe as "
                                      "long as a K=16 one: 5 steps for 4.5)")) if x6 else "fp32 MFMA peak",
                     "hw_16bit_tflops": round(achieved * per_product, 1) if x6 else None,
@@ -565,10 +590,10 @@ def main():
                    "f32 (bf16x6 split-precision MFMA, fp32 accumulate)")
                   if (opt.engine is not None and opt.engine.x6_fwd) else "f32"),
         "dtype_note": ((("3x3 convs: power-of-two-scaled 2-way fp16 split of both operands = 22 of 24 significand bits, three fp16 MFMAs "
-                         "per product block, fp32 accumulate; image layer on exact bf16x6 products; pixel-gradient error vs fp64 2.8e-7, "
-                         "the reference's own fp32: 4.5e-7") if models._x3_enabled() else
-                        "3x3 convs: exact 3-way bf16 split of both operands on the bf16 matrix cores, fp32 accumulate; pixel-gradient "
-                        "error vs fp64 2.6e-7, the reference's own fp32: 4.5e-7")
+                         "per product block, fp32 accumulate; image layer on exact bf16x6 products; accuracy of the timed kernels against "
+                         "fp64, measured in this run: `accuracy_probe`; whole-network pixel gradient: "
+                         "tests/test_engine_gpu.py::test_pixel_gradient_is_as_close_to_fp64_as_the_reference_fp32") if models._x3_enabled() else
+                        "3x3 convs: exact 3-way bf16 split of both operands on the bf16 matrix cores, fp32 accumulate")
                        if (opt.engine is not None and opt.engine.x6_fwd) else None),
         "data": "synthetic",
         "config": {"workload": f"{S}x{S} single-scale VGG-19 Gram style transfer, {a.optimizer.upper()}"
@@ -640,6 +665,8 @@ def main():
         extra["exact_split"] = finish_exact_split_child(exact_child)
     if extra:
         out["extra"] = extra
+    if world == 1 and not a.no_accuracy_probe and a.model == "vgg19" and models._x3_enabled() and models._x3w_enabled():
+        out["accuracy_probe"] = accuracy_probe()
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(S, a.optimizer, model=a.model)
     print(json.dumps(out), flush=True)

@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(XQ_THREADS, 2) conv_x3q_kernel(ConvArgs p, flo
         const bool refresh = i == 3 && next_tap >= 0;
         XQ_FENCE();
         if (i < 3) load_ai(cur ^ 1, tap, i + 1);
-        else if (next_tap >= 0) load_ai(cur ^ 1, next_tap, 0);
+        else if (next_tap >= 0 && tap != 4) load_ai(cur ^ 1, next_tap, 0);  // (tap 5's planes are in LDS behind XM only: see the loop)
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         if constexpr (FRESH) {
 #pragma unroll
@@ -492,11 +492,14 @@ __global__ void __launch_bounds__(XQ_THREADS, 2) conv_x3q_kernel(ConvArgs p, flo
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         step(4, 1, 5, KEEP, 0.f, V4, [&]() { publish_max(); });
         step(4, 2, 5, KEEP, 0.f, V4, nothing);
-        step(4, 3, 5, KEEP, 0.f, V0, nothing);   // requests tap 5: the patch and the planes of taps 5-8 stay across XM
+        step(4, 3, 5, KEEP, 0.f, V0, nothing);   // requests tap 5's PATCH fragments (the patch stays across XM) - not its filter fragments:
+                                                 // the planes of taps 5-8 were streamed during taps 0-3 by all eight waves, and another
+                                                 // wave's LDS-DMA is only known to have landed behind the barrier that follows its wait
         XQ_MARK(2);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // XM: the filter planes of taps 0-4 are free; the maxima of the next chunk are visible
+        __builtin_amdgcn_s_barrier();  // XM: the filter planes of taps 0-4 are free, those of taps 5-8 and the maxima of the next chunk visible
         XQ_MARK(3);
+        load_ai(0, 5, 0);
         inv_next = chunk_scale() * w_inv_scale;
         step(5, 0, 6, FOLD, inv_cur, V2, nothing);
         step(5, 1, 6, FOLD, inv_cur, V2, [&]() { if (more) dma_filters(ch + 1, 0, 1, 0); });
@@ -607,27 +610,34 @@ __global__ void __launch_bounds__(XQ_THREADS, 2) conv_x3q_kernel(ConvArgs p, flo
         if constexpr (ACC || OM) asm volatile("" : "+v"(lane_off));
         float* __restrict__ yl = yout + lane_off;
         const float* __restrict__ oml = OM ? om + lane_off : nullptr;
+        // (accumulating launches - rare - take one channel group at a time: with the previous contents of all sixteen channels in flight
+        //  the compiler's allocation of the whole kernel tips over into hundreds of spills; masks alone come sixteen at a time)
+        constexpr int GB = ACC ? 1 : 4;  // channel groups per batch of loads
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {  // (ACC / OM: one channel group at a time, for the same reason)
-            if constexpr (ACC || OM) XQ_FENCE();
-            float prev[4], msk[4];
+        for (int i0 = 0; i0 < 4; i0 += GB) {
+            if constexpr (ACC) XQ_FENCE();
+            float prev[GB * 4], msk[GB * 4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int cr = i * 16 + r;
-                const bool cv = full || cl + cr < p.Cout;
-                prev[r] = 0.f;
-                msk[r] = 1.f;
-                if constexpr (ACC) if (cv) prev[r] = yl[(int64_t)cr * out_plane];
-                if constexpr (OM) if (cv) msk[r] = oml[(int64_t)cr * out_plane];
-            }
+            for (int i = i0; i < i0 + GB; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int cr = i * 16 + r;
-                float v = master[i][g][r] + prev[r];
-                if (p.relu) v = v > 0.f ? v : 0.f;
-                v = msk[r] > 0.f ? v : 0.f;
-                if (full || cl + cr < p.Cout) yl[(int64_t)cr * out_plane] = v;
-            }
+                for (int r = 0; r < 4; ++r) {
+                    const int cr = i * 16 + r, e = (i - i0) * 4 + r;
+                    const bool cv = full || cl + cr < p.Cout;
+                    prev[e] = 0.f;
+                    msk[e] = 1.f;
+                    if constexpr (ACC) if (cv) prev[e] = yl[(int64_t)cr * out_plane];
+                    if constexpr (OM) if (cv) msk[e] = oml[(int64_t)cr * out_plane];
+                }
+#pragma unroll
+            for (int i = i0; i < i0 + GB; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int cr = i * 16 + r, e = (i - i0) * 4 + r;
+                    float v = master[i][g][r] + prev[e];
+                    if (p.relu) v = v > 0.f ? v : 0.f;
+                    v = msk[e] > 0.f ? v : 0.f;
+                    if (full || cl + cr < p.Cout) yl[(int64_t)cr * out_plane] = v;
+                }
         }
     }
 }

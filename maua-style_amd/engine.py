@@ -198,16 +198,18 @@ class StyleEngine:
         # backward-data pass of the convolution runs on conv_x3w.hip, it stages its input straight from the pooled map's gradient and
         # the decision bytes (hip.conv3x3_x3w_unpool) - the pool's backward launch and the full-size gradient it would write and the
         # convolution read again do not exist.  fused_unpool[conv step] = pool step.
-        self.fused_unpool = {}
-        if self.x6_bwd and os.environ.get("MAUA_FUSE_UNPOOL", "1") != "0":
+        self.fused_unpool, self.pool_groups = {}, set()  # (pool_groups: the candidates, whether or not the fusion is switched on)
+        if self.x6_bwd:
             for s in self.steps:
                 if s.kind != "conv" or not s.relu or s.k != 3 or s.stride != 1 or s.pad != 1:
                     continue
                 users = [t for t in self.steps if t.src == s.dst and t is not s]
                 if len(users) == 1 and users[0].kind == "pool" and id(users[0]) in self.pool_codes and \
                         self._x6_ok(s, s.mod.in_channels) and models_mod.conv3x3_bwd_is_x3w(s.mod, *shapes[s.dst][2:]):
-                    self.fused_unpool[id(s)] = users[0]
-                    self.gbuf[s.dst] = torch.empty(shapes[s.dst], device="meta")
+                    self.pool_groups.add(id(s))
+                    if os.environ.get("MAUA_FUSE_UNPOOL", "1") != "0":
+                        self.fused_unpool[id(s)] = users[0]
+                        self.gbuf[s.dst] = torch.empty(shapes[s.dst], device="meta")
         self.unpooled_by_conv = {id(v) for v in self.fused_unpool.values()}
         # Single images: where a style loss is the only loss on the input activation of a 3x3 layer whose backward-data pass runs
         # on conv_x3w.hip, that pass takes the Gram backward along (D . F as extra one-tap chunks of its K loop) instead of a
@@ -278,7 +280,9 @@ class StyleEngine:
                              hip.conv_x3_workspace_bytes(n, cin, h, w, cout, s.pad),
                              hip.conv_x3_workspace_bytes(n, cout, oh, ow, cin, 2 - s.pad),
                              hip.conv_x3w_workspace_bytes(n, cin, h, w, cout, s.pad),
-                             hip.conv_x3w_workspace_bytes(n, cout, oh, ow, cin, 2 - s.pad))
+                             hip.conv_x3w_workspace_bytes(n, cout, oh, ow, cin, 2 - s.pad),
+                             hip.conv_x3q_workspace_bytes(n, cin, h, w, cout, s.pad),
+                             hip.conv_x3q_workspace_bytes(n, cout, oh, ow, cin, 2 - s.pad))
         self.ws = torch.empty(ws, dtype=torch.uint8, device=dev)
         self.x_static = torch.empty(self.shape, device=dev)
         if os.environ.get("MAUA_DEBUG_POISON") == "1":  # tests: every buffer starts as NaN, so a read-before-write shows up
@@ -760,7 +764,7 @@ class StyleEngine:
                     fused_done.add(id(fg[0]))
                 elif self.x6_bwd and self._x6_ok(s, s.mod.in_channels):
                     self._timed("conv3x3_split_bwd", fl, nb, lambda: models_mod.conv3x3_mfma(
-                        g[s.dst], s.mod, True, out=g[s.src], out_relu_mask=im, workspace=self.ws))
+                        g[s.dst], s.mod, True, out=g[s.src], out_relu_mask=im, workspace=self.ws, pool_group=id(s) in self.pool_groups))
                 elif self.x6_bwd and models_mod.conv1x1_is_mfma(s.mod, True):
                     self._timed("conv_1x1_bwd", fl, nb, lambda: models_mod.conv1x1_mfma(
                         g[s.dst], s.mod, True, out=g[s.src], out_relu_mask=im, workspace=self.ws))

@@ -60,6 +60,30 @@ def _image_kernel_enabled():
     return os.environ.get("MAUA_CONV_IMAGE", "1") == "1"
 
 
+def _x3q_min_channels():
+    """MAUA_CONV_X3Q: the smallest consumed channel count (a multiple of 32) from which a 3x3 layer runs conv_x3q.hip - 32-channel chunks on
+    v_mfma_f32_16x16x32_f16, one workgroup of eight waves per CU (round 4) - instead of conv_x3w.hip; "0" = never.  Default 256: measured
+    on one box (tools/bench_x3q.py, 1024 x 1024 layer shapes) 1.13-1.22 x conv_x3w at 512 channels, 1.04-1.13 x at 256, 1.02 x at 128;
+    the 64- and 128-channel layers run two to four chunks per workgroup, too few to pay for the single workgroup's prologue."""
+    import os
+    v = os.environ.get("MAUA_CONV_X3Q", "256")
+    return int(v) if v.isdigit() else 256
+
+
+X3Q_UNPOOL_MIN_CHANNELS = 512  # conv_x3q's unpooling form pays from here: its corner vectors are cut in the exposed store phase
+                               # (measured in the network: conv4_4's backward pass 181 -> 176 us, conv3_4's 186 -> 207)
+
+
+def conv3x3_is_x3q(consumed, h, w, pad, at_least=0):
+    """Whether a 3x3 stride-1 pass that consumes `consumed` channels of an h x w plane runs on conv_x3q.hip (forward: consumed = the
+    layer's input channels, pad = its padding; backward-data: its output channels, 2 - padding).  `at_least`: a higher channel bound
+    for this pass (the backward pass of a conv + ReLU + pool group: the same kernel family whether or not the pool's backward pass is
+    fused into it, so that the fusion changes no bit)."""
+    mc = max(_x3q_min_channels(), at_least) if _x3q_min_channels() > 0 else 0
+    return _x3_enabled() and _x3w_enabled() and mc > 0 and consumed >= mc and h * w >= _x3w_min_pixels() and \
+        hip.conv_x3q_supported(consumed, h, w, pad)
+
+
 _X3W_MIN_PIXELS = None
 
 
@@ -73,15 +97,20 @@ def _x3w_min_pixels():
     return _X3W_MIN_PIXELS
 
 
-def conv3x3_mfma(x, mod, backward, out=None, out_relu_mask=None, relu=False, accumulate=False, workspace=None):
+def conv3x3_mfma(x, mod, backward, out=None, out_relu_mask=None, relu=False, accumulate=False, workspace=None, pool_group=False):
     """The fp32-accurate reduced-width matrix-core convolution of a 3x3 stride-1 layer (forward, or backward-data when
-    `backward`): fp16x3 or bf16x6 according to MAUA_CONV_X3."""
+    `backward`): fp16x3 or bf16x6 according to MAUA_CONV_X3.  `pool_group`: the backward pass of a layer whose output feeds a 2x2 max
+    pool with kept decisions, run here on the pool's own backward output (MAUA_FUSE_UNPOOL=0): same kernel family as the fused form."""
     pad = mod.padding[0]
     if backward:
         cout, p, bias = mod.in_channels, 2 - pad, None
     else:
         cout, p, bias = mod.out_channels, pad, mod.bias_device()
     consumed = mod.out_channels if backward else mod.in_channels
+    if conv3x3_is_x3q(consumed, x.shape[2], x.shape[3], p, X3Q_UNPOOL_MIN_CHANNELS if pool_group else 0):
+        bf, bb, wsc = mod.banks3q()
+        return hip.conv3x3_x3q(x, bb if backward else bf, wsc, bias, cout, p, relu, out=out, out_relu_mask=out_relu_mask,
+                               accumulate=accumulate, workspace=workspace)
     if _x3_enabled() and _x3w_enabled() and x.shape[2] * x.shape[3] >= _x3w_min_pixels() and \
             hip.conv_x3w_supported(consumed, x.shape[2], x.shape[3], p):
         bf, bb, wsc = mod.banks3w()
@@ -110,6 +139,9 @@ def conv3x3_fwd_is_x3w(mod, h, w):
 def conv3x3_relu_pool(x, mod, pooled, codes, workspace=None):
     """conv + bias + ReLU + the 2x2 / 2 max pool behind it without the full-size activation (hip.conv3x3_x3w_relu_pool: one launch, or -
     small grids, with a workspace - a split channel loop whose adding pass pools)."""
+    if conv3x3_is_x3q(mod.in_channels, x.shape[2], x.shape[3], mod.padding[0]):
+        bf, _, wsc = mod.banks3q()
+        return hip.conv3x3_x3q_relu_pool(x, bf, wsc, mod.bias_device(), mod.out_channels, mod.padding[0], pooled, codes, workspace=workspace)
     bf, _, wsc = mod.banks3w()
     return hip.conv3x3_x3w_relu_pool(x, bf, wsc, mod.bias_device(), mod.out_channels, mod.padding[0], pooled, codes, workspace=workspace)
 
@@ -135,6 +167,11 @@ def conv3x3_bwd_from_pooled(gy_pooled, codes, honour_relu_bit, mod, out, out_rel
     """Backward-data pass of a conv + ReLU + 2x2 max pool group from the gradient of the POOLED map and the pool's decision bytes
     (hip.conv3x3_x3w_unpool): the pool's backward pass happens while the kernel stages its input; with `dmat_bank`, the Gram backward
     of the style loss on the layer's input goes along (out_relu_mask = that activation)."""
+    if dmat_bank is None and conv3x3_is_x3q(mod.out_channels, 2 * gy_pooled.shape[2], 2 * gy_pooled.shape[3], 2 - mod.padding[0],
+                                            X3Q_UNPOOL_MIN_CHANNELS):
+        _, bb, wsc = mod.banks3q()
+        return hip.conv3x3_x3q_unpool(gy_pooled, codes, honour_relu_bit, bb, wsc, mod.in_channels, 2 - mod.padding[0], out=out,
+                                      out_relu_mask=out_relu_mask, workspace=workspace)
     _, bb, wsc = mod.banks3w()
     return hip.conv3x3_x3w_unpool(gy_pooled, codes, honour_relu_bit, bb, wsc, mod.in_channels, 2 - mod.padding[0], out=out,
                                   out_relu_mask=out_relu_mask, dmat_bank=dmat_bank, dmat_inv_scale=dmat_inv_scale, workspace=workspace)
@@ -248,6 +285,15 @@ class Conv2d(nn.Conv2d):
             self._banks3w = hip.conv_pack_filters_x3w(self.weight.detach().contiguous())
             self._bank3w_key = key
         return self._banks3w
+
+    def banks3q(self):
+        """Banks of the 32-channel-chunk fp16x3 kernel (conv_x3q.hip): the same pre-split, pre-scaled fp16 pairs as banks3,
+        [chunk of 32][cout tile][tap][part][octet][co][8 ch]."""
+        key = (self.weight.data_ptr(), self.weight._version, self.weight.device)
+        if getattr(self, "_bank3q_key", None) != key:
+            self._banks3q = hip.conv_pack_filters_x3q(self.weight.detach().contiguous())
+            self._bank3q_key = key
+        return self._banks3q
 
     def banks_kxk(self):
         """fp16x2 pre-split, pre-scaled banks (forward, backward-data, filter scale) of the k x k fp16x3 kernel."""

@@ -291,6 +291,27 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     assert "x2" in d["config"]["parallelism"]
 
 
+def test_bench_allow_fewer_runs_on_what_is_there_and_says_so(tmp_path):
+    """`python bench.py --gpus 2 --allow_fewer` on a box with one GPU: one rank runs, the line says n_gpus 1 and requested_gpus 2 (the
+    driver's scaling run on a smaller node must not report a 2-GPU number it did not measure); the accuracy probe of the timed kernels
+    is measured in the run."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer devices than requested")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "MAUA_DIST_BACKEND")}
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--allow_fewer", "--size", "128", "--steps", "4",
+                          "--warmup", "1", "--history", "5", "--no_cpu_baseline"], capture_output=True, text=True, env=env, timeout=900,
+                         cwd=str(tmp_path))
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert "--allow_fewer" in out.stderr and "1 device(s) visible" in out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["requested_gpus"] == 2 and "2 GPUs requested" in d["note_gpus"] and d["value"] > 0
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) <= 1e-2 * d["value"]       # one rank's rate, not doubled
+    p = d["accuracy_probe"]
+    assert 0 < p["conv_x3w"] <= 1.5 * p["fp32_cpu_conv"] and 0 < p["conv_x3q"] <= 1.5 * p["fp32_cpu_conv"] and p["fp32_cpu_conv"] < 1e-6
+
+
 def test_bench_spawns_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` WITHOUT torchrun (the form the driver's scaling run uses): the parent starts two rank
     processes itself, never touches the GPU, and relays rank 0's line; the communicator's own size is reported."""
