@@ -186,6 +186,9 @@ int maua_conv_pack_filters_x3q(const float* w_oihw, void* bank_fwd, void* bank_b
 int maua_conv_x3q_supported(int cin, int h, int w, int pad);
 size_t maua_conv_x3q_workspace_bytes(int n, int cin, int h, int w, int cout, int pad);
 int maua_conv_x3q_split(int n, int cin, int h, int w, int cout, int pad);
+/* 1 where this geometry fills the kernel's 256 workgroup slots (one per CU) well enough to beat conv_x3w's finer tiles - the host side's
+ * routing rule, under the current batch hint; 0 otherwise. */
+int maua_conv_x3q_preferred(int n, int cin, int h, int w, int cout, int pad);
 int maua_conv3x3_x3q(const float* x, const void* bank, float w_scale, const float* bias, const float* out_relu_mask, float* y,
                      int n, int cin, int h, int w, int cout, int pad, int relu, int accumulate, void* workspace,
                      size_t workspace_bytes, maua_stream_t stream);

@@ -265,17 +265,25 @@ int conv_splitk_finish(const ConvArgs& a, int n, int ksplit, hipStream_t stream)
 // complete sums, which a split channel loop does not have): relu(bias + sum of the slabs) of a window's four elements - the additions in
 // conv_splitk_finish_kernel's order - then pool2x2_fwd_codes_kernel's decision (first maximum in scan order, NaN wins; bit 2 = not
 // positive) and its byte layout.  The full-size activation is not written.
+template <bool ALIGNED>  // (even output width: a window row is one 8-byte load; odd planes - floor-mode pooling - drop their last row / column)
 __global__ void __launch_bounds__(256)
 conv_splitk_finish_pool_kernel(const float* __restrict__ ws, const float* __restrict__ bias, float* __restrict__ pooled,
-                               unsigned char* __restrict__ codes, int ksplit, int Cout, int OW, int PW, int64_t pplane) {
+                               unsigned char* __restrict__ codes, int ksplit, int Cout, int OW, int PW, int64_t pplane, int64_t out_plane) {
     const int px = blockIdx.x * 256 + threadIdx.x, py = blockIdx.y;
     if (px >= PW) return;
     const int nc = blockIdx.z, n = nc / Cout, co = nc - n * Cout;  // (image, channel): one division per workgroup
-    const int64_t out_plane = 4 * pplane, per_n = (int64_t)Cout * out_plane;
+    const int64_t per_n = (int64_t)Cout * out_plane;
     const float* src = ws + (int64_t)n * ksplit * per_n + (int64_t)co * out_plane + (int64_t)(2 * py) * OW + 2 * px;
     float2 r0 = make_float2(0.f, 0.f), r1 = make_float2(0.f, 0.f);
     for (int k = 0; k < ksplit; ++k) {
-        const float2 a = *reinterpret_cast<const float2*>(src + (int64_t)k * per_n), c = *reinterpret_cast<const float2*>(src + (int64_t)k * per_n + OW);
+        float2 a, c;
+        if constexpr (ALIGNED) {
+            a = *reinterpret_cast<const float2*>(src + (int64_t)k * per_n);
+            c = *reinterpret_cast<const float2*>(src + (int64_t)k * per_n + OW);
+        } else {
+            a = make_float2(src[(int64_t)k * per_n], src[(int64_t)k * per_n + 1]);
+            c = make_float2(src[(int64_t)k * per_n + OW], src[(int64_t)k * per_n + OW + 1]);
+        }
         r0.x += a.x; r0.y += a.y; r1.x += c.x; r1.y += c.y;
     }
     const float b = bias ? bias[co] : 0.f;
@@ -294,8 +302,12 @@ conv_splitk_finish_pool_kernel(const float* __restrict__ ws, const float* __rest
 int conv_splitk_finish_pool(const ConvArgs& a, int n, int ksplit, hipStream_t stream) {
     const int PW = a.OW / 2, PH = a.OH / 2;
     dim3 grid((unsigned)((PW + 255) / 256), (unsigned)PH, (unsigned)(n * a.Cout));
-    hipLaunchKernelGGL(conv_splitk_finish_pool_kernel, grid, dim3(256), 0, stream, a.ws, a.bias, a.y, a.pool_codes, ksplit, a.Cout, a.OW, PW,
-                       (int64_t)PW * PH);
+    if (a.OW % 2 == 0)
+        hipLaunchKernelGGL(conv_splitk_finish_pool_kernel<true>, grid, dim3(256), 0, stream, a.ws, a.bias, a.y, a.pool_codes, ksplit, a.Cout, a.OW,
+                           PW, (int64_t)PW * PH, (int64_t)a.OH * a.OW);
+    else
+        hipLaunchKernelGGL(conv_splitk_finish_pool_kernel<false>, grid, dim3(256), 0, stream, a.ws, a.bias, a.y, a.pool_codes, ksplit, a.Cout, a.OW,
+                           PW, (int64_t)PW * PH, (int64_t)a.OH * a.OW);
     return check_launch("conv_splitk_finish_pool_kernel");
 }
 

@@ -556,7 +556,7 @@ __global__ void __launch_bounds__(XQ_THREADS, 2) conv_x3q_kernel(ConvArgs p, flo
 #pragma unroll
         for (int h = 0; h < 2; ++h) {  // column half of the tile
             const int oxx = x0 + 16 * h + px;
-            const bool store = (lane & 1) == 0 && oy + 1 < p.OH && oxx + 1 < p.OW;  // (even extents: a window is inside or outside)
+            const bool store = (lane & 1) == 0 && oy + 1 < p.OH && oxx + 1 < p.OW;  // (a window is inside or outside; an odd plane's last row / column has none)
             const int64_t ppix = (int64_t)(oy >> 1) * PW + (oxx >> 1);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -767,6 +767,33 @@ size_t maua_conv_x3q_workspace_bytes(int n, int cin, int h, int w, int cout, int
     return ks > 1 ? (size_t)n * ks * cout * a.OH * a.OW * sizeof(float) : 0;
 }
 
+int maua_conv_x3q_preferred(int n, int cin, int h, int w, int cout, int pad) {
+    // One fat workgroup per CU only pays where the grid fills the 256 slots evenly and every workgroup has a K loop long enough to
+    // carry its exposed prologue and epilogue (measured, profiles/probes_r04.md section 2: at 724 px - 181 x 181 and 90 x 90 planes,
+    // 288 and 432 workgroups - conv_x3w's finer tiles win by 15-20 %; at 1024 / 2048 px the grids are multiples of 256).
+    if (!conv_dims_ok(n, cin, h, w, cout, pad) || cin % 32 != 0) return 0;
+    ConvArgs a{};
+    a.Cin = cin;
+    a.Cout = cout;
+    a.OH = h + 2 * pad - 2;
+    a.OW = w + 2 * pad - 2;
+    if (a.OH <= 0 || a.OW <= 0) return 0;
+    static const double min_fill = [] {
+        const char* e = getenv("MAUA_X3Q_MIN_FILL");
+        return e ? atof(e) : 0.85;
+    }();
+    static const int min_chunks = [] {
+        const char* e = getenv("MAUA_X3Q_MIN_CHUNKS");
+        return e ? atoi(e) : 4;
+    }();
+    const int ks = x3q_choose_split(a, n);
+    const int64_t wgs = (int64_t)((a.OW + 31) / 32) * ((a.OH + XQ_ROWS - 1) / XQ_ROWS) * ((a.Cout + XQ_COT - 1) / XQ_COT) * split_batch_hint() * ks;
+    const double fill = (double)wgs / (double)(((wgs + 255) / 256) * 256);
+    // (ragged tiles count too: the pixels a 16 x 32 tile grid covers beyond the plane)
+    const double cover = (double)a.OH * a.OW / ((double)((a.OH + XQ_ROWS - 1) / XQ_ROWS * XQ_ROWS) * ((a.OW + 31) / 32 * 32));
+    return fill * cover >= min_fill && (cin / 32 + ks - 1) / ks >= min_chunks ? 1 : 0;
+}
+
 int maua_conv_x3q_split(int n, int cin, int h, int w, int cout, int pad) {
     if (!conv_dims_ok(n, cin, h, w, cout, pad)) return 0;
     ConvArgs a{};
@@ -801,7 +828,7 @@ static int conv3x3_x3q_entry(const float* x, const void* bank, float w_scale, co
     a.accumulate = accumulate;
     MAUA_REQUIRE(conv_x3q_supports(a), MAUA_E_UNSUPPORTED, "conv3x3_x3q: needs cin %% 32 == 0 and a plane of at most 2^24 pixels");
     if (in_codes) {
-        MAUA_REQUIRE(h % 2 == 0 && w % 2 == 0 && !accumulate, MAUA_E_UNSUPPORTED, "conv3x3_x3q_unpool: needs an even input plane, no accumulation");
+        MAUA_REQUIRE(h >= 2 && w >= 2 && !accumulate, MAUA_E_UNSUPPORTED, "conv3x3_x3q_unpool: needs an input plane of 2 x 2 and more, no accumulation");
         a.in_codes = in_codes;
         a.in_code_mask = in_code_mask;
     }
@@ -835,8 +862,8 @@ int maua_conv3x3_x3q_relu_pool(const float* x, const void* bank, float w_scale, 
     a.OW = w + 2 * pad - 2;
     a.pad = pad;
     a.relu = 1;
-    MAUA_REQUIRE(a.OH >= 2 && a.OW >= 2 && a.OH % 2 == 0 && a.OW % 2 == 0 && cout % 8 == 0 && conv_x3q_supports(a), MAUA_E_UNSUPPORTED,
-                 "conv3x3_x3q_relu_pool: needs an even output plane, cin %% 32 == 0, cout %% 8 == 0");
+    MAUA_REQUIRE(a.OH >= 2 && a.OW >= 2 && cout % 8 == 0 && conv_x3q_supports(a), MAUA_E_UNSUPPORTED,
+                 "conv3x3_x3q_relu_pool: needs an output plane of 2 x 2 and more, cin %% 32 == 0, cout %% 8 == 0");
     // without a workspace: one pass over the channels, the epilogue holds complete sums and pools them itself
     a.ws = (workspace && workspace_bytes >= maua_conv_x3q_workspace_bytes(n, cin, h, w, cout, pad)) ? (float*)workspace : nullptr;
     return conv_x3q_launch(a, n, w_scale, (hipStream_t)stream);

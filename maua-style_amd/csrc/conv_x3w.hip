@@ -655,7 +655,7 @@ __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_in
         float* __restrict__ py = p.y + (int64_t)n * p.Cout * pplane;
         unsigned char* __restrict__ pc = p.pool_codes + (int64_t)n * p.Cout * pplane;
         const int oy = y0 + 2 * wave, oxx = x0 + j;
-        const bool store = (lane & 1) == 0 && oy + 1 < p.OH && oxx + 1 < p.OW;  // (even extents: a window is inside or outside)
+        const bool store = (lane & 1) == 0 && oy + 1 < p.OH && oxx + 1 < p.OW;  // (a window is inside or outside; an odd plane's last row / column has none)
         const int64_t ppix = (int64_t)(oy >> 1) * PW + (oxx >> 1);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -926,7 +926,7 @@ static int conv3x3_x3w_entry(const float* x, const void* bank, float w_scale, co
         a.dinv = dinv;
     }
     if (in_codes) {
-        MAUA_REQUIRE(h % 2 == 0 && w % 2 == 0 && !accumulate, MAUA_E_UNSUPPORTED, "conv3x3_x3w_unpool: needs an even input plane, no accumulation");
+        MAUA_REQUIRE(h >= 2 && w >= 2 && !accumulate, MAUA_E_UNSUPPORTED, "conv3x3_x3w_unpool: needs an input plane of 2 x 2 and more, no accumulation");
         a.in_codes = in_codes;
         a.in_code_mask = in_code_mask;
     }
@@ -971,8 +971,8 @@ int maua_conv3x3_x3w_relu_pool(const float* x, const void* bank, float w_scale, 
     a.OW = w + 2 * pad - 2;
     a.pad = pad;
     a.relu = 1;
-    MAUA_REQUIRE(a.OH >= 2 && a.OW >= 2 && a.OH % 2 == 0 && a.OW % 2 == 0 && cout % 8 == 0 && conv_x3w_supports(a), MAUA_E_UNSUPPORTED,
-                 "conv3x3_x3w_relu_pool: needs an even output plane, cin %% 16 == 0, cout %% 8 == 0");
+    MAUA_REQUIRE(a.OH >= 2 && a.OW >= 2 && cout % 8 == 0 && conv_x3w_supports(a), MAUA_E_UNSUPPORTED,
+                 "conv3x3_x3w_relu_pool: needs an output plane of 2 x 2 and more, cin %% 16 == 0, cout %% 8 == 0");
     // without a workspace: one pass over the channels, the epilogue holds complete sums and pools them itself
     a.ws = (workspace && workspace_bytes >= maua_conv_x3w_workspace_bytes(n, cin, h, w, cout, pad)) ? (float*)workspace : nullptr;
     return conv_x3w_launch(a, n, w_scale, (hipStream_t)stream);

@@ -305,13 +305,24 @@ __device__ __forceinline__ int64_t pool_code_index(int64_t image_channel, int64_
     return ((image_channel >> 3) * pooled_plane + pooled_pixel) * 8 + (image_channel & 7);  // (C % 8 == 0: n * C + c keeps c's low bits)
 }
 
+// Planes of any extent >= 2 (round 4): `MaxPool2d(2, 2)` is floor mode (/root/reference/models.py:120), an odd plane's last row / column
+// belongs to no window - it is not read on the way forward and gets a zero gradient on the way back.  ALIGNED (even width): the two
+// elements of a window row are one 8-byte access.
+template <bool ALIGNED>
 __global__ void __launch_bounds__(256)
-pool2x2_fwd_codes_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ codes, int W, int OW) {
+pool2x2_fwd_codes_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ codes, int H, int W, int OW) {
     const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y;
     if (ox >= OW) return;
     const int64_t OHl = gridDim.y;
-    const float* p = x + ((int64_t)blockIdx.z * 2 * OHl + 2 * oy) * W + 2 * ox;
-    const float2 r0 = *reinterpret_cast<const float2*>(p), r1 = *reinterpret_cast<const float2*>(p + W);
+    const float* p = x + ((int64_t)blockIdx.z * H + 2 * oy) * W + 2 * ox;
+    float2 r0, r1;
+    if constexpr (ALIGNED) {
+        r0 = *reinterpret_cast<const float2*>(p);
+        r1 = *reinterpret_cast<const float2*>(p + W);
+    } else {
+        r0 = make_float2(p[0], p[1]);
+        r1 = make_float2(p[W], p[W + 1]);
+    }
     float m = r0.x;
     int arg = 0;
     if (r0.y > m || r0.y != r0.y) { m = r0.y; arg = 1; }
@@ -322,20 +333,33 @@ pool2x2_fwd_codes_kernel(const float* __restrict__ x, float* __restrict__ y, uns
     codes[pool_code_index(blockIdx.z, OHl * OW, oy * (int64_t)OW + ox)] = (unsigned char)(arg | (m > 0.f ? 0 : 4));
 }
 
+template <bool ALIGNED>
 __global__ void __launch_bounds__(256)
-pool2x2_bwd_codes_kernel(const float* __restrict__ gy, const unsigned char* __restrict__ codes, float* __restrict__ gx, int W,
+pool2x2_bwd_codes_kernel(const float* __restrict__ gy, const unsigned char* __restrict__ codes, float* __restrict__ gx, int H, int W,
                          int OW, int relu_mask) {
     const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y;
     if (ox >= OW) return;
     const int64_t OHl = gridDim.y;
-    const int64_t base = ((int64_t)blockIdx.z * 2 * OHl + 2 * oy) * W + 2 * ox;
+    const int64_t base = ((int64_t)blockIdx.z * H + 2 * oy) * W + 2 * ox;
     const int64_t o = ((int64_t)blockIdx.z * OHl + oy) * OW + ox;
     const int code = codes[pool_code_index(blockIdx.z, OHl * OW, oy * (int64_t)OW + ox)];
     const int arg = code & 3;
     float g = gy[o];
     if (relu_mask && (code & 4)) g = 0.f;
-    *reinterpret_cast<float2*>(gx + base) = make_float2(arg == 0 ? g : 0.f, arg == 1 ? g : 0.f);
-    *reinterpret_cast<float2*>(gx + base + W) = make_float2(arg == 2 ? g : 0.f, arg == 3 ? g : 0.f);
+    if constexpr (ALIGNED) {
+        *reinterpret_cast<float2*>(gx + base) = make_float2(arg == 0 ? g : 0.f, arg == 1 ? g : 0.f);
+        *reinterpret_cast<float2*>(gx + base + W) = make_float2(arg == 2 ? g : 0.f, arg == 3 ? g : 0.f);
+    } else {
+        gx[base] = arg == 0 ? g : 0.f;
+        gx[base + 1] = arg == 1 ? g : 0.f;
+        gx[base + W] = arg == 2 ? g : 0.f;
+        gx[base + W + 1] = arg == 3 ? g : 0.f;
+        if (ox == OW - 1) gx[base + 2] = gx[base + W + 2] = 0.f;  // (odd width: the column no window owns)
+    }
+    if ((H & 1) && oy == (int)OHl - 1) {  // odd height: the row no window owns
+        gx[base + 2 * W] = gx[base + 2 * W + 1] = 0.f;
+        if ((W & 1) && ox == OW - 1) gx[base + 2 * W + 2] = 0.f;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -518,23 +542,31 @@ int maua_pool2d_bwd(const float* gy, const float* x, float* gx, int n, int c, in
 }
 
 int maua_pool2x2_codes_supported(int n, int c, int h, int w) {
-    return conv_dims_ok(n, c, h, w, 1, 0) && h % 2 == 0 && w % 2 == 0 && c % 8 == 0 && (int64_t)n * c <= 65535 && h / 2 <= 65535;
+    return conv_dims_ok(n, c, h, w, 1, 0) && h >= 2 && w >= 2 && c % 8 == 0 && (int64_t)n * c <= 65535 && h / 2 <= 65535;
 }
 
 int maua_pool2x2_fwd_codes(const float* x, float* y, unsigned char* codes, int n, int c, int h, int w, maua_stream_t stream) {
     MAUA_REQUIRE(x && y && codes, MAUA_E_INVAL, "pool2x2_fwd_codes: null pointer");
-    MAUA_REQUIRE(maua_pool2x2_codes_supported(n, c, h, w), MAUA_E_UNSUPPORTED, "pool2x2_fwd_codes: needs even planes and c %% 8 == 0");
-    hipLaunchKernelGGL(pool2x2_fwd_codes_kernel, dim3((w / 2 + 255) / 256, h / 2, n * c), dim3(256), 0, (hipStream_t)stream, x, y,
-                       codes, w, w / 2);
+    MAUA_REQUIRE(maua_pool2x2_codes_supported(n, c, h, w), MAUA_E_UNSUPPORTED, "pool2x2_fwd_codes: needs planes of 2 x 2 and more, c %% 8 == 0");
+    if (w % 2 == 0)
+        hipLaunchKernelGGL(pool2x2_fwd_codes_kernel<true>, dim3((w / 2 + 255) / 256, h / 2, n * c), dim3(256), 0, (hipStream_t)stream, x, y,
+                           codes, h, w, w / 2);
+    else
+        hipLaunchKernelGGL(pool2x2_fwd_codes_kernel<false>, dim3((w / 2 + 255) / 256, h / 2, n * c), dim3(256), 0, (hipStream_t)stream, x, y,
+                           codes, h, w, w / 2);
     return check_launch("pool2x2_fwd_codes_kernel");
 }
 
 int maua_pool2x2_bwd_codes(const float* gy, const unsigned char* codes, float* gx, int n, int c, int h, int w, int relu_mask,
                            maua_stream_t stream) {
     MAUA_REQUIRE(gy && gx && codes, MAUA_E_INVAL, "pool2x2_bwd_codes: null pointer");
-    MAUA_REQUIRE(maua_pool2x2_codes_supported(n, c, h, w), MAUA_E_UNSUPPORTED, "pool2x2_bwd_codes: needs even planes and c %% 8 == 0");
-    hipLaunchKernelGGL(pool2x2_bwd_codes_kernel, dim3((w / 2 + 255) / 256, h / 2, n * c), dim3(256), 0, (hipStream_t)stream, gy,
-                       codes, gx, w, w / 2, relu_mask);
+    MAUA_REQUIRE(maua_pool2x2_codes_supported(n, c, h, w), MAUA_E_UNSUPPORTED, "pool2x2_bwd_codes: needs planes of 2 x 2 and more, c %% 8 == 0");
+    if (w % 2 == 0)
+        hipLaunchKernelGGL(pool2x2_bwd_codes_kernel<true>, dim3((w / 2 + 255) / 256, h / 2, n * c), dim3(256), 0, (hipStream_t)stream, gy,
+                           codes, gx, h, w, w / 2, relu_mask);
+    else
+        hipLaunchKernelGGL(pool2x2_bwd_codes_kernel<false>, dim3((w / 2 + 255) / 256, h / 2, n * c), dim3(256), 0, (hipStream_t)stream, gy,
+                           codes, gx, h, w, w / 2, relu_mask);
     return check_launch("pool2x2_bwd_codes_kernel");
 }
 

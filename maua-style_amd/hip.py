@@ -84,6 +84,7 @@ SIGNATURES = {
     "maua_conv_x3q_supported": (c_i, [c_i, c_i, c_i, c_i]),
     "maua_conv_x3q_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "maua_conv_x3q_split": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    "maua_conv_x3q_preferred": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "maua_conv3x3_x3q": (c_i, [c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "maua_conv3x3_x3q_relu_pool": (c_i, [c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "maua_conv3x3_x3q_unpool": (c_i, [c_p, c_p, c_i, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
@@ -331,6 +332,10 @@ def conv_x3q_workspace_bytes(n, cin, h, w, cout, pad):
     return lib().maua_conv_x3q_workspace_bytes(n, cin, h, w, cout, pad)
 
 
+def conv_x3q_preferred(n, cin, h, w, cout, pad):
+    return bool(lib().maua_conv_x3q_preferred(int(n), int(cin), int(h), int(w), int(cout), int(pad)))
+
+
 def conv_x3q_split(n, cin, h, w, cout, pad):
     return int(lib().maua_conv_x3q_split(int(n), int(cin), int(h), int(w), int(cout), int(pad)))
 
@@ -343,6 +348,17 @@ def conv3x3_x3q(x, bank, w_scale, bias, cout, pad, relu, out=None, out_relu_mask
     _check(lib().maua_conv3x3_x3q(_ptr(_f32(x, "x")), bank.data_ptr(), float(w_scale), _ptr(bias), _ptr(out_relu_mask), _ptr(out), n,
                                   cin, h, w, cout, pad, int(relu), int(accumulate), wp, wn, _stream()), "maua_conv3x3_x3q")
     return out
+
+
+def _unpooled_hw(ph, pw, pad, out):
+    """Extent of the plane a 2x2 / 2 floor-mode max pool reduced to ph x pw: taken from the output the caller provides (the plane may be
+    odd: 181 -> 90), 2 ph x 2 pw without one."""
+    if out is None:
+        return 2 * ph, 2 * pw
+    h, w = out.shape[2] - 2 * pad + 2, out.shape[3] - 2 * pad + 2
+    if h // 2 != ph or w // 2 != pw:
+        raise ValueError(f"unpool: a {ph}x{pw} pooled map does not come from a {h}x{w} plane")
+    return h, w
 
 
 def conv3x3_x3q_relu_pool(x, bank, w_scale, bias, cout, pad, pooled, codes, workspace=None):
@@ -359,7 +375,7 @@ def conv3x3_x3q_unpool(pooled_x, codes, honour_relu_bit, bank, w_scale, cout, pa
     """Backward-data pass on conv_x3q.hip staged straight from the pooled map's gradient and the pool's decision bytes
     (conv3x3_x3w_unpool's contract, without the Gram term)."""
     n, cin, hp, wp_ = pooled_x.shape
-    h, w = 2 * hp, 2 * wp_
+    h, w = _unpooled_hw(hp, wp_, pad, out)
     if out is None:
         out = torch.empty(n, cout, h + 2 * pad - 2, w + 2 * pad - 2, device=pooled_x.device, dtype=torch.float32)
     wp, wn = _ws_args(workspace, conv_x3q_workspace_bytes(n, cin, h, w, cout, pad) if workspace is None else 0, pooled_x.device)
@@ -433,7 +449,7 @@ def conv3x3_x3w_unpool(pooled_x, codes, honour_relu_bit, bank, w_scale, cout, pa
     pool's backward pass happens while the kernel stages its input); with `dmat_bank`, the Gram backward of the style loss on the
     layer's input (out_relu_mask = F) goes along as in conv3x3_x3w_gram."""
     n, cin, ph, pw = pooled_x.shape
-    h, w = 2 * ph, 2 * pw
+    h, w = _unpooled_hw(ph, pw, pad, out)
     if out is None:
         out = torch.empty(n, cout, h + 2 * pad - 2, w + 2 * pad - 2, device=pooled_x.device, dtype=torch.float32)
     wp, wn = _ws_args(workspace, conv_x3w_workspace_bytes(n, cin, h, w, cout, pad) if workspace is None else 0, pooled_x.device)

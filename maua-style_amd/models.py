@@ -74,14 +74,14 @@ X3Q_UNPOOL_MIN_CHANNELS = 512  # conv_x3q's unpooling form pays from here: its c
                                # (measured in the network: conv4_4's backward pass 181 -> 176 us, conv3_4's 186 -> 207)
 
 
-def conv3x3_is_x3q(consumed, h, w, pad, at_least=0):
+def conv3x3_is_x3q(consumed, h, w, pad, at_least=0, produced=None, n=1):
     """Whether a 3x3 stride-1 pass that consumes `consumed` channels of an h x w plane runs on conv_x3q.hip (forward: consumed = the
     layer's input channels, pad = its padding; backward-data: its output channels, 2 - padding).  `at_least`: a higher channel bound
     for this pass (the backward pass of a conv + ReLU + pool group: the same kernel family whether or not the pool's backward pass is
     fused into it, so that the fusion changes no bit)."""
     mc = max(_x3q_min_channels(), at_least) if _x3q_min_channels() > 0 else 0
     return _x3_enabled() and _x3w_enabled() and mc > 0 and consumed >= mc and h * w >= _x3w_min_pixels() and \
-        hip.conv_x3q_supported(consumed, h, w, pad)
+        hip.conv_x3q_supported(consumed, h, w, pad) and (produced is None or hip.conv_x3q_preferred(n, consumed, h, w, produced, pad))
 
 
 _X3W_MIN_PIXELS = None
@@ -107,7 +107,7 @@ def conv3x3_mfma(x, mod, backward, out=None, out_relu_mask=None, relu=False, acc
     else:
         cout, p, bias = mod.out_channels, pad, mod.bias_device()
     consumed = mod.out_channels if backward else mod.in_channels
-    if conv3x3_is_x3q(consumed, x.shape[2], x.shape[3], p, X3Q_UNPOOL_MIN_CHANNELS if pool_group else 0):
+    if conv3x3_is_x3q(consumed, x.shape[2], x.shape[3], p, X3Q_UNPOOL_MIN_CHANNELS if pool_group else 0, cout, x.shape[0]):
         bf, bb, wsc = mod.banks3q()
         return hip.conv3x3_x3q(x, bb if backward else bf, wsc, bias, cout, p, relu, out=out, out_relu_mask=out_relu_mask,
                                accumulate=accumulate, workspace=workspace)
@@ -139,7 +139,7 @@ def conv3x3_fwd_is_x3w(mod, h, w):
 def conv3x3_relu_pool(x, mod, pooled, codes, workspace=None):
     """conv + bias + ReLU + the 2x2 / 2 max pool behind it without the full-size activation (hip.conv3x3_x3w_relu_pool: one launch, or -
     small grids, with a workspace - a split channel loop whose adding pass pools)."""
-    if conv3x3_is_x3q(mod.in_channels, x.shape[2], x.shape[3], mod.padding[0]):
+    if conv3x3_is_x3q(mod.in_channels, x.shape[2], x.shape[3], mod.padding[0], 0, mod.out_channels, x.shape[0]):
         bf, _, wsc = mod.banks3q()
         return hip.conv3x3_x3q_relu_pool(x, bf, wsc, mod.bias_device(), mod.out_channels, mod.padding[0], pooled, codes, workspace=workspace)
     bf, _, wsc = mod.banks3w()
@@ -167,8 +167,8 @@ def conv3x3_bwd_from_pooled(gy_pooled, codes, honour_relu_bit, mod, out, out_rel
     """Backward-data pass of a conv + ReLU + 2x2 max pool group from the gradient of the POOLED map and the pool's decision bytes
     (hip.conv3x3_x3w_unpool): the pool's backward pass happens while the kernel stages its input; with `dmat_bank`, the Gram backward
     of the style loss on the layer's input goes along (out_relu_mask = that activation)."""
-    if dmat_bank is None and conv3x3_is_x3q(mod.out_channels, 2 * gy_pooled.shape[2], 2 * gy_pooled.shape[3], 2 - mod.padding[0],
-                                            X3Q_UNPOOL_MIN_CHANNELS):
+    if dmat_bank is None and conv3x3_is_x3q(mod.out_channels, out.shape[2], out.shape[3], 2 - mod.padding[0], X3Q_UNPOOL_MIN_CHANNELS,
+                                            mod.in_channels, gy_pooled.shape[0]):
         _, bb, wsc = mod.banks3q()
         return hip.conv3x3_x3q_unpool(gy_pooled, codes, honour_relu_bit, bb, wsc, mod.in_channels, 2 - mod.padding[0], out=out,
                                       out_relu_mask=out_relu_mask, workspace=workspace)

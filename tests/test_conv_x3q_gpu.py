@@ -183,7 +183,8 @@ def test_conv3x3_x3q_index_exact(hip):
         assert torch.equal(y.cpu(), F.conv2d(x, w, padding=1)), tap
 
 
-@pytest.mark.parametrize("n,cin,cout,H,W", [(1, 256, 256, 64, 64), (1, 512, 512, 64, 96), (2, 128, 200, 66, 70), (1, 64, 64, 130, 96)])
+@pytest.mark.parametrize("n,cin,cout,H,W", [(1, 256, 256, 64, 64), (1, 512, 512, 64, 96), (2, 128, 200, 66, 70), (1, 64, 64, 130, 96),
+                                           (1, 256, 256, 45, 91), (2, 128, 200, 33, 70), (1, 512, 64, 181, 181)])  # odd planes: floor-mode pooling
 def test_x3q_conv_relu_pool_in_one_launch(hip, n, cin, cout, H, W):
     """maua_conv3x3_x3q_relu_pool (conv3_4 / conv4_4 shapes among them): bit for bit maua_conv3x3_x3q + maua_pool2x2_fwd_codes in the
     one-pass and the split-K form, and max_pool2d(relu(conv2d)) in fp64 to 2e-6 with decision bytes that name a maximum of the fp64
@@ -224,6 +225,9 @@ UNPOOL_CASES = [
     (256, 256, 66, 70, 1),         # conv3_4's channels, ragged tiles (even plane)
     (512, 512, 64, 64, 1),         # conv4_4: split-K at this size
     (32, 200, 18, 260, 1),         # ragged cout tile of the produced gradient
+    (256, 256, 65, 71, 1),         # odd planes (724 / 1448-px images: 181 -> 90): the last row / column belongs to no window
+    (128, 128, 45, 45, 2),
+    (512, 512, 91, 64, 1),
 ]
 
 
@@ -251,7 +255,8 @@ def test_x3q_backward_pass_straight_from_the_pooled_gradient(hip, cg, c, H, W, n
     for mask in (None, dev(fmap)):
         for ws in (None, one_pass_ws()):
             two = hip.conv3x3_x3q(full, bb, wsc, None, c, 1, False, out_relu_mask=mask, workspace=ws)
-            one = hip.conv3x3_x3q_unpool(dev(gp), codes, relu_bit, bb, wsc, c, 1, out_relu_mask=mask, workspace=ws)
+            one = hip.conv3x3_x3q_unpool(dev(gp), codes, relu_bit, bb, wsc, c, 1, out=torch.empty(n, c, H, W, device="cuda"), out_relu_mask=mask,
+                                               workspace=ws)
             torch.cuda.synchronize()
             assert torch.equal(one, two), (mask is not None, ws is not None)
         assert rel_l2(one.cpu(), ref * (fmap > 0) if mask is not None else ref) <= BAR

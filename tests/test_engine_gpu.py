@@ -47,7 +47,7 @@ def check_against_golden(g, losses, slots, total, grad, tol_loss=TOL_LOSS, tol_g
     assert rel_l2(grad.cpu(), g["grad"]) <= tol_grad
 
 
-@pytest.mark.parametrize("S,variant", [(32, v) for v in FEVAL_VARIANTS] + [(64, "default"), (64, "no_grad_norm")])
+@pytest.mark.parametrize("S,variant", [(32, v) for v in FEVAL_VARIANTS] + [(64, "default"), (64, "no_grad_norm"), (90, "default"), (130, "default")])
 def test_engine_feval_matches_reference(weight_files, S, variant):
     import engine
     g = gold(f"feval_vgg19_S{S}_{variant}")
@@ -587,7 +587,8 @@ def test_pixel_gradient_is_as_close_to_fp64_as_the_reference_fp32(weight_files):
     fp64 reference as the reference's own fp32 arithmetic does (fixtures hold both), not merely inside a loose tolerance."""
     import engine
     import optim
-    for S, name, temporal in ((32, "feval_vgg19_S32_default", False), (64, "feval_temporal_default_S64", True)):
+    for S, name, temporal in ((32, "feval_vgg19_S32_default", False), (64, "feval_temporal_default_S64", True), (90, "feval_vgg19_S90_default", False),
+                              (130, "feval_vgg19_S130_default", False)):
         g32, g64 = gold(name), gold(name + "_f64")
         args = product_args(weight_files, S=S)
         content, style, init = synth.images(S)
@@ -737,6 +738,37 @@ def test_pool_backward_in_the_convolution_staging_changes_no_bit(weight_files, m
     assert res["0"][2] == 0 and res["1"][2] >= 3 and res["1"][3] == res["1"][2], res["1"][2:]
     assert torch.isfinite(res["1"][1]).all()
     assert torch.equal(res["0"][0], res["1"][0]) and torch.equal(res["0"][1], res["1"][1])
+
+
+@pytest.mark.parametrize("S", [130, 362])
+def test_odd_planes_take_the_fused_pool_paths_and_change_no_bit(weight_files, monkeypatch, S):
+    """Floor-mode pooling of an odd plane (`nn.MaxPool2d(2, 2)`, /root/reference/models.py:120; the reference's default sizes 724 and
+    1448 give 181 -> 90): the decision bytes, the pooling epilogue and the unpooling staging serve odd planes too (the last row / column
+    belongs to no window: not read on the way forward, zero gradient on the way back).  S = 130 pools a 65 x 65 plane, S = 362 a
+    181 x 181 and a 45 x 45 one.  Every pool keeps its decisions; with and without the fusions: the same bits."""
+    import engine
+    res = {}
+    for flags in (("0", "0"), ("1", "1")):
+        monkeypatch.setenv("MAUA_FUSE_POOL", flags[0])
+        monkeypatch.setenv("MAUA_FUSE_UNPOOL", flags[1])
+        monkeypatch.setenv("MAUA_DEBUG_POISON", "1")
+        args = product_args(weight_files, S=S)
+        content, style, init = synth.images(S)
+        net, losses = build(args, content, [style], S)
+        eng = engine.StyleEngine(net, losses)
+        slots, total, grad = eng.feval(init.cuda())
+        torch.cuda.synchronize()
+        pools = [s for s in eng.steps if s.kind == "pool"]
+        odd = [s for s in pools if eng.act[s.src].shape[2] % 2 == 1]
+        res[flags] = (slots.clone().cpu(), grad.clone().cpu(), len(eng.pool_codes), len(pools), len(odd),
+                      sum(1 for s in odd if id(s) in eng.pooled_by_conv), sum(1 for s in odd if id(s) in eng.unpooled_by_conv))
+    off, on = res[("0", "0")], res[("1", "1")]
+    assert on[2] == on[3] == 4 and on[4] >= 1                      # every pool keeps decision bytes, odd planes among them
+    assert off[5] == off[6] == 0
+    big_odd = 1 if S == 130 else 1                                  # 65 x 65 (S = 130) / 181 x 181 (S = 362) run the wide kernels; 45 x 45 does not
+    assert on[5] >= big_odd and on[6] >= big_odd, on[2:]
+    assert torch.isfinite(on[1]).all()
+    assert torch.equal(off[0], on[0]) and torch.equal(off[1], on[1])
 
 
 def test_pool_backward_in_the_convolution_staging_on_a_frame_batch(weight_files, monkeypatch):

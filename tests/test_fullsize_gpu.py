@@ -314,6 +314,64 @@ def test_config2_512_lbfgs_graph_equals_eager_and_descends(weight_files):
     assert math.isfinite(after) and after < 0.95 * before, (before, after)  # no line search: slow start
 
 
+@pytest.mark.parametrize("S", [724, 1448])
+def test_default_image_sizes_with_odd_planes(weight_files, S):
+    """The reference's default `--image_sizes 256,512,724,1024,1448` (/root/reference/config.py:23, config/args-img.json:9): at 724 and
+    1448 px the plane in front of the third / fourth pool is 181 x 181, and `nn.MaxPool2d(2, 2)` (models.py:120, floor mode) drops
+    its last row and column.  The decision-byte pools, the pooling epilogue and the unpooling staging serve those planes (round 4).
+    Checked at full size: deterministic evaluation, gradient = directional derivative, the odd layer's pooled output and its input
+    gradient on crops against fp64 (far corner included: the row / column no window owns), hipGraph replay = eager launches."""
+    import torch.nn.functional as F
+    import hip
+    import optim
+    args, net, losses, eng, x = _engine_for(weight_files, S, ["--no_grad_norm"])
+    _check_determinism_and_slope(eng, x, 0.5, 2e-2)
+    eng.feval(x)
+    torch.cuda.synchronize()
+    pools = [s for s in eng.steps if s.kind == "pool"]
+    assert len(eng.pool_codes) == len(pools) == 4
+    odd = [s for s in pools if eng.act[s.src].shape[2] % 2 == 1 and eng.act[s.src].shape[2] >= 64]
+    assert [tuple(eng.act[s.src].shape[2:]) for s in odd] == [(181, 181)]
+    pool = odd[0]
+    assert id(pool) in eng.pooled_by_conv and id(pool) in eng.unpooled_by_conv      # fused both ways
+    step = next(s for s in eng.steps if s.kind == "conv" and s.dst == pool.src)
+    mod, a_in, pooled = step.mod, eng.act[step.src], eng.act[pool.dst]
+    assert tuple(pooled.shape[2:]) == (90, 90) and eng.act[step.dst].is_meta and eng.gbuf[step.dst].is_meta
+    # forward: pooled crop = max_pool2d(relu(conv)) of the window it depends on, in fp64 and in the reference's fp32 arithmetic
+    for py0, px0 in ((0, 0), (40, 31), (74, 74)):     # pooled rows 74..89 read input rows 147..180 of 181 (row 180 feeds no window)
+        res = {}
+        for dt in (torch.float64, torch.float32):
+            full = torch.relu(_crop_reference(a_in, mod.weight.detach(), mod.bias.detach(), 2 * py0, 2 * px0, 32, 1, dt))
+            res[dt] = F.max_pool2d(full, 2, 2)
+        mine = pooled[:, :, py0:py0 + 16, px0:px0 + 16].cpu()
+        floor = rel_l2(res[torch.float32], res[torch.float64])
+        assert rel_l2(mine, res[torch.float64]) <= max(1.5 * floor, 1e-7), (S, "fwd", (py0, px0))
+    # backward: g[input] = [input > 0] * conv_transpose(unpool(g[pooled])) on crops, the far corner included
+    g_full = hip.pool2x2_bwd_codes(eng.gbuf[pool.dst], eng.pool_codes[id(pool)], torch.empty(eng.act[step.dst].shape, device="cuda"), True)
+    assert float(g_full[:, :, 180, :].abs().max()) == 0.0 and float(g_full[:, :, :, 180].abs().max()) == 0.0
+    w_eff = mod.weight.detach().flip(2, 3).transpose(0, 1).contiguous()
+    g_in = eng.gbuf[step.src]
+    for y0, x0 in ((0, 0), (80, 61), (149, 149)):
+        mask = a_in[:, :, y0:y0 + 32, x0:x0 + 32].cpu() > 0
+        res = {dt: _crop_reference(g_full, w_eff, None, y0, x0, 32, 1, dt) * mask for dt in (torch.float64, torch.float32)}
+        mine = g_in[:, :, y0:y0 + 32, x0:x0 + 32].cpu()
+        floor = rel_l2(res[torch.float32], res[torch.float64])
+        assert rel_l2(mine, res[torch.float64]) <= max(1.5 * floor, 1e-7), (S, "bwd", (y0, x0))
+    # hipGraph replay = eager launches, and the iterations descend
+    before = float(eng.feval(x)[1])
+    outs = []
+    for flag in (True, False):
+        args.hip_graph = flag
+        opt = optim.PixelOptimizer(net, losses, x.cpu(), args)
+        for _ in range(12):
+            opt.step()
+        torch.cuda.synchronize()
+        outs.append(opt.x.clone())
+    assert torch.equal(outs[0], outs[1])
+    after = float(eng.feval(outs[0])[1])
+    assert math.isfinite(after) and after < before, (before, after)
+
+
 def test_config5_nin_covariance_1024(weight_files):
     """NIN + --use_covariance at 1024x1024 (BASELINE config 5): the odd-sized maps (254 / 127 / 63 / 31), the strided stem,
     the 5x5 and split 1x1 kernels and the ceil-mode pools at their real grids - determinism, directional derivative,

@@ -924,7 +924,7 @@ def test_deprocess_u8_is_bit_exact(hip):
     assert np.array_equal(np.asarray(load.deprocess(dev(x))), want.numpy())  # device tensors take the kernel
 
 
-@pytest.mark.parametrize("shape", [(1, 64, 128, 256), (2, 8, 34, 66), (1, 512, 16, 16)])
+@pytest.mark.parametrize("shape", [(1, 64, 128, 256), (2, 8, 34, 66), (1, 512, 16, 16), (1, 64, 181, 181), (2, 8, 33, 66), (1, 16, 90, 45)])
 def test_pool2x2_with_kept_decisions_equals_the_recomputing_pair(hip, shape):
     """maua_pool2x2_fwd_codes / _bwd_codes against maua_pool2d_fwd / _bwd (which recompute the arg-max from the input): the
     same bits, ties, zeros (ReLU inputs) and NaNs included."""

@@ -53,7 +53,7 @@ def test_synthetic_inputs_regenerate_identically():
         assert synth.checksum(sd[k]) == want
 
 
-@pytest.mark.parametrize("S,variant", [(32, v) for v in FEVAL_VARIANTS] + [(64, "default"), (64, "no_grad_norm")])
+@pytest.mark.parametrize("S,variant", [(32, v) for v in FEVAL_VARIANTS] + [(64, "default"), (64, "no_grad_norm"), (90, "default"), (130, "default")])
 def test_feval_matches_reference(S, variant):
     g = gold(f"feval_vgg19_S{S}_{variant}")
     cfg = make_cfg(**FEVAL_VARIANTS[variant])

@@ -825,13 +825,26 @@ def gen_imgvid():
     save("imgvid_S64", **res)
 
 
-GROUPS = {"imgvid": gen_imgvid, "traj_extra": gen_traj_extra, "batch": gen_batch, "vid": gen_vid, "temporal": gen_temporal, "cli": gen_cli, "traj64v": gen_traj_variants64, "feval": gen_feval, "traj": gen_traj, "nin": gen_nin, "hist": gen_hist, "host": gen_host}
+def gen_feval_odd():
+    """Odd planes behind the floor-mode pools (the reference's default --image_sizes 724 / 1448 give 181 -> 90): S = 90
+    (90, 45, 22, 11, 5: odd planes pooled twice) and S = 130 (130, 65, 32, 16, 8: an odd plane LARGE enough for the fused conv + ReLU +
+    pool / unpooling launches of the wide kernels), default flags, fp32 and the fp64 arbiter."""
+    print("[feval_odd] single forward/backward fixtures at S = 90 and S = 130")
+    for S in (90, 130):
+        content, style, init = synth.images(S)
+        for double in (False, True):
+            out, _ = single_feval(get_args([], S=S), content, [style], init, double=double)
+            out["input_checksums"] = np.array([synth.checksum(t) for t in (content, style, init)])
+            save(f"feval_vgg19_S{S}_default" + ("_f64" if double else ""), **out)
+
+
+GROUPS = {"feval_odd": gen_feval_odd, "imgvid": gen_imgvid, "traj_extra": gen_traj_extra, "batch": gen_batch, "vid": gen_vid, "temporal": gen_temporal, "cli": gen_cli, "traj64v": gen_traj_variants64, "feval": gen_feval, "traj": gen_traj, "nin": gen_nin, "hist": gen_hist, "host": gen_host}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     want = sys.argv[1:] or ["all"]
     if "all" in want:
-        want = [g for g in GROUPS if g not in ("traj64v", "cli", "vid")] + ["cli", "vid"]
+        want = [g for g in GROUPS if g not in ("traj64v", "cli", "vid", "feval_odd")] + ["cli", "vid"]
     for gname in want:
         GROUPS[gname]()
     meta = {"torch": torch.__version__, "threads": 1, "numpy": np.__version__,
