@@ -130,6 +130,8 @@ class StyleEngine:
         self.shape = tuple(x.shape)
         self.prepared_for = (self.independent, self.batch_hint)
         self.graph = None
+        self.alloc_epoch = getattr(self, "alloc_epoch", 0) + 1  # every buffer below is new: graphs captured over the old ones are void
+        self.iter_graphs = {}
         shapes = {0: tuple(x.shape)}
         for s in self.steps:
             n, c, h, w = shapes[s.src]
@@ -834,7 +836,11 @@ class StyleEngine:
                 if id(s) not in self.pooled_by_conv:
                     hip.pool2d_fwd(a[s.src], s.k, s.stride, s.ceil, s.mode, out=a[s.dst])
         for s in want:
-            s.mod.target = a[s.src].detach().clone()
+            t = getattr(s.mod, "target", None)
+            if torch.is_tensor(t) and t.shape == a[s.src].shape and t.device == a[s.src].device and t.dtype == a[s.src].dtype:
+                t.copy_(a[s.src])  # in place: a captured iteration (optim.PixelOptimizer's graph bundles) that reads this target stays valid
+            else:
+                s.mod.target = a[s.src].detach().clone()
 
     def _graph_key(self):
         """Everything a captured evaluation bakes in besides the image: the addresses and shapes of every target / weight

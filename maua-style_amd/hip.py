@@ -897,6 +897,11 @@ class LbfgsState:
         self._status = torch.zeros(5, dtype=torch.float32, device=device)
         _check(lib().maua_lbfgs_init(self.buf.data_ptr(), nbytes, self.count, self.history, _stream()), "maua_lbfgs_init")
 
+    def reset(self):
+        """Back to the state of a new object (no pairs, iteration 0) in the same memory: a captured graph that holds this state's
+        address serves the next optimisation problem."""
+        _check(lib().maua_lbfgs_init(self.buf.data_ptr(), self.buf.numel(), self.count, self.history, _stream()), "maua_lbfgs_init")
+
     def iterate(self, x, grad, lr=1.0, tolerance_change=-1.0, tolerance_grad=-1.0, loss=None):
         """One trip of LBFGS.step's loop; `loss` (device scalar of the evaluation that produced `grad`) feeds the
         |loss - prev_loss| < tolerance_change test and may be None."""

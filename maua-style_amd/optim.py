@@ -152,14 +152,18 @@ def lbfgs_moves(num_iters):
 
 
 GRAPH_MIN_ITERS = 128
+GRAPH_MIN_ITERS_REPEATED = 20  # ... for calls the caller announces it will repeat on the same network and shapes (vid_img's frame batches)
 
 
 class PixelOptimizer:
     """The iteration loop for one image: fused feval + device-side optimizer step."""
 
-    def __init__(self, net, losses, init, args, planned_iters=None, grad_hook=None, independent=False, batch_hint=1):
+    def __init__(self, net, losses, init, args, planned_iters=None, grad_hook=None, independent=False, batch_hint=1, repeated=False):
         """`independent`: `init` holds B separate single-frame problems (vid_img's frames without optical flow) that are
-        evaluated together - one L-BFGS state (or Adam moment pair) per frame, the single-frame loss arithmetic per frame."""
+        evaluated together - one L-BFGS state (or Adam moment pair) per frame, the single-frame loss arithmetic per frame.
+        `repeated`: the caller will run more problems of this shape on this network (vid_img: one call per frame batch and pass):
+        the captured iteration is kept with its image buffer and optimiser states (a "bundle" on the engine) and the next call
+        replays it from its first iteration on - content / temporal targets are rewritten in place, so the graph stays valid."""
         self.args = args
         self.independent = bool(independent) and init.shape[0] > 1
         self.grad_hook = grad_hook  # in-place edit of the gradient before the optimiser sees it (img_vid's overlap masking)
@@ -177,9 +181,28 @@ class PixelOptimizer:
             self.engine.independent, self.engine.batch_hint = self.independent, self.batch_hint
         elif self.independent:
             raise engine_mod.UnsupportedNet("independent frame batches need the fused engine")
+        # A bundle of an earlier call on this network: same shapes, same optimiser parameters, and nothing the captured graph
+        # baked in has moved since (engine buffers: alloc_epoch; targets / weights / coefficients: _graph_key)
+        self._bundle_key, bundle = None, None
+        if self.engine is not None and self.kind == "lbfgs" and grad_hook is None and os.environ.get("MAUA_GRAPH_BUNDLES", "1") != "0":
+            self._bundle_key = ("lbfgs", tuple(self.x.shape), self.independent, self.batch_hint, int(args.lbfgs_num_correction),
+                                float(args.lbfgs_tolerance_change), float(args.lbfgs_tolerance_grad))
+            self.engine._prepare(self.x)  # (allocates for this shape if the engine last served another one: a new epoch)
+            bundle = self.engine.iter_graphs.get(self._bundle_key)
+            if bundle is not None and (bundle["epoch"] != self.engine.alloc_epoch or bundle["graph_key"] != self.engine._graph_key()):
+                bundle = None
+                del self.engine.iter_graphs[self._bundle_key]
+        if bundle is not None:
+            bundle["x"].copy_(self.x)
+            self.x = bundle["x"]
         self.frames = [self.x[b] for b in range(self.x.shape[0])] if self.independent else [self.x]
         if self.kind == "lbfgs":
-            self.states = [hip.LbfgsState(f.numel(), int(args.lbfgs_num_correction), self.x.device) for f in self.frames]
+            if bundle is not None:
+                self.states = bundle["states"]
+                for st in self.states:
+                    st.reset()
+            else:
+                self.states = [hip.LbfgsState(f.numel(), int(args.lbfgs_num_correction), self.x.device) for f in self.frames]
             self.state = self.states[0]
         elif self.kind == "adam":
             self.m, self.v = th.zeros_like(self.x), th.zeros_like(self.x)
@@ -192,9 +215,12 @@ class PixelOptimizer:
         # call) launch eagerly.
         hg = getattr(args, "hip_graph", None)
         if hg is None:
-            hg = os.environ.get("MAUA_HIP_GRAPH", "1") != "0" and (planned_iters is None or planned_iters >= GRAPH_MIN_ITERS)
+            enough = planned_iters is None or planned_iters >= (GRAPH_MIN_ITERS_REPEATED if repeated and self._bundle_key else GRAPH_MIN_ITERS)
+            hg = os.environ.get("MAUA_HIP_GRAPH", "1") != "0" and (enough or bundle is not None)
         self.use_graph = bool(hg)
-        self._graph = None
+        self._graph = bundle["graph"] if (bundle is not None and self.use_graph) else None
+        self._keep_bundle = bool(repeated) and self._bundle_key is not None
+        self.owns_x = bundle is None and not self._keep_bundle  # (else `x` lives on in the bundle: callers get a copy)
 
     def feval(self):
         """(loss slots, total, gradient) at the current image - device tensors, no sync."""
@@ -266,6 +292,9 @@ class PixelOptimizer:
                 self.grad_hook(self.engine.gbuf[0])
             self._lbfgs_move(self.engine.gbuf[0], self.engine.total)
         self._graph = graph
+        if self._keep_bundle:
+            self.engine.iter_graphs[self._bundle_key] = {"graph": graph, "x": self.x, "states": self.states, "epoch": self.engine.alloc_epoch,
+                                                         "graph_key": self.engine._graph_key()}
         return slots, total
 
     def step(self):
@@ -403,11 +432,12 @@ def optimize_frames(contents, styles, inits, num_iters, args, net, losses, plann
     if args.normalize_weights:
         for mod in net.content_losses + net.style_losses + net.temporal_losses:
             mod.strength = mod.strength / max(mod.target.size())
-    opt = PixelOptimizer(net, losses, inits, args, planned_iters=num_iters, independent=True, batch_hint=hint)
+    opt = PixelOptimizer(net, losses, inits, args, planned_iters=num_iters, independent=True, batch_hint=hint,
+                         repeated=not args.normalize_weights)  # (compounding strengths change the graph's coefficients every call)
     _run_iterations(opt, num_iters, args)
     for mod in losses:
         mod.loss = 0
-    return opt.x.detach()
+    return opt.x.detach() if opt.owns_x else opt.x.detach().clone()
 
 
 def optimize(content, styles, init, num_iters, args, net=None, losses=None, keep_on_device=False):
@@ -449,9 +479,11 @@ def optimize(content, styles, init, num_iters, args, net=None, losses=None, keep
         for mod in net.content_losses + net.style_losses + net.temporal_losses:
             mod.strength = mod.strength / max(mod.target.size())
 
-    opt = PixelOptimizer(net, losses, init, args, planned_iters=num_iters)
+    opt = PixelOptimizer(net, losses, init, args, planned_iters=num_iters, repeated=bool(getattr(args, "_maua_repeated_calls", False)))
     _run_iterations(opt, num_iters, args)
 
     for mod in losses:
         mod.loss = 0
-    return opt.x.detach() if keep_on_device else opt.x.detach().cpu()
+    if not keep_on_device:
+        return opt.x.detach().cpu()
+    return opt.x.detach() if opt.owns_x else opt.x.detach().clone()

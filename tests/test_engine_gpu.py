@@ -771,6 +771,37 @@ def test_odd_planes_take_the_fused_pool_paths_and_change_no_bit(weight_files, mo
     assert torch.equal(off[0], on[0]) and torch.equal(off[1], on[1])
 
 
+def test_iteration_graph_is_captured_once_per_network_and_changes_no_bit(weight_files, monkeypatch):
+    """vid_img calls optim.optimize_frames once per frame batch and pass on the same network (reference style.py:192-290: one
+    optim.optimize per frame).  The captured iteration - evaluation + L-BFGS update, with its image buffer and optimiser states - is
+    kept on the engine and replayed by the next call from its first iteration on; content targets are rewritten in place.  Three
+    calls with different frames: the same bits as with eager launches, one capture."""
+    import models
+    import optim
+    S, B, N = 128, 3, 24
+    style = synth.images(S)[1]
+    out = {}
+    for mode in ("bundles", "eager"):
+        monkeypatch.setenv("MAUA_HIP_GRAPH", "1" if mode == "bundles" else "0")
+        args = product_args(weight_files, optimizer="lbfgs", S=S, N=N)
+        optim.set_model_args(args, S)
+        net, losses = models.load_model(args)
+        res, graphs = [], []
+        for call in range(3):
+            contents = torch.cat([synth.images(S, seed=70 + 10 * call + k)[0] for k in range(B)])
+            inits = torch.cat([synth.images(S, seed=80 + 10 * call + k)[2] for k in range(B)])
+            r = optim.optimize_frames(contents.cuda(), [style], inits.cuda(), N, args, net, losses)
+            res.append(r.cpu())
+            eng = net._maua_engine
+            graphs.append([id(b["graph"]) for b in eng.iter_graphs.values()])
+        out[mode] = (res, graphs)
+    assert out["eager"][1] == [[], [], []]
+    assert len(out["bundles"][1][0]) == 1 and out["bundles"][1][0] == out["bundles"][1][1] == out["bundles"][1][2]   # captured once
+    for a, b in zip(out["bundles"][0], out["eager"][0]):
+        assert torch.equal(a, b)
+    assert not torch.equal(out["bundles"][0][0], out["bundles"][0][1])       # (the calls did solve different problems)
+
+
 def test_pool_backward_in_the_convolution_staging_on_a_frame_batch(weight_files, monkeypatch):
     """The same on optim.optimize_frames (three frames through every launch, grid z = frame): bit-identical results with and without."""
     import models
