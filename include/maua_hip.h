@@ -17,7 +17,8 @@
  *    asynchronously on it, nothing synchronises, so calls can be captured into a hipGraph;
  *  - return value: 0 = ok, <0 = invalid argument / unsupported shape (MAUA_E_*), >0 = hipError_t
  *    of the failed launch; maua_last_error() gives a thread-local message;
- *  - no global mutable state besides that message: thread-safe across streams;
+ *  - no process-wide mutable state: the message and the split-K batch hint (maua_set_split_batch_hint) are per host thread, so
+ *    concurrent jobs on their own threads and streams do not interfere;
  *  - reductions are fixed-order (no float atomics): reruns are bit-identical, like the reference
  *    at a fixed thread count.
  */
@@ -390,8 +391,9 @@ int maua_deprocess_u8(const float* x_bgr_chw, unsigned char* out_rgb_hwc, int h,
  * slabs a layer is cut into is a cost-model decision that would depend on n.  To keep a frame's result independent of how
  * many frames happen to share a launch, the cost models count the frames the CALLER PLANS per launch: the host sets that
  * number once per job (style.vid_img: frames_per_batch(size); 1 = single images, the default) and every launch of the job -
- * a full batch, the short last batch, a single frame - uses the same split.  Process-wide setting, read at launch time and by
- * the *_workspace_bytes functions (set it before sizing workspaces). */
+ * a full batch, the short last batch, a single frame - uses the same split.  A setting of the calling host thread (round 4; it was
+ * process-wide before), read at launch time and by the *_workspace_bytes functions on that thread (set it before sizing
+ * workspaces): concurrent jobs with different plans run on a thread each. */
 void maua_set_split_batch_hint(int frames);
 int maua_get_split_batch_hint(void);
 

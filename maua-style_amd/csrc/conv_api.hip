@@ -8,8 +8,9 @@ using namespace maua;
 
 namespace maua {
 // Frames the caller plans to evaluate per launch (see maua_set_split_batch_hint): the split-K cost models count
-// `frames` images' worth of workgroups, whatever the batch size of the launch at hand.
-static int g_split_batch_hint = 1;
+// `frames` images' worth of workgroups, whatever the batch size of the launch at hand.  Per host thread, like the error
+// message: two jobs with different plans in one process (one thread each) do not see each other's value.
+static thread_local int g_split_batch_hint = 1;
 int split_batch_hint() { return g_split_batch_hint; }
 }  // namespace maua
 
@@ -18,7 +19,8 @@ static inline bool mfma_geometry(int kh, int kw, int stride) {
 }
 // a 3x3 pass that produces <= 4 channels from many (conv1_1 backward-data) is vector-ALU work, not an MFMA tile
 static int conv_route(const ConvArgs& a, int ks, int n, hipStream_t stream) {
-    if (ks == 3 && a.Cout <= 4 && a.Cin >= 16 && !getenv("MAUA_CONV_NO_FEW_OUT")) return conv3x3_few_out(a, n, stream);
+    static const bool few_out = getenv("MAUA_CONV_NO_FEW_OUT") == nullptr;  // (experiment switch, read once)
+    if (ks == 3 && a.Cout <= 4 && a.Cin >= 16 && few_out) return conv3x3_few_out(a, n, stream);
     return conv_mfma_dispatch(a, ks, n, stream);
 }
 

@@ -337,12 +337,14 @@ static int launch2(const ConvArgs& a, int n, hipStream_t stream) {
     return launch2e<KS, TCO, TPX, TL, MASK, false, false>(a, n, stream);
 }
 
+// Round 4: this fp32-MFMA route is the general entry point's arithmetic (maua_conv2d_fwd / _bwd_data) and the A/B reference of the
+// split-precision kernels (MAUA_CONV_X6=0), not the product's hot path: one tile shape per filter size and two-level accumulation
+// always (24 kernel instances instead of 112: the library shrinks by 2 MB; the single-level and small-grid variants bought 5-10 % on
+// geometries nothing dispatches here any more).
 template <int KS, int TCO, int TPX>
 static int launch2_variant(const ConvArgs& a, int n, hipStream_t stream) {
-    static const int tl_env = getenv("MAUA_CONV_TL") ? atoi(getenv("MAUA_CONV_TL")) : -1;  // experiment switch
-    const bool tl = tl_env >= 0 ? tl_env != 0 : (a.Cin + 7) / 8 > 4;  // two-level accumulation only where the K loop is long
-    if (a.mask) return tl ? launch2<KS, TCO, TPX, true, true>(a, n, stream) : launch2<KS, TCO, TPX, false, true>(a, n, stream);
-    return tl ? launch2<KS, TCO, TPX, true, false>(a, n, stream) : launch2<KS, TCO, TPX, false, false>(a, n, stream);
+    if (a.mask) return launch2<KS, TCO, TPX, true, true>(a, n, stream);
+    return launch2<KS, TCO, TPX, true, false>(a, n, stream);
 }
 
 // Split the channel loop when the output grid is far too small for 256 CUs (deep 1x1 layers on 31x31 maps ...).
@@ -361,18 +363,11 @@ int conv_mfma2_choose_split(const ConvArgs& a, int ks, int n) {
 int conv_mfma_dispatch(const ConvArgs& a0, int ks, int n, hipStream_t stream) {
     ConvArgs a = a0;
     a.ksplit = a.ws ? conv_mfma2_choose_split(a, ks, n) : 1;
-    const int64_t opix = (int64_t)a.OH * a.OW;
-    const int64_t co_tiles = (a.Cout + 63) / 64;
-    const int64_t big_tiles = (ks == 1) ? (opix + 255) / 256 : (int64_t)((a.OW + 31) / 32) * ((a.OH + 7) / 8);
-    const bool small_rows = big_tiles * co_tiles * n < 512;
-    const bool narrow_co = a.Cout <= 32;
     switch (ks) {
         case 1:
-            if (narrow_co) return launch2_variant<1, 1, 2>(a, n, stream);
-            return small_rows ? launch2_variant<1, 2, 1>(a, n, stream) : launch2_variant<1, 2, 2>(a, n, stream);
+            return launch2_variant<1, 2, 1>(a, n, stream);
         case 3:
-            if (narrow_co) return launch2_variant<3, 1, 2>(a, n, stream);
-            return small_rows ? launch2_variant<3, 2, 1>(a, n, stream) : launch2_variant<3, 2, 2>(a, n, stream);
+            return launch2_variant<3, 2, 1>(a, n, stream);
         case 5:  // 25 taps x 64 channels of filters would leave one workgroup per CU: 32-channel tiles keep two
             return launch2_variant<5, 1, 2>(a, n, stream);
         default:
