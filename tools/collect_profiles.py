@@ -8,8 +8,8 @@ import subprocess
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rr = sys.argv[1] if len(sys.argv) > 1 else "03"
-src = os.path.join(REPO, sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/r3fin")
+rr = sys.argv[1] if len(sys.argv) > 1 else "04"
+src = os.path.join(REPO, sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/r4fin")
 dst = os.path.join(REPO, "profiles")
 
 
@@ -19,7 +19,7 @@ def last_json(path):
 
 
 def conv_avg(stats_csv):
-    rows = [r for r in csv.DictReader(open(stats_csv)) if "conv_x3w_kernel" in r["Name"]]
+    rows = [r for r in csv.DictReader(open(stats_csv)) if "conv_x3w_kernel" in r["Name"] or "conv_x3q_kernel" in r["Name"]]
     t, c = sum(float(r["TotalDurationNs"]) for r in rows), sum(int(r["Calls"]) for r in rows)
     return t / c / 1e3, c
 
@@ -50,11 +50,11 @@ note = f"""
 Everything of an iteration is in stream order at this size (the Gram / loss chains moved off the side stream in round 3: their partial
 kernels go out in two launches behind the forward pass; images of 1536² and more still overlap them with the convolutions).  `bench.py`
 brackets every convolution launch with HIP events in a pass of its own, and this trace is what its `roofline.avg_launch_ms` has to agree with:
-**{s_avg:.1f} µs here ({s_calls} launches of the `conv_x3w_kernel` variants) against {under['roofline']['avg_launch_ms'] * 1e3:.1f} µs in `bench_r{rr}_under_rocprof.json`** (the JSON
+**{s_avg:.1f} µs here ({s_calls} launches of the `conv_x3w_kernel` and `conv_x3q_kernel` variants) against {under['roofline']['avg_launch_ms'] * 1e3:.1f} µs in `bench_r{rr}_under_rocprof.json`** (the JSON
 line of this very run: the events also see the launch gaps of an eager run under the profiler).  Unprofiled, the same figure is
 {graph['roofline']['avg_launch_ms'] * 1e3:.1f} µs (`bench_r{rr}_final_1024_lbfgs.json`, {graph['value']:.1f} it/s with graph replay).
 
-What the variants are (template arguments ACC, OM, POOL, UNPOOL): `<false,false,false,false>` plain forward / backward-data launches;
+What the variants are (template arguments ACC, OM, POOL, UNPOOL; `conv_x3q_kernel` = the 256+ channel passes since round 4, `conv_x3w_kernel` the others): `<false,false,false,false>` plain forward / backward-data launches;
 `<false,true,false,false>` backward-data with the ReLU mask of the produced gradient in the epilogue, one of them carrying the Gram backward of
 relu3_1 (`maua_conv3x3_x3w_gram`); `<false,true,false,true>` the backward passes of conv1_2 / 2_2 / 3_4 / 4_4 staged from the POOLED map's gradient
 and the pool's decision bytes (`maua_conv3x3_x3w_unpool`; conv1_2 / conv2_2 with the Gram backward of relu1_1 / relu2_1 along);

@@ -1,6 +1,6 @@
 set -x
 # (the *_clock.py tools below load diagnostic builds from tools/_build/: run tools/build_stamp_libs.sh in the container first, after any change to csrc/)
-R=$PWD; O=$R/gpurun_out/${ROUND_DIR:-r3fin}; mkdir -p $O
+R=$PWD; O=$R/gpurun_out/${ROUND_DIR:-r4fin}; mkdir -p $O
 python bench.py --steps 200 > $O/bench_graph.json 2> $O/bench_graph.err
 python bench.py --steps 100 --no_hip_graph --no_cpu_baseline --no_extra_sizes > $O/bench_eager.json 2>/dev/null
 cd /tmp; export TMPDIR=/tmp
@@ -25,8 +25,9 @@ python tools/run_configs.py --configs 2,3,4,5,6 --out $O/configs.json > $O/confi
 python tools/x3w_clock.py 512 512 128 > $O/clock_conv4_2.txt 2>&1
 python tools/x3w_clock.py 64 64 1024 > $O/clock_conv1_2.txt 2>&1
 python tools/bench_x3w.py 1024 5 10 > $O/x3_vs_x3w.txt 2>&1
-python tools/wino/bench_wino.py 1024 5 10 > $O/x3w_vs_wino.txt 2>&1
-python tools/wino/wino_clock.py 512 512 128 > $O/clock_wino_conv4_2.txt 2>&1
+python tools/x3q_clock.py 512 512 128 > $O/clock_x3q_conv4_2.txt 2>&1
+python tools/bench_x3q.py 1024 5 10 > $O/x3w_vs_x3q.txt 2>&1
+python tools/stress_x3q.py 30 > $O/stress_x3q.txt 2>&1
 python bench.py --model nin --steps 200 --no_cpu_baseline > $O/bench_nin.json 2>/dev/null
 python tools/lbfgs_clock.py 196608 100 > $O/clock_lbfgs.txt 2>&1
 python tools/bench_fused_gram.py 1024 20 > $O/fused_gram.txt 2>&1
