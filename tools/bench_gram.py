@@ -15,6 +15,13 @@ def timeit(f, reps=20):
 shapes = [("relu1_1", 64, 1 << 20), ("relu2_1", 128, 1 << 18), ("relu3_1", 256, 1 << 16), ("relu4_1", 512, 1 << 14), ("relu5_1", 512, 1 << 12),
           ("vid B6 relu1_1", 384, 1 << 18), ("vid B6 relu2_1", 768, 1 << 16), ("vid B6 relu3_1", 1536, 1 << 14), ("vid B6 relu4_1", 3072, 1 << 12),
           ("vid B6 relu5_1", 3072, 1 << 10)]
+if len(sys.argv) > 1 and sys.argv[1] == "sizes":  # every style layer of VGG-19 / NIN at the image sizes of the scale pyramid
+    shapes = []
+    for S in (256, 362, 512, 724, 1448, 2048):
+        for name, c, d in (("relu2_1", 128, 2), ("relu3_1", 256, 4), ("relu4_1", 512, 8), ("relu5_1", 512, 16)):
+            shapes.append((f"{S} {name}", c, (S // d) * (S // d)))
+    shapes += [("nin 512 relu3", 256, 63 * 63), ("nin 512 relu5", 256, 31 * 31), ("nin 512 relu7", 384, 15 * 15), ("nin 512 relu10", 1024, 15 * 15),
+               ("nin 1024 relu7", 384, 31 * 31), ("nin 1024 relu10", 1024, 31 * 31)]
 for name, c, hw in shapes:
     f = torch.relu(torch.randn(1, c, hw, 1, device="cuda"))
     ws = torch.empty(hip.gram_workspace_bytes(c, hw), dtype=torch.uint8, device="cuda")
