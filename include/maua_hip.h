@@ -255,8 +255,11 @@ int maua_pool2x2_bwd_codes(const float* gy, const unsigned char* codes, float* g
 /* ---- Gram / covariance matrix: loss.GramMatrix.forward, loss.py:67-91 (torch.mm at :91) ----------- */
 /* gram[C][C] = scale * Fc Fc^T with Fc = f[C][hw] (minus row means when `center` != 0, loss.py:87-89).
  * row_mean_out (nullable unless center): receives the C row means.  Split-K over hw with a fixed-order reduction.
- * workspace: maua_gram_workspace_bytes(C, hw) bytes. */
+ * workspace: maua_gram_workspace_bytes(C, hw) bytes.
+ * maua_gram_block: edge of the blocks the split-K kernel of this shape multiplies in - 64, or 128 with MAUA_GRAM_T128=1 (read once per
+ * process; 128+ channels, 4096+ pixels; one workgroup per CU, see gram.hip). */
 size_t maua_gram_workspace_bytes(int c, int64_t hw);
+int maua_gram_block(int c, int64_t hw);
 int maua_gram_fwd(const float* f, float* gram, float* row_mean_out, int c, int64_t hw, float scale, int center,
                   void* workspace, size_t workspace_bytes, maua_stream_t stream);
 
@@ -317,7 +320,7 @@ int maua_gram_fwd_mse_ledger(const float* f, float* gram, float* row_mean_out, i
  * `slots[i]` in `ledgers[i]` - with the same arithmetic in the same order: bit-identical results. */
 int maua_gram_partial(const float* f, float* row_mean_out, int c, int64_t hw, int center, void* workspace, size_t workspace_bytes,
                       maua_stream_t stream);
-/* maua_gram_partial for up to 8 layers at once - at most two partial launches (the layers of one 64-channel tile; the others)
+/* maua_gram_partial for up to 8 layers at once - at most three partial launches (the layers of one 64-channel tile; the others; those of 128 x 128 blocks)
  * and one first-level fold instead of one to two launches per layer; every layer keeps the plan of its own call: the same slabs, bit for
  * bit.  Host arrays of `count` entries.  slab_counts (nullable; also the last array of maua_gram_finish_mse_batch): an entry > 0 says that
  * the layer's workspace already holds that many 64 x 64 slabs (C <= 64: maua_conv3x3_image_gram) - no partial launch for it, only the

@@ -937,18 +937,17 @@ gram_bwd_kernel(const float* __restrict__ d, const float* __restrict__ f, const 
     }
 }
 
-// Layers of 128 channels and more multiply in 128 x 128 blocks (gram_x3_partial128_kernel, fp16x3 route only); MAUA_GRAM_T128=0: 64 x 64.
-static bool gram_tile128(int c) {
+// MAUA_GRAM_T128=1 (read once per process): layers of 128 channels and more multiply in 128 x 128 blocks (gram_x3_partial128_kernel, fp16x3
+// route only) on maps its 32-bit buffer offsets reach (row index up to c + 127) with 64 stages and more to share out.  Off by default: with
+// the one workgroup per CU it needs it is worth -1.3 % ... +0.75 % of an iteration (724 x 724 ... 2048 x 2048; profiles/probes_r04.md section 2).
+static bool gram_tile128(int c, int64_t hw) {
     static const bool on = [] {
         const char* e = getenv("MAUA_GRAM_T128");
         const char* x3 = getenv("MAUA_GRAM_X3");
-        return !(e && e[0] == '0') && !(x3 && x3[0] == '0');
+        return e && e[0] == '1' && !(x3 && x3[0] == '0');
     }();
-    return on && c >= 128;
+    return on && c >= 128 && hw >= 64 * GK && (int64_t)(c + 128) * hw < (1ll << 29);
 }
-// ... on maps its 32-bit buffer offsets reach (row index up to c + 127) with 64 stages and more to share out: below, a quarter as many
-// workgroups as 64 x 64 tiles give leave CUs idle (profiles/probes_r04.md section 2: 512 x 2025 27.2 us against 23.7, 1024 x 225 19.8 / 15.1)
-static bool gram_tile128(int c, int64_t hw) { return gram_tile128(c) && hw >= 64 * GK && (int64_t)(c + 128) * hw < (1ll << 29); }
 #ifndef MAUA_GRAM_T128_WGS
 #define MAUA_GRAM_T128_WGS 512  // (two rounds of one workgroup per CU)
 #endif
@@ -973,6 +972,8 @@ static void gram_plan(int c, int64_t hw, int* npairs, int* ksplit, int64_t* chun
 using namespace maua;
 
 extern "C" {
+
+int maua_gram_block(int c, int64_t hw) { return c > 0 && hw > 0 && gram_tile128(c, hw) ? 128 : 64; }
 
 size_t maua_gram_workspace_bytes(int c, int64_t hw) {
     if (c <= 0 || hw <= 0 || c > (1 << 16) || hw >= (1ll << 30)) return 0;

@@ -60,6 +60,7 @@ SIGNATURES = {
     "maua_pool2x2_fwd_codes": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "maua_pool2x2_bwd_codes": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "maua_gram_workspace_bytes": (c_sz, [c_i, c_i64]),
+    "maua_gram_block": (c_i, [c_i, c_i64]),
     "maua_gram_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i64, c_f, c_i, c_p, c_sz, c_p]),
     "maua_reduce_workspace_bytes": (c_sz, [c_i64]),
     "maua_mse_fwd_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_f, c_f, c_i, c_i, c_p, c_p, c_sz, c_p]),
@@ -631,6 +632,11 @@ def _ws(workspace, need, device):
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=device)
     return workspace
+
+
+def gram_block(c, hw):
+    """Edge of the blocks the Gram kernels multiply this shape in: 64, or 128 (MAUA_GRAM_T128=1, large layers)."""
+    return int(lib().maua_gram_block(int(c), int(hw)))
 
 
 def gram_fwd(f, scale, center=False, out=None, mean_out=None, workspace=None):

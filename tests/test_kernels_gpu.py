@@ -170,8 +170,7 @@ def test_relu(hip):
 
 @pytest.mark.parametrize("C,HW", [(64, 4096), (64, 1000), (96, 900), (128, 77), (256, 256), (512, 64), (512, 4), (384, 3969),
                                   (1024, 961), (3, 5),
-                                  # 128 x 128 blocks (128+ channels, 4096+ pixels): one / several tile pairs, ragged last stage, odd row pitch,
-                                  # a last tile with 64 / 104 of its 128 rows
+                                  # several tile pairs x several stages, ragged last stage, odd row pitch, ragged last tile
                                   (128, 16384), (256, 8100), (512, 4131), (192, 5000), (1000, 4200), (1024, 4096)])
 @pytest.mark.parametrize("center", [False, True])
 def test_gram_fwd_bwd(hip, C, HW, center):
@@ -235,8 +234,7 @@ def test_gram_survives_extreme_inputs(hip, kind):
 
 @pytest.mark.parametrize("C,HW,center", [(128, 4096, False), (256, 65536, False), (512, 16384, True), (1024, 4096, False), (512, 1024, False)])
 def test_gram_deterministic(hip, C, HW, center):
-    """The same bits on every launch, many workgroups per CU side by side (a build of the 128 x 128 kernel with three registers spilled to
-    scratch differed from run to run in a few 64 x 64 blocks: profiles/probes_r04.md section 2)."""
+    """The same bits on every launch, many workgroups per CU side by side."""
     f = dev(torch.relu(rnd(1, C, HW, 1, seed=14)))
     a, _ = hip.gram_fwd(f, 1e-3, center)
     for _ in range(12):
@@ -591,6 +589,22 @@ def test_conv1x1_x3_channel_shift_is_the_gram_centring(hip, cin, cout, hw):
     y = hip.conv1x1_x3(dev(x), dev(w), x_shift=dev(shift))
     torch.cuda.synchronize()
     assert rel_l2(y.cpu(), ref) <= 2e-6
+
+
+def test_gram_128_blocks_opt_in_subprocess():
+    """MAUA_GRAM_T128=1 (read once per process): layers of 128+ channels and 4096+ pixels multiply in 128 x 128 blocks.  tools/stress_gram.py
+    under that switch: every layer set against fp64 (<= 2e-5 with the means of the covariance sets), the batched launches bit for bit what the
+    per-layer launches leave, and the same bits on every one of 12 launches between LDS-scribbling convolutions."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path[:0] = [%r, %r]; import hip\n"
+            "print('blocks', hip.gram_block(128, 4096), hip.gram_block(512, 16384), hip.gram_block(512, 2025), hip.gram_block(64, 1 << 20))\n") % (REPO, PKG)
+    for flag, want in (("1", "blocks 128 128 64 64"), ("0", "blocks 64 64 64 64")):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MAUA_GRAM_T128=flag), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and want in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "stress_gram.py"), "12"], env=dict(os.environ, MAUA_GRAM_T128="1"),
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and "differing results: 0" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
 
 
 def test_gram_bwd_fp32_route_subprocess():
