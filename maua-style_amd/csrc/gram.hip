@@ -382,32 +382,34 @@ __device__ __forceinline__ void gram_x3_partial_body(const float* __restrict__ f
 }
 
 // The same partial product in 128 x 128 blocks, for layers of 128 channels and more: a workgroup = a PAIR of
-// 128-channel tiles x one slice of HW, a wave = a 64 x 64 sub-block = 2 x 2 accumulators of 32 x 32.  A 64 x 64 workgroup splits every
-// value it stages once for 12 MFMAs per wave and stage (~300 vector-ALU / LDS instructions: issue-bound, profiles/probes_r03.md section 6);
-// here a wave stages twice the values for 48 MFMAs - half the split and LDS-store work per product, 0.67 fragment reads per MFMA instead of
-// 1.33.  What it costs: eight accumulators + four masters would not fit beside the staged values, so the scale of a staging unit covers
-// its 32 rows x the whole 64-pixel stage (the 64 x 64 kernel: 32 x 32) and every block has ONE accumulator per stage; the fp16 planes of a
-// stage ([tile][part][128 rows][64 px]: 72 KB) are single-buffered - two barriers per stage - with one stage of loads in flight in registers.
+// 128-channel tiles x one slice of HW.  A 64 x 64 workgroup splits every value it stages once for 12 MFMAs per wave and stage (~300
+// vector-ALU / LDS instructions: issue-bound, profiles/probes_r03.md section 6); here a stage's values are split once for 48 MFMAs per
+// multiplying wave - half the split and LDS-store work per product, 0.67 fragment reads per MFMA instead of 1.33.
+//
+// Eight waves, ONE workgroup per CU, two ROLES (one wave of each per SIMD):
+//   waves 4 - 7 stage: wave w loads rows 32 w ... 32 w + 31 of both tiles, 64 pixels per stage, two stages of loads in flight in its
+//     registers; one power-of-two scale per (tile, its 32 rows, stage) from their maximum; the two fp16 parts go into the planes of the
+//     stage's LDS buffer ([tile][part][128 rows][64 px] = 72 KB, two buffers), the inverse scale beside them;
+//   waves 0 - 3 multiply: wave (wi, wj) owns the 64 x 64 sub-block = 2 x 2 accumulators of 32 x 32, folds them into fp32 masters with the
+//     product of the row-block and column-block inverse scales once per stage, and writes the slab of the 64-channel tile pair at the end.
+// ONE barrier per stage: behind it buffer st is complete and buffer st + 1 is free (the multiplying waves arrive with stage st - 1 done).
+// Every multiplying wave runs the same 48 MFMAs per stage - the mirrored sub-block of a diagonal pair is computed and not stored.
 // Same slabs (per 64 x 64 tile pair, in gram_partial_kernel's format), same finishing kernels.
 //
-// ONE workgroup per CU (GX128_LDS_EXCL of dynamic LDS asked for, 72 KB used).  With two per CU - diagonal and off-diagonal pairs side by
-// side on the SIMDs - a slab came out now and then with ONE accumulator register of a wave's (1, 1) block zero in lanes 48 - 63 (16 zeros in
-// a 64 x 64 block, a different block from launch to launch); never with one workgroup per CU.  Not explained: LDS and register
-// allocations do not overlap (tools/mfma_probe/lds_isolation.hip), 512 cycles of s_nop behind every k-step or in front of the fold change
-// nothing, an MFMA behind an EXEC restore is fine (tools/mfma_probe/exec_mfma_hazard.hip); profiles/probes_r04.md section 2 has the
-// experiments.  tools/stress_gram.py is the test that sees it.
+// Why not four waves that do both, two workgroups per CU (the first form: 1.3 - 1.9 x the 64 x 64 kernel): with two such waves on a
+// SIMD a slab came out now and then with ONE accumulator register of a wave's (1, 1) block zero in lanes 48 - 63 - 16 zeros in a 64 x 64
+// block, a different block from launch to launch - and never with one; not explained (profiles/probes_r04.md section 2 has the
+// experiments, tools/stress_gram.py is the test that sees it).  Here a SIMD has one wave that multiplies and one that does not.
 constexpr int GX128_PLANE = 128 * GXROW;             // one [row][px] plane of one part of one 128-channel tile
 constexpr int GX128_BUF = 2 * 2 * GX128_PLANE + 64;  // [tile][part] planes + inverse scales [tile][32-row block]
-constexpr int GX128_LDS_EXCL = 96 * 1024;            // more than half of a CU's 160 KB: no second workgroup beside this one
+constexpr int GX128_LDS = 2 * GX128_BUF;             // two stages: 144 KB
 
 __device__ __forceinline__ void gram_x3_partial128_body(const float* __restrict__ f, const float* __restrict__ mean, float* __restrict__ partial,
                                                         int C, int64_t HW, int ksplit, int64_t chunk, const int pair_index, const int ks) {
     extern __shared__ __attribute__((aligned(16))) float smem_f32[];
     unsigned char* smem = reinterpret_cast<unsigned char*>(smem_f32);
-    // (the wave number as a scalar: `skip` / `sub_diag` below branch on scc, no EXEC masks around the MFMAs)
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i32 = lane & 31, half = lane >> 5;
-    const int wi = wave >> 1, wj = wave & 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3;
     const int ntile128 = (C + 127) / 128, ntile64 = (C + GT - 1) / GT;
     int pair = pair_index, Ti = 0;
     while (pair >= ntile128 - Ti) {
@@ -416,98 +418,118 @@ __device__ __forceinline__ void gram_x3_partial128_body(const float* __restrict_
     }
     const int Tj = Ti + pair;
     const bool diag = Ti == Tj;
-    const int nplanes = diag ? 2 : 4;
-    float* inv_lds = reinterpret_cast<float*>(smem + nplanes * GX128_PLANE);
     const int64_t p_begin = (int64_t)ks * chunk;
     const int64_t p_end = min(HW, p_begin + chunk);
+    const int nstages = p_begin < p_end ? (int)((p_end - p_begin + GK - 1) / GK) : 0;
+    const int inv_off = 4 * GX128_PLANE;  // (the scales of a buffer: behind its four planes, whatever the pair uses of them)
 
-    // staging units of this wave (in each tile): rows wave * 32 + lane / 8 + 8 r (r < 4), pixels pxh * 32 + (lane % 8) * 4 .. + 3, pxh = 0, 1
-    const int srow = wave * 32 + (lane >> 3), spx = (lane & 7) * 4;
-    f32x4 ra[2][4], rb[2][4];  // one stage in flight: [pixel half][r] of tile i / tile j
-    // Loads through a buffer descriptor over the whole map (32-bit offsets: the host side sends maps of 2^29 values and more to the 64 x 64
-    // kernel): rows beyond C are beyond its range and come back as zeros; pixels beyond the slice are zeroed in the (wave-uniform) tail path.
-    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(f), 0, (unsigned)((int64_t)C * HW * 4), 0x00020000);
-    // (a unit's offset = one per-thread register + scalars, added per load: eight loop-carried offset registers are eight the wave does not have)
-    const unsigned vbase = ((unsigned)srow * (unsigned)HW + (unsigned)spx) * 4u;
-    auto load_unit = [&](f32x4 (&r4)[4], int tile, int64_t p0) {
-        unsigned vb = vbase;
-        asm volatile("" : "+v"(vb));
-        const unsigned sb = ((unsigned)(tile * 128) * (unsigned)HW + (unsigned)p0) * 4u;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            r4[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(frs, vb + (sb + (unsigned)(8 * r) * (unsigned)HW * 4u), 0, 0));
-        if (p0 + 32 > p_end) {  // wave-uniform: the slice's last, partial stage
-            const int left = (int)(p_end - p0) - spx;  // cells of this thread's four that exist (<= 0: none)
+    if (wave8 >= 4) {
+        // ---------------------------------------------------------------- staging waves
+        // units of this wave (in each tile): rows wave * 32 + lane / 8 + 8 r (r < 4), pixels pxh * 32 + (lane % 8) * 4 .. + 3, pxh = 0, 1
+        const int srow = wave * 32 + (lane >> 3), spx = (lane & 7) * 4;
+        f32x4 rr[2][2][2][4];  // [stage parity][tile i / j][pixel half][r]: two stages in flight
+        // Loads through a buffer descriptor over the whole map (32-bit offsets: the host side sends maps of 2^29 values and more to the 64 x 64
+        // kernel): rows beyond C are beyond its range and come back as zeros; pixels beyond the slice are zeroed in the (wave-uniform) tail path.
+        const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(f), 0, (unsigned)((int64_t)C * HW * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(mean ? mean : f), 0, mean ? (unsigned)C * 4u : 0u, 0x00020000);
+        const unsigned vbase = ((unsigned)srow * (unsigned)HW + (unsigned)spx) * 4u;
+        auto load_unit = [&](f32x4 (&r4)[4], int tile, int64_t p0) {
+            unsigned vb = vbase;
+            asm volatile("" : "+v"(vb));  // (a unit's offset = one per-thread register + scalars, added per load)
+            const unsigned sb = ((unsigned)(tile * 128) * (unsigned)HW + (unsigned)p0) * 4u;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (k >= left) r4[r][k] = 0.f;
-        }
-    };
-    const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(mean ? mean : f), 0, mean ? (unsigned)C * 4u : 0u, 0x00020000);
-    auto load_stage = [&](int64_t p0) {
-        load_unit(ra[0], Ti, p0);
-        load_unit(ra[1], Ti, p0 + 32);
-        if (!diag) {
-            load_unit(rb[0], Tj, p0);
-            load_unit(rb[1], Tj, p0 + 32);
-        }
-    };
-    // split the wave's 32 rows x 64 pixels of one tile (one scale from their maximum) and write them into the planes
-    auto store_tile = [&](f32x4 (&r4)[2][4], int tile_slot, int64_t p0) {
-        if (mean) {  // covariance form: centre the cells that exist (padding cells stay zero; rows beyond C read a mean of 0)
-            unsigned vm = (unsigned)srow * 4u;
-            asm volatile("" : "+v"(vm));
-            const unsigned sm = (unsigned)((tile_slot == 0 ? Ti : Tj) * 128) * 4u;
-            const bool tail = p0 + GK > p_end;  // wave-uniform
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                // (re-read per stage: the wave has no eight registers for the values)
-                const float mr = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mrs, vm + (sm + 32u * r), 0, 0));
+                r4[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(frs, vb + (sb + (unsigned)(8 * r) * (unsigned)HW * 4u), 0, 0));
+        };
+        auto load_stage = [&](f32x4 (&r)[2][2][4], int64_t p0) {
+            load_unit(r[0][0], Ti, p0);
+            load_unit(r[0][1], Ti, p0 + 32);
+            if (!diag) {
+                load_unit(r[1][0], Tj, p0);
+                load_unit(r[1][1], Tj, p0 + 32);
+            }
+        };
+        // split the wave's 32 rows x 64 pixels of one tile (one scale from their maximum) and write them into the planes of `buf`
+        auto store_tile = [&](f32x4 (&r4)[2][4], int tile_slot, int64_t p0, unsigned char* buf) {
+            if (p0 + GK > p_end) {  // wave-uniform: the slice's last, partial stage - cells beyond it are zeros
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    if (tail) {
-                        const int left = (int)(p_end - p0) - 32 * h - spx;
+                    const int left = (int)(p_end - p0) - 32 * h - spx;  // cells of this thread's four that exist (<= 0: none)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
-                            if (k < left) r4[h][r][k] -= mr;
-                    } else {
+                            if (k >= left) r4[h][r][k] = 0.f;
+                }
+            }
+            if (mean) {  // covariance form: centre the cells that exist (padding cells stay zero; rows beyond C read a mean of 0)
+                unsigned vm = (unsigned)srow * 4u;
+                asm volatile("" : "+v"(vm));
+                const unsigned sm = (unsigned)((tile_slot == 0 ? Ti : Tj) * 128) * 4u;
+                const bool tail = p0 + GK > p_end;  // wave-uniform
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) r4[h][r][k] -= mr;
+                for (int r = 0; r < 4; ++r) {
+                    const float mr = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mrs, vm + (sm + 32u * r), 0, 0));
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        if (tail) {
+                            const int left = (int)(p_end - p0) - 32 * h - spx;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                if (k < left) r4[h][r][k] -= mr;
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) r4[h][r][k] -= mr;
+                        }
                     }
                 }
             }
-        }
-        float m = 0.f;
+            float m = 0.f;
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                m = fmaxf(m, fmaxf(fmaxf(fabsf(r4[h][r][0]), fabsf(r4[h][r][1])), fmaxf(fabsf(r4[h][r][2]), fabsf(r4[h][r][3]))));
-        m = wave_max_nonneg(m);
-        int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu) - 127;
-        e = m > 0.f ? max(e, -100) : 11;
-        const float sx = __builtin_bit_cast(float, (unsigned)(127 + 11 - e) << 23);
-        if (lane == 0) inv_lds[tile_slot * 4 + wave] = __builtin_bit_cast(float, (unsigned)(127 + e - 11) << 23);
+                for (int r = 0; r < 4; ++r)
+                    m = fmaxf(m, fmaxf(fmaxf(fabsf(r4[h][r][0]), fabsf(r4[h][r][1])), fmaxf(fabsf(r4[h][r][2]), fabsf(r4[h][r][3]))));
+            m = wave_max_nonneg(m);
+            int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu) - 127;
+            e = m > 0.f ? max(e, -100) : 11;
+            const float sx = __builtin_bit_cast(float, (unsigned)(127 + 11 - e) << 23);
+            if (lane == 0) reinterpret_cast<float*>(buf + inv_off)[tile_slot * 4 + wave] = __builtin_bit_cast(float, (unsigned)(127 + e - 11) << 23);
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v0 = r4[h][r][0] * sx, v1 = r4[h][r][1] * sx, v2 = r4[h][r][2] * sx, v3 = r4[h][r][3] * sx;
-                const unsigned h0 = gx_cvt_pk(v0, v1), h1 = gx_cvt_pk(v2, v3);
-                const g16x2 hh0 = __builtin_bit_cast(g16x2, h0), hh1 = __builtin_bit_cast(g16x2, h1);
-                const unsigned l0 = gx_cvt_pk(v0 - (float)hh0[0], v1 - (float)hh0[1]), l1 = gx_cvt_pk(v2 - (float)hh1[0], v3 - (float)hh1[1]);
-                unsigned char* dst = smem + (tile_slot * 2) * GX128_PLANE + (srow + 8 * r) * GXROW + (32 * h + spx) * 2;
-                *reinterpret_cast<gu32x2*>(dst) = gu32x2{h0, h1};
-                *reinterpret_cast<gu32x2*>(dst + GX128_PLANE) = gu32x2{l0, l1};
+                for (int r = 0; r < 4; ++r) {
+                    const float v0 = r4[h][r][0] * sx, v1 = r4[h][r][1] * sx, v2 = r4[h][r][2] * sx, v3 = r4[h][r][3] * sx;
+                    const unsigned h0 = gx_cvt_pk(v0, v1), h1 = gx_cvt_pk(v2, v3);
+                    const g16x2 hh0 = __builtin_bit_cast(g16x2, h0), hh1 = __builtin_bit_cast(g16x2, h1);
+                    const unsigned l0 = gx_cvt_pk(v0 - (float)hh0[0], v1 - (float)hh0[1]), l1 = gx_cvt_pk(v2 - (float)hh1[0], v3 - (float)hh1[1]);
+                    unsigned char* dst = buf + (tile_slot * 2) * GX128_PLANE + (srow + 8 * r) * GXROW + (32 * h + spx) * 2;
+                    *reinterpret_cast<gu32x2*>(dst) = gu32x2{h0, h1};
+                    *reinterpret_cast<gu32x2*>(dst + GX128_PLANE) = gu32x2{l0, l1};
+                }
+        };
+        if (nstages > 0) load_stage(rr[0], p_begin);
+        if (nstages > 1) load_stage(rr[1], p_begin + GK);
+        // (two stages per trip: the register set of a stage is a compile-time index)
+        for (int st = 0; st < nstages; st += 2) {
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                const int s1 = st + par;
+                if (s1 < nstages) {  // wave-uniform
+                    unsigned char* buf = smem + par * GX128_BUF;
+                    const int64_t p0 = p_begin + (int64_t)s1 * GK;
+                    store_tile(rr[par][0], 0, p0, buf);
+                    if (!diag) store_tile(rr[par][1], 1, p0, buf);
+                    if (s1 + 2 < nstages) load_stage(rr[par], p0 + 2 * GK);
+                    __syncthreads();  // buffer `par` holds stage s1; the multiplying waves are done with the other one
+                }
             }
-    };
-    auto store_stage = [&](int64_t p0) {
-        store_tile(ra, 0, p0);
-        if (!diag) store_tile(rb, 1, p0);
-    };
-
+        }
+        return;
+    }
+    // -------------------------------------------------------------------- multiplying waves
+    const int i32 = lane & 31, half = lane >> 5;
+    const int wi = wave >> 1, wj = wave & 1;
     f32x16 master[2][2], acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -515,76 +537,61 @@ __device__ __forceinline__ void gram_x3_partial128_body(const float* __restrict_
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) master[a][b][r] = acc[a][b][r] = 0.f;
-    const bool skip = diag && wi == 1 && wj == 0;   // wave-uniform: the mirrored 64 x 64 sub-block of a diagonal pair
-    const bool sub_diag = diag && wi == wj;         // a diagonal 64 x 64 sub-block: its (1, 0) block is the transpose of (0, 1)
     const int bslot = diag ? 0 : 1;
     const int a_off = (wi * 64 + i32) * GXROW + half * 16;
     const int b_off = (bslot * 2) * GX128_PLANE + (wj * 64 + i32) * GXROW + half * 16;
-
-    const int64_t nstages = p_begin < p_end ? (p_end - p_begin + GK - 1) / GK : 0;
-    if (nstages > 0) {
-        load_stage(p_begin);
-        store_stage(p_begin);
-        if (nstages > 1) load_stage(p_begin + GK);
-        __syncthreads();
-        for (int64_t st = 0; st < nstages; ++st) {
-            float s_row[2], s_col[2];
-            if (!skip) {
+    for (int st = 0; st < nstages; ++st) {
+        __syncthreads();  // stage st is in its buffer
+        const unsigned char* buf = smem + (st & 1) * GX128_BUF;
+        const float* inv_lds = reinterpret_cast<const float*>(buf + inv_off);
+        float s_row[2], s_col[2];
 #pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    s_row[a] = inv_lds[2 * wi + a];
-                    s_col[a] = inv_lds[bslot * 4 + 2 * wj + a];
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    g16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) {
-                        ah[a] = *reinterpret_cast<const g16x8*>(smem + a_off + a * 32 * GXROW + q * 32);
-                        al[a] = *reinterpret_cast<const g16x8*>(smem + GX128_PLANE + a_off + a * 32 * GXROW + q * 32);
-                        bh[a] = *reinterpret_cast<const g16x8*>(smem + b_off + a * 32 * GXROW + q * 32);
-                        bl[a] = *reinterpret_cast<const g16x8*>(smem + GX128_PLANE + b_off + a * 32 * GXROW + q * 32);
-                    }
-#pragma unroll
-                    for (int a = 0; a < 2; ++a)
-#pragma unroll
-                        for (int b = 0; b < 2; ++b) {
-                            if (sub_diag && a == 1 && b == 0) continue;  // wave-uniform
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-                        }
-                    __builtin_amdgcn_sched_barrier(0);  // (one k-step's fragments at a time: hoisting the next steps' reads costs registers the wave does not have)
-                }
-            }
-            __syncthreads();  // every wave is done with the planes (and has its scales in registers)
-            if (st + 1 < nstages) {
-                store_stage(p_begin + (st + 1) * GK);
-                if (st + 2 < nstages) load_stage(p_begin + (st + 2) * GK);
-            }
-            if (!skip) {
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        const float sc = s_row[a] * s_col[b];
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            master[a][b][r] = fmaf(acc[a][b][r], sc, master[a][b][r]);
-                            acc[a][b][r] = 0.f;
-                        }
-                    }
-            }
-            __syncthreads();  // the planes of stage st + 1 are complete
+        for (int a = 0; a < 2; ++a) {
+            s_row[a] = inv_lds[2 * wi + a];
+            s_col[a] = inv_lds[bslot * 4 + 2 * wj + a];
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            g16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                ah[a] = *reinterpret_cast<const g16x8*>(buf + a_off + a * 32 * GXROW + q * 32);
+                al[a] = *reinterpret_cast<const g16x8*>(buf + GX128_PLANE + a_off + a * 32 * GXROW + q * 32);
+                bh[a] = *reinterpret_cast<const g16x8*>(buf + b_off + a * 32 * GXROW + q * 32);
+                bl[a] = *reinterpret_cast<const g16x8*>(buf + GX128_PLANE + b_off + a * 32 * GXROW + q * 32);
+            }
+            // (the four accumulators in turn: no MFMA waits for the one before it)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const float sc = s_row[a] * s_col[b];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    master[a][b][r] = fmaf(acc[a][b][r], sc, master[a][b][r]);
+                    acc[a][b][r] = 0.f;
+                }
+            }
     }
-    // the wave's 64 x 64 sub-block is the slab of the 64-channel tile pair (2 Ti + wi, 2 Tj + wj)
+    if (nstages == 0) return;
+    // the wave's 64 x 64 sub-block is the slab of the 64-channel tile pair (2 Ti + wi, 2 Tj + wj); the mirrored one of a diagonal pair is not stored
     const int ti64 = 2 * Ti + wi, tj64 = 2 * Tj + wj;
     if (ti64 > tj64 || tj64 >= ntile64) return;
     const int p64 = ti64 * ntile64 - ti64 * (ti64 - 1) / 2 + (tj64 - ti64);
-    // (the lane number read afresh: carried from the top of the kernel it is two registers spilled to scratch)
-    const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    float* out = partial + ((int64_t)p64 * ksplit + ks) * (GT * GT) + (ln >> 5) * 4 * GT + (ln & 31);
+    float* out = partial + ((int64_t)p64 * ksplit + ks) * (GT * GT) + half * 4 * GT + i32;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -593,7 +600,7 @@ __device__ __forceinline__ void gram_x3_partial128_body(const float* __restrict_
             for (int r = 0; r < 16; ++r) out[(a * 32 + (r & 3) + 8 * (r >> 2)) * GT + b * 32] = master[a][b][r];
 }
 
-__global__ void __launch_bounds__(256, 1)
+__global__ void __launch_bounds__(512, 1)
 gram_x3_partial128_kernel(const float* __restrict__ f, const float* __restrict__ mean, float* __restrict__ partial, int C,
                           int64_t HW, int ksplit, int64_t chunk) {
     gram_x3_partial128_body(f, mean, partial, C, HW, ksplit, chunk, blockIdx.x, blockIdx.y);
@@ -626,7 +633,7 @@ __global__ void __launch_bounds__(256, 2) gram_x3_partial_batch_kernel(GramParti
     gram_x3_partial_body(b.f[z], b.mean[z], b.partial[z], b.C[z], b.HW[z], b.ksplit[z], b.chunk[z], b.nplanes[z], local - ks * b.npairs[z], ks);
 }
 // ... and the layers that multiply in 128 x 128 blocks: a launch of their own (one workgroup per CU, see gram_x3_partial128_body)
-__global__ void __launch_bounds__(256, 1) gram_x3_partial128_batch_kernel(GramPartialBatch b) {
+__global__ void __launch_bounds__(512, 1) gram_x3_partial128_batch_kernel(GramPartialBatch b) {
     int z = 0;
     while (z + 1 < b.count && (int)blockIdx.x >= b.first[z + 1]) ++z;
     const int local = blockIdx.x - b.first[z];
@@ -937,16 +944,20 @@ gram_bwd_kernel(const float* __restrict__ d, const float* __restrict__ f, const 
     }
 }
 
-// MAUA_GRAM_T128=1 (read once per process): layers of 128 channels and more multiply in 128 x 128 blocks (gram_x3_partial128_kernel, fp16x3
-// route only) on maps its 32-bit buffer offsets reach (row index up to c + 127) with 64 stages and more to share out.  Off by default: with
-// the one workgroup per CU it needs it is worth -1.3 % ... +0.75 % of an iteration (724 x 724 ... 2048 x 2048; profiles/probes_r04.md section 2).
+// Layers of 128 channels and more multiply in 128 x 128 blocks (gram_x3_partial128_kernel, fp16x3 route only) on maps its 32-bit buffer
+// offsets reach (row index up to c + 127) with 16 stages and more to share out (MAUA_GRAM_T128_MIN_HW pixels; below, the 64 x 64 tiles' four
+// times as many workgroups fill the chip better: 512 x 256 10.0 us against 8.8).  MAUA_GRAM_T128=0 (read once per process): 64 x 64 everywhere.
 static bool gram_tile128(int c, int64_t hw) {
     static const bool on = [] {
         const char* e = getenv("MAUA_GRAM_T128");
         const char* x3 = getenv("MAUA_GRAM_X3");
-        return e && e[0] == '1' && !(x3 && x3[0] == '0');
+        return !(e && e[0] == '0') && !(x3 && x3[0] == '0');
     }();
-    return on && c >= 128 && hw >= 64 * GK && (int64_t)(c + 128) * hw < (1ll << 29);
+    static const int64_t min_hw = [] {
+        const char* e = getenv("MAUA_GRAM_T128_MIN_HW");
+        return e ? (int64_t)atoll(e) : (int64_t)16 * GK;
+    }();
+    return on && c >= 128 && hw >= min_hw && (int64_t)(c + 128) * hw < (1ll << 29);
 }
 #ifndef MAUA_GRAM_T128_WGS
 #define MAUA_GRAM_T128_WGS 512  // (two rounds of one workgroup per CU)
@@ -1025,10 +1036,10 @@ static int gram_partial_impl(const float* f, float* row_mean_out, int c, int64_t
         gram_plan(c, hw, &npairs, &ksplit, &chunk, &wgs);
         static bool attr128 = false;
         if (!attr128) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gram_x3_partial128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GX128_LDS_EXCL);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gram_x3_partial128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GX128_LDS);
             attr128 = true;
         }
-        hipLaunchKernelGGL(gram_x3_partial128_kernel, dim3(wgs, ksplit), dim3(256), GX128_LDS_EXCL, s, f, center ? row_mean_out : nullptr, (float*)workspace,
+        hipLaunchKernelGGL(gram_x3_partial128_kernel, dim3(wgs, ksplit), dim3(512), GX128_LDS, s, f, center ? row_mean_out : nullptr, (float*)workspace,
                            c, hw, ksplit, chunk);
     } else if (use_x3) {
         const int nplanes = c <= GT ? 2 : 4;
@@ -1145,7 +1156,7 @@ int maua_gram_partial_batch(int count, const float* const* fs, float* const* mea
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gram_x3_partial_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GXBUF);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gram_x3_partial128_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GX128_LDS_EXCL);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gram_x3_partial128_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GX128_LDS);
         attr_set = true;
     }
     hipStream_t s = (hipStream_t)stream;
@@ -1224,7 +1235,7 @@ int maua_gram_partial_batch(int count, const float* const* fs, float* const* mea
         if (!nb) continue;
         b.count = nb;
         if (group == 2) {
-            hipLaunchKernelGGL(gram_x3_partial128_batch_kernel, dim3(b.first[nb]), dim3(256), GX128_LDS_EXCL, s, b);
+            hipLaunchKernelGGL(gram_x3_partial128_batch_kernel, dim3(b.first[nb]), dim3(512), GX128_LDS, s, b);
         } else {
             const size_t lds = 2 * ((size_t)(group == 1 ? 4 : 2) * GXPLANE + 64);
             hipLaunchKernelGGL(gram_x3_partial_batch_kernel, dim3(b.first[nb]), dim3(256), lds, s, b);

@@ -57,7 +57,7 @@ def test_host_only_entry_points(libpath):
     assert L.maua_pool_out_size(1, 2, 2, 0) == 0
     assert L.maua_gram_workspace_bytes(64, 1 << 20) > 0
     assert L.maua_gram_workspace_bytes(0, 5) == 0
-    assert L.maua_gram_block(512, 1 << 14) == 64 and L.maua_gram_block(64, 1 << 20) == 64  # (128 only with MAUA_GRAM_T128=1)
+    assert L.maua_gram_block(512, 1 << 14) == 128 and L.maua_gram_block(64, 1 << 20) == 64 and L.maua_gram_block(512, 256) == 64
     assert L.maua_lbfgs_state_bytes(3 * 64 * 64, 100) > 2 * 101 * 3 * 64 * 64 * 4
     assert L.maua_reduce_workspace_bytes(10) >= 8
 

@@ -631,9 +631,11 @@ def test_frame_batch_is_bit_identical_to_frame_by_frame(weight_files, opt, S, ex
         assert torch.equal(together[k], single[k]), (k, rel_l2(together[k], single[k]))
     assert not torch.equal(together[0], together[1])
     # a plain optimize call plans for one image: possibly another split-K summation order - the same answer up to what the
-    # optimiser makes of last-bit differences (fp32 L-BFGS is chaotic, SURVEY.md section 0 fact 2: a sanity bound only)
+    # optimiser makes of last-bit differences (fp32 L-BFGS is chaotic, SURVEY.md section 0 fact 2: a sanity bound only; Adam divides by
+    # sqrt(v) + 1e-8: where a pixel's gradient is rounding noise its step is +-lr either way - seven iterations of frame 0 move by 1e-4 ... 7e-4
+    # when ANY kernel route changes its rounding (MAUA_CONV_X6=0, MAUA_GRAM_X3=0, the 128 x 128 Gram blocks), 5e-8 otherwise)
     plain = optim.optimize(contents[:1], [style], inits[:1].clone(), N, args, net, losses)
-    assert rel_l2(plain[0], together[0]) <= (0.2 if opt == "lbfgs" else 1e-4)
+    assert rel_l2(plain[0], together[0]) <= (0.2 if opt == "lbfgs" else 5e-3)
 
 
 @pytest.mark.parametrize("opt,N", [("lbfgs", 5), ("lbfgs", 10), ("adam", 10)])
