@@ -256,8 +256,8 @@ int maua_pool2x2_bwd_codes(const float* gy, const unsigned char* codes, float* g
 /* gram[C][C] = scale * Fc Fc^T with Fc = f[C][hw] (minus row means when `center` != 0, loss.py:87-89).
  * row_mean_out (nullable unless center): receives the C row means.  Split-K over hw with a fixed-order reduction.
  * workspace: maua_gram_workspace_bytes(C, hw) bytes.
- * maua_gram_block: edge of the blocks the split-K kernel of this shape multiplies in - 64, or 128 with MAUA_GRAM_T128=1 (read once per
- * process; 128+ channels, 4096+ pixels; one workgroup per CU, see gram.hip). */
+ * maua_gram_block: edge of the blocks the split-K kernel of this shape multiplies in - 128 for 128+ channels and 1024+ pixels in whole
+ * 64-pixel stages, else 64 (MAUA_GRAM_T128, read once per process: 0 = always 64, 2 = ragged maps too; see gram.hip). */
 size_t maua_gram_workspace_bytes(int c, int64_t hw);
 int maua_gram_block(int c, int64_t hw);
 int maua_gram_fwd(const float* f, float* gram, float* row_mean_out, int c, int64_t hw, float scale, int center,

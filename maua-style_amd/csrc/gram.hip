@@ -945,19 +945,24 @@ gram_bwd_kernel(const float* __restrict__ d, const float* __restrict__ f, const 
 }
 
 // Layers of 128 channels and more multiply in 128 x 128 blocks (gram_x3_partial128_kernel, fp16x3 route only) on maps its 32-bit buffer
-// offsets reach (row index up to c + 127) with 16 stages and more to share out (MAUA_GRAM_T128_MIN_HW pixels; below, the 64 x 64 tiles' four
-// times as many workgroups fill the chip better: 512 x 256 10.0 us against 8.8).  MAUA_GRAM_T128=0 (read once per process): 64 x 64 everywhere.
+// offsets reach (row index up to c + 127), of 16 stages and more (MAUA_GRAM_T128_MIN_HW pixels; below, the 64 x 64 tiles' four times as many
+// workgroups fill the chip better: 512 x 256 10.0 us against 8.8) and - by default - a whole number of stages.  That last condition is a
+// measured one (profiles/probes_r04.md section 2): the 128 x 128 launch is one more launch beside the 64 x 64 one of the layers that stay
+// there, and where not every layer qualifies or the gain per layer is small that costs what the blocks win - VGG-19 at 362 / 724 / 1448
+// (-1.1 % ... +0.4 % of a step) and NIN's 127 x 127 / 63 x 63 maps (-0.9 %) against +1.2 % / +1.0 % at 1024 / 2048.
+// MAUA_GRAM_T128 (read once per process): 0 = 64 x 64 everywhere, 2 = every map of MIN_HW pixels and more (ragged last stages included).
 static bool gram_tile128(int c, int64_t hw) {
-    static const bool on = [] {
+    static const int mode = [] {
         const char* e = getenv("MAUA_GRAM_T128");
         const char* x3 = getenv("MAUA_GRAM_X3");
-        return !(e && e[0] == '0') && !(x3 && x3[0] == '0');
+        if (x3 && x3[0] == '0') return 0;
+        return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1;
     }();
     static const int64_t min_hw = [] {
         const char* e = getenv("MAUA_GRAM_T128_MIN_HW");
         return e ? (int64_t)atoll(e) : (int64_t)16 * GK;
     }();
-    return on && c >= 128 && hw >= min_hw && (int64_t)(c + 128) * hw < (1ll << 29);
+    return mode && c >= 128 && hw >= min_hw && (mode == 2 || hw % GK == 0) && (int64_t)(c + 128) * hw < (1ll << 29);
 }
 #ifndef MAUA_GRAM_T128_WGS
 #define MAUA_GRAM_T128_WGS 512  // (two rounds of one workgroup per CU)

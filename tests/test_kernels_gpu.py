@@ -592,15 +592,15 @@ def test_conv1x1_x3_channel_shift_is_the_gram_centring(hip, cin, cout, hw):
 
 
 def test_gram_128_blocks_stress_and_the_64_route_subprocess():
-    """Layers of 128+ channels and 1024+ pixels multiply in 128 x 128 blocks (MAUA_GRAM_T128=0, read once per process: 64 x 64 everywhere).
-    tools/stress_gram.py under both settings: every layer set against fp64 (<= 2e-5 with the means of the covariance sets), the batched
+    """Layers of 128+ channels and 1024+ pixels in whole 64-pixel stages multiply in 128 x 128 blocks (MAUA_GRAM_T128, read once per
+    process: 0 = 64 x 64 everywhere, 2 = ragged maps too).  tools/stress_gram.py under the three settings: every layer set against fp64 (<= 2e-5 with the means of the covariance sets), the batched
     launches bit for bit what the per-layer launches leave, and the same bits on every one of 12 launches between LDS-scribbling
     convolutions (the first form of the 128 x 128 kernel passed every single-launch test and failed this one: probes_r04.md section 2)."""
     import subprocess
     import sys
     code = ("import sys; sys.path[:0] = [%r, %r]; import hip\n"
-            "print('blocks', hip.gram_block(128, 4096), hip.gram_block(512, 16384), hip.gram_block(512, 484), hip.gram_block(64, 1 << 20))\n") % (REPO, PKG)
-    for flag, want in (("1", "blocks 128 128 64 64"), ("0", "blocks 64 64 64 64")):
+            "print('blocks', hip.gram_block(128, 4096), hip.gram_block(512, 16384), hip.gram_block(256, 8100), hip.gram_block(512, 484), hip.gram_block(64, 1 << 20))\n") % (REPO, PKG)
+    for flag, want in (("1", "blocks 128 128 64 64 64"), ("2", "blocks 128 128 128 64 64"), ("0", "blocks 64 64 64 64 64")):
         env = dict(os.environ, MAUA_GRAM_T128=flag)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and want in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
