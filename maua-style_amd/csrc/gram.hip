@@ -964,9 +964,6 @@ static bool gram_tile128(int c, int64_t hw) {
     }();
     return mode && c >= 128 && hw >= min_hw && (mode == 2 || hw % GK == 0) && (int64_t)(c + 128) * hw < (1ll << 29);
 }
-#ifndef MAUA_GRAM_T128_WGS
-#define MAUA_GRAM_T128_WGS 512  // (two rounds of one workgroup per CU)
-#endif
 // npairs: 64-channel tile pairs = slabs per slice of HW (the slab format of every kernel); *wgs_per_slab (nullable): workgroups per slice
 static void gram_plan(int c, int64_t hw, int* npairs, int* ksplit, int64_t* chunk, int* wgs_per_slab = nullptr) {
     const int ntile = (c + GT - 1) / GT;
@@ -974,8 +971,14 @@ static void gram_plan(int c, int64_t hw, int* npairs, int* ksplit, int64_t* chun
     const int nt128 = (c + 127) / 128;
     const int wgs = gram_tile128(c, hw) ? nt128 * (nt128 + 1) / 2 : *npairs;
     if (wgs_per_slab) *wgs_per_slab = wgs;
-    int64_t want = ((gram_tile128(c, hw) ? MAUA_GRAM_T128_WGS : 768) + wgs - 1) / wgs;
     const int64_t stages = (hw + GK - 1) / GK;
+    int64_t want = (768 + wgs - 1) / wgs;
+    if (gram_tile128(c, hw)) {
+        // one workgroup per CU: one to two rounds of them, 16 stages each where the map has that many (fewer, longer slices = fewer slabs for the
+        // finishing kernels: 512 workgroups per layer at 1024 x 1024 cost them 35 us instead of 23, and the partial launch 120 instead of 112)
+        const int64_t lo = (256 + wgs - 1) / wgs, hi = (512 + wgs - 1) / wgs;
+        want = stages / 16 < lo ? lo : stages / 16 > hi ? hi : stages / 16;
+    }
     if (want > stages) want = stages;
     if (want < 1) want = 1;
     int64_t ch = ((hw + want - 1) / want + GK - 1) / GK * GK;
