@@ -32,4 +32,6 @@ python bench.py --model nin --steps 200 --no_cpu_baseline > $O/bench_nin.json 2>
 python tools/lbfgs_clock.py 196608 100 > $O/clock_lbfgs.txt 2>&1
 python tools/bench_fused_gram.py 1024 20 > $O/fused_gram.txt 2>&1
 python tools/stress_fused.py 100 > $O/stress_fused.txt 2>&1
+python tools/bench_gram.py > $O/bench_gram.txt 2>/dev/null
+python tools/stress_gram.py 100 > $O/stress_gram.txt 2>&1
 ls -la $O; tail -c 600 $O/bench_graph.json
