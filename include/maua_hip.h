@@ -205,6 +205,31 @@ int maua_conv3x3_x3q_unpool(const float* pooled_x, const unsigned char* codes, i
                             const float* out_relu_mask, float* y, int n, int cin, int h, int w, int cout, int pad, void* workspace,
                             size_t workspace_bytes, maua_stream_t stream);
 
+/* The fourth structure (conv_x3p.hip, round 5): conv_x3q's workgroup made persistent.  One workgroup of eight waves per CU walks a
+ * static share of the launch's work items - (image, 64-channel output tile, 16 x 32 pixel tile, K split) - as one stream of 32-channel
+ * chunks: the first chunk of the next item is staged during the last chunk of the current one, and an item's epilogue (ReLU, mask, pool,
+ * stores) rides among the MFMAs of the next item's first chunk.  Same layer arithmetic - `nn.Conv2d(cin, c, 3)` + `nn.ReLU(inplace=True)`
+ * (+ `nn.MaxPool2d(2, 2)`), models.py:120, 129-130, and the backward-data pass autograd derives - same banks (maua_conv_pack_filters_x3q)
+ * and, in one pass over the channels, the same bits as maua_conv3x3_x3q / _relu_pool / _unpool.  ONE entry point, every fused form an
+ * argument (all nullable):
+ *   in_codes + honour_relu_bit  x is the gradient of the POOLED map and these the pool's decision bytes (maua_conv3x3_x3w_unpool);
+ *   bias, relu, out_relu_mask   as maua_conv3x3_x3q (no accumulation);
+ *   dmat_bank + dmat_inv_scale  the Gram backward D . F of the style loss on out_relu_mask = F goes along (maua_conv3x3_x3w_gram; the
+ *                               bank is maua_conv_pack_dmat_x3w's);
+ *   pool_codes                  y is the POOLED map and these its decision bytes (maua_conv3x3_x3w_relu_pool; needs relu, no mask).
+ * Needs cin % 32 == 0, cout % 64 == 0, cout <= 1024, planes of at most 2^24 pixels and one image's output below 2 GiB
+ * (maua_conv_x3p_supported).  workspace as for maua_conv3x3_x3q (maua_conv_x3p_workspace_bytes; maua_conv_x3p_split = the K splits a
+ * launch would use, 1 = one pass). */
+int maua_conv_x3p_supported(int cin, int h, int w, int cout, int pad);
+int maua_conv_x3p_split(int n, int cin, int h, int w, int cout, int pad);
+size_t maua_conv_x3p_workspace_bytes(int n, int cin, int h, int w, int cout, int pad);
+/* 1 where the launch's work items deal out evenly enough over the 256 persistent workgroups (and its 16 x 32 tiles cover the plane
+ * tightly enough) to beat conv_x3w's finer tiles - the host side's routing rule, under the current batch hint; 0 otherwise. */
+int maua_conv_x3p_preferred(int n, int cin, int h, int w, int cout, int pad);
+int maua_conv3x3_x3p(const float* x, const unsigned char* in_codes, int honour_relu_bit, const void* bank, float w_scale, const float* bias,
+                     const float* out_relu_mask, const void* dmat_bank, const float* dmat_inv_scale, float* y, unsigned char* pool_codes,
+                     int n, int cin, int h, int w, int cout, int pad, int relu, void* workspace, size_t workspace_bytes, maua_stream_t stream);
+
 /* ---- KS x KS stride-1 convolution in the same fp16x3 arithmetic (conv_kxk_x3.hip; KS = 5: NIN's conv2, models.py:86).
  *      Banks as for maua_conv_pack_filters_x3 with KS*KS taps; backward-data of a pad-p conv: bank_bwd, cin/cout exchanged,
  *      pad KS-1-p.  workspace (nullable) as for maua_conv3x3_x6: lets small output grids split the channel loop. ---- */

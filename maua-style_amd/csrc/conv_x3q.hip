@@ -147,6 +147,21 @@ __global__ void __launch_bounds__(XQ_THREADS, 2) conv_x3q_kernel(ConvArgs p, flo
     const int lane = tid & 63, wave = tid >> 6;
     const int px = lane & 15, oct = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
+#ifdef XQ_STAMP
+    const unsigned t_entry_ = (unsigned)__builtin_amdgcn_s_memtime(), r_entry_ = (unsigned)__builtin_amdgcn_s_memrealtime();
+#define XQ_EXIT_STAMP()                                                                                                              \
+    do {                                                                                                                             \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                             \
+        if (lane == 0 && p.mask) {                                                                                                   \
+            float* d_ = const_cast<float*>(p.mask) + ((((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 64 + 63) * 8;    \
+            d_[5] = __builtin_bit_cast(float, t_entry_);                                                                             \
+            d_[6] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_s_memtime());                                               \
+            d_[7] = __builtin_bit_cast(float, r_entry_);                                                                             \
+        }                                                                                                                            \
+    } while (0)
+#else
+#define XQ_EXIT_STAMP() do {} while (0)
+#endif
     const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
     const int n = blockIdx.z / ksplit, split = blockIdx.z - n * ksplit;
     const int cotile = blockIdx.y;
@@ -455,6 +470,7 @@ __global__ void __launch_bounds__(XQ_THREADS, 2) conv_x3q_kernel(ConvArgs p, flo
         d_[0] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4));
         d_[1] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_s_memtime());
         d_[2] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_s_memrealtime());
+        d_[-8] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 20));  // slot 62: HW_REG_XCC_ID
     }
 #endif
     // chunk c:
@@ -580,6 +596,7 @@ __global__ void __launch_bounds__(XQ_THREADS, 2) conv_x3q_kernel(ConvArgs p, flo
                 if (store && cq < p.Cout) *reinterpret_cast<unsigned*>(pc + ((int64_t)(cq >> 3) * pplane + ppix) * 8 + (cq & 7)) = pk;
             }
         }
+        XQ_EXIT_STAMP();
         return;
     }
     float* __restrict__ yout = p.y + (int64_t)n * p.Cout * out_plane;
@@ -640,6 +657,7 @@ __global__ void __launch_bounds__(XQ_THREADS, 2) conv_x3q_kernel(ConvArgs p, flo
                 }
         }
     }
+    XQ_EXIT_STAMP();
 }
 
 // split-K over 32-channel chunks when the grid leaves most of the 256 workgroup slots (1 per CU) empty

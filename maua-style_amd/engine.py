@@ -284,7 +284,9 @@ class StyleEngine:
                              hip.conv_x3w_workspace_bytes(n, cin, h, w, cout, s.pad),
                              hip.conv_x3w_workspace_bytes(n, cout, oh, ow, cin, 2 - s.pad),
                              hip.conv_x3q_workspace_bytes(n, cin, h, w, cout, s.pad),
-                             hip.conv_x3q_workspace_bytes(n, cout, oh, ow, cin, 2 - s.pad))
+                             hip.conv_x3q_workspace_bytes(n, cout, oh, ow, cin, 2 - s.pad),
+                             hip.conv_x3p_workspace_bytes(n, cin, h, w, cout, s.pad),
+                             hip.conv_x3p_workspace_bytes(n, cout, oh, ow, cin, 2 - s.pad))
         self.ws = torch.empty(ws, dtype=torch.uint8, device=dev)
         self.x_static = torch.empty(self.shape, device=dev)
         if os.environ.get("MAUA_DEBUG_POISON") == "1":  # tests: every buffer starts as NaN, so a read-before-write shows up

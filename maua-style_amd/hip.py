@@ -89,6 +89,11 @@ SIGNATURES = {
     "maua_conv3x3_x3q": (c_i, [c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "maua_conv3x3_x3q_relu_pool": (c_i, [c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "maua_conv3x3_x3q_unpool": (c_i, [c_p, c_p, c_i, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
+    "maua_conv_x3p_supported": (c_i, [c_i, c_i, c_i, c_i, c_i]),
+    "maua_conv_x3p_split": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    "maua_conv_x3p_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    "maua_conv_x3p_preferred": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    "maua_conv3x3_x3p": (c_i, [c_p, c_p, c_i, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "maua_conv3x3_x3w_relu_pool": (c_i, [c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "maua_conv_x3w_dmat_bank_bytes": (c_sz, [c_i]),
     "maua_conv_pack_dmat_x3w": (c_i, [c_p, c_i, c_p, c_p, c_p]),
@@ -383,6 +388,45 @@ def conv3x3_x3q_unpool(pooled_x, codes, honour_relu_bit, bank, w_scale, cout, pa
     _check(lib().maua_conv3x3_x3q_unpool(_ptr(_f32(pooled_x, "pooled_x")), codes.data_ptr(), int(bool(honour_relu_bit)), bank.data_ptr(),
                                          float(w_scale), _ptr(out_relu_mask) if out_relu_mask is not None else None, _ptr(out), n, cin, h, w,
                                          cout, pad, wp, wn, _stream()), "maua_conv3x3_x3q_unpool")
+    return out
+
+
+def conv_x3p_supported(cin, h, w, cout, pad):
+    return bool(lib().maua_conv_x3p_supported(int(cin), int(h), int(w), int(cout), int(pad)))
+
+
+def conv_x3p_split(n, cin, h, w, cout, pad):
+    return int(lib().maua_conv_x3p_split(int(n), int(cin), int(h), int(w), int(cout), int(pad)))
+
+
+def conv_x3p_preferred(n, cin, h, w, cout, pad):
+    return bool(lib().maua_conv_x3p_preferred(int(n), int(cin), int(h), int(w), int(cout), int(pad)))
+
+
+def conv_x3p_workspace_bytes(n, cin, h, w, cout, pad):
+    return lib().maua_conv_x3p_workspace_bytes(n, cin, h, w, cout, pad)
+
+
+def conv3x3_x3p(x, bank, w_scale, bias, cout, pad, relu, out=None, out_relu_mask=None, workspace=None, in_codes=None, honour_relu_bit=True,
+                dmat_bank=None, dmat_inv_scale=None, pool_codes=None):
+    """The persistent fp16x3 3x3 kernel (conv_x3p.hip) in any of its forms: plain / masked, staged from a pooled gradient (`in_codes`: x is
+    the pooled map's gradient, `out` fixes the full-size plane), with the Gram backward along (`dmat_bank`, out_relu_mask = F), or with ReLU
+    + 2x2 max pool in the epilogue (`pool_codes`: out = the pooled map).  Banks: conv_pack_filters_x3q's."""
+    n, cin = x.shape[0], x.shape[1]
+    if in_codes is not None:
+        h, w = _unpooled_hw(x.shape[2], x.shape[3], pad, out)
+    else:
+        h, w = x.shape[2], x.shape[3]
+    oh, ow = h + 2 * pad - 2, w + 2 * pad - 2
+    if out is None:
+        out = torch.empty((n, cout, oh // 2, ow // 2) if pool_codes is not None else (n, cout, oh, ow), device=x.device, dtype=torch.float32)
+    wp, wn = _ws_args(workspace, conv_x3p_workspace_bytes(n, cin, h, w, cout, pad) if workspace is None else 0, x.device)
+    _check(lib().maua_conv3x3_x3p(_ptr(_f32(x, "x")), in_codes.data_ptr() if in_codes is not None else None, int(bool(honour_relu_bit)),
+                                  bank.data_ptr(), float(w_scale), _ptr(bias), _ptr(out_relu_mask) if out_relu_mask is not None else None,
+                                  dmat_bank.data_ptr() if dmat_bank is not None else None,
+                                  _ptr(dmat_inv_scale) if dmat_inv_scale is not None else None, _ptr(out),
+                                  pool_codes.data_ptr() if pool_codes is not None else None, n, cin, h, w, cout, pad, int(relu), wp, wn,
+                                  _stream()), "maua_conv3x3_x3p")
     return out
 
 

@@ -70,6 +70,33 @@ def _x3q_min_channels():
     return int(v) if v.isdigit() else 256
 
 
+def _x3p_min_channels():
+    """MAUA_CONV_X3P: the smallest consumed channel count (a multiple of 32) from which a 3x3 layer runs conv_x3p.hip - conv_x3q's
+    workgroup made persistent (round 5): one stream of chunks per CU, the next tile staged under the current one, the epilogue under the
+    next tile's first chunk - instead of conv_x3q.hip / conv_x3w.hip; "0" = never.  Default 64: every VGG layer it supports."""
+    import os
+    v = os.environ.get("MAUA_CONV_X3P", "64")
+    return int(v) if v.isdigit() else 64
+
+
+def conv3x3_is_x3p(consumed, h, w, pad, produced, n=1, accumulate=False):
+    """Whether a 3x3 stride-1 pass that consumes `consumed` channels of an h x w plane and produces `produced` runs on conv_x3p.hip
+    (forward: pad = the layer's padding; backward-data: 2 - padding)."""
+    import os
+    mc = _x3p_min_channels()
+    return _x3_enabled() and _x3w_enabled() and mc > 0 and mc <= consumed <= int(os.environ.get("MAUA_CONV_X3P_MAX", "100000")) and not accumulate and h * w >= _x3w_min_pixels() and \
+        hip.conv_x3p_supported(consumed, h, w, produced, pad) and hip.conv_x3p_preferred(n, consumed, h, w, produced, pad)
+
+
+def _x3p_gram_enabled(n, c_in, c_out, h, w):
+    """Whether the Gram backward rides in conv_x3p's launch (its D . F chunks run between two items, latency-exposed) or in conv_x3w's
+    (MAUA_X3P_GRAM_MIN_MB, default 700): measured in the network, conv_x3p's form wins 7-8 % where the launch's maps - gradient in,
+    gradient out, F - are beyond what the 256 MB of Infinity Cache hold (2048 x 2048 images) and loses 2-3 % where they are not (1024)."""
+    import os
+    mb = n * (c_in + 2 * c_out) * h * w * 4 / 1e6
+    return mb >= float(os.environ.get("MAUA_X3P_GRAM_MIN_MB", "700"))
+
+
 X3Q_UNPOOL_MIN_CHANNELS = 512  # conv_x3q's unpooling form pays from here: its corner vectors are cut in the exposed store phase
                                # (measured in the network: conv4_4's backward pass 181 -> 176 us, conv3_4's 186 -> 207)
 
@@ -107,6 +134,9 @@ def conv3x3_mfma(x, mod, backward, out=None, out_relu_mask=None, relu=False, acc
     else:
         cout, p, bias = mod.out_channels, pad, mod.bias_device()
     consumed = mod.out_channels if backward else mod.in_channels
+    if conv3x3_is_x3p(consumed, x.shape[2], x.shape[3], p, cout, x.shape[0], accumulate):
+        bf, bb, wsc = mod.banks3q()
+        return hip.conv3x3_x3p(x, bb if backward else bf, wsc, bias, cout, p, relu, out=out, out_relu_mask=out_relu_mask, workspace=workspace)
     if conv3x3_is_x3q(consumed, x.shape[2], x.shape[3], p, X3Q_UNPOOL_MIN_CHANNELS if pool_group else 0, cout, x.shape[0]):
         bf, bb, wsc = mod.banks3q()
         return hip.conv3x3_x3q(x, bb if backward else bf, wsc, bias, cout, p, relu, out=out, out_relu_mask=out_relu_mask,
@@ -139,6 +169,10 @@ def conv3x3_fwd_is_x3w(mod, h, w):
 def conv3x3_relu_pool(x, mod, pooled, codes, workspace=None):
     """conv + bias + ReLU + the 2x2 / 2 max pool behind it without the full-size activation (hip.conv3x3_x3w_relu_pool: one launch, or -
     small grids, with a workspace - a split channel loop whose adding pass pools)."""
+    if conv3x3_is_x3p(mod.in_channels, x.shape[2], x.shape[3], mod.padding[0], mod.out_channels, x.shape[0]):
+        bf, _, wsc = mod.banks3q()
+        return hip.conv3x3_x3p(x, bf, wsc, mod.bias_device(), mod.out_channels, mod.padding[0], True, out=pooled, pool_codes=codes,
+                               workspace=workspace)
     if conv3x3_is_x3q(mod.in_channels, x.shape[2], x.shape[3], mod.padding[0], 0, mod.out_channels, x.shape[0]):
         bf, _, wsc = mod.banks3q()
         return hip.conv3x3_x3q_relu_pool(x, bf, wsc, mod.bias_device(), mod.out_channels, mod.padding[0], pooled, codes, workspace=workspace)
@@ -157,6 +191,11 @@ def conv3x3_bwd_is_x3w(mod, h, w):
 def conv3x3_bwd_with_gram(gy, mod, feature_map, dmat_bank, dmat_inv_scale, out, workspace=None):
     """out = [F > 0] * (backward-data of the layer + D . F): the layer's input gradient and the Gram backward of the style loss on
     its input activation F in one launch."""
+    if conv3x3_is_x3p(mod.out_channels, gy.shape[2], gy.shape[3], 2 - mod.padding[0], mod.in_channels, gy.shape[0]) and \
+            _x3p_gram_enabled(gy.shape[0], mod.out_channels, mod.in_channels, gy.shape[2], gy.shape[3]):
+        _, bb, wsc = mod.banks3q()
+        return hip.conv3x3_x3p(gy, bb, wsc, None, mod.in_channels, 2 - mod.padding[0], False, out=out, out_relu_mask=feature_map,
+                               dmat_bank=dmat_bank, dmat_inv_scale=dmat_inv_scale, workspace=workspace)
     _, bb, wsc = mod.banks3w()
     return hip.conv3x3_x3w_gram(gy, bb, wsc, feature_map, dmat_bank, dmat_inv_scale, mod.in_channels, 2 - mod.padding[0], out=out,
                                 workspace=workspace)
@@ -167,6 +206,12 @@ def conv3x3_bwd_from_pooled(gy_pooled, codes, honour_relu_bit, mod, out, out_rel
     """Backward-data pass of a conv + ReLU + 2x2 max pool group from the gradient of the POOLED map and the pool's decision bytes
     (hip.conv3x3_x3w_unpool): the pool's backward pass happens while the kernel stages its input; with `dmat_bank`, the Gram backward
     of the style loss on the layer's input goes along (out_relu_mask = that activation)."""
+    if conv3x3_is_x3p(mod.out_channels, out.shape[2], out.shape[3], 2 - mod.padding[0], mod.in_channels, gy_pooled.shape[0]) and \
+            (dmat_bank is None or _x3p_gram_enabled(out.shape[0], mod.out_channels // 4, mod.in_channels, out.shape[2], out.shape[3])):
+        _, bb, wsc = mod.banks3q()
+        return hip.conv3x3_x3p(gy_pooled, bb, wsc, None, mod.in_channels, 2 - mod.padding[0], False, out=out, out_relu_mask=out_relu_mask,
+                               in_codes=codes, honour_relu_bit=honour_relu_bit, dmat_bank=dmat_bank, dmat_inv_scale=dmat_inv_scale,
+                               workspace=workspace)
     if dmat_bank is None and conv3x3_is_x3q(mod.out_channels, out.shape[2], out.shape[3], 2 - mod.padding[0], X3Q_UNPOOL_MIN_CHANNELS,
                                             mod.in_channels, gy_pooled.shape[0]):
         _, bb, wsc = mod.banks3q()

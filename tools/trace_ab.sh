@@ -5,7 +5,7 @@ R=$PWD; O=$R/$1; VAR=$2; VALS=$3; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 for v in $VALS; do
   export $VAR=$v
-  rocprofv3 --kernel-trace --output-format csv -d $O/t_$v -o p -- python3 $R/bench.py --steps 12 --warmup 2 --no_prefill --no_cpu_baseline --no_extra_sizes --no_exact_split --no_repeats --no_hip_graph $BENCH_ARGS > /dev/null 2>&1
+  rocprofv3 --kernel-trace --output-format csv -d $O/t_$v -o p -- python3 $R/bench.py --steps 12 --warmup 2 --no_prefill --no_cpu_baseline --no_extra_sizes --no_exact_split --no_repeats ${GRAPH:---no_hip_graph} $BENCH_ARGS > /dev/null 2>&1
 done
 cd $R
 python - "$O" $VALS <<'PY'
