@@ -226,6 +226,10 @@ size_t maua_conv_x3p_workspace_bytes(int n, int cin, int h, int w, int cout, int
 /* 1 where the launch's work items deal out evenly enough over the 256 persistent workgroups (and its 16 x 32 tiles cover the plane
  * tightly enough) to beat conv_x3w's finer tiles - the host side's routing rule, under the current batch hint; 0 otherwise. */
 int maua_conv_x3p_preferred(int n, int cin, int h, int w, int cout, int pad);
+/* Tests: the workgroups a launch may use (a multiple of 8 from 8 on; anything else restores one per CU = 256), so that small shapes walk
+ * several items per workgroup.  Returns the previous value.  Process-wide; results do not depend on it (a tile's arithmetic is the same
+ * wherever it sits in a workgroup's list). */
+int maua_conv_x3p_set_max_groups(int groups);
 int maua_conv3x3_x3p(const float* x, const unsigned char* in_codes, int honour_relu_bit, const void* bank, float w_scale, const float* bias,
                      const float* out_relu_mask, const void* dmat_bank, const float* dmat_inv_scale, float* y, unsigned char* pool_codes,
                      int n, int cin, int h, int w, int cout, int pad, int relu, void* workspace, size_t workspace_bytes, maua_stream_t stream);

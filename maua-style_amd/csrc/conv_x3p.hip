@@ -52,6 +52,9 @@ constexpr unsigned XP_OOB = 0x80000000u;
 #ifndef XP_EARLY_LOADS
 #define XP_EARLY_LOADS 0   // 1: every chunk requests the next patch in steps 0-7 (0: the chunks without an epilogue spread it over taps 0-3)
 #endif
+#ifndef XP_MIDFOLD
+#define XP_MIDFOLD 1       // chunks that are not the first of an item fold their sums into the masters at tap 5 as well (0: one fold per chunk everywhere)
+#endif
 #ifndef XP_STAGGER
 #define XP_STAGGER 0       // start delay of workgroup q: (q % 4) x this many 1024-cycle sleeps
 #endif
@@ -239,7 +242,6 @@ __global__ void __launch_bounds__(XP_THREADS, 2) conv_x3p_kernel(ConvArgs p, X3p
         const int o4 = tid / 100, pb = 512 + tid - o4 * 100;
         const int rb = pb / XP_PC, cb4 = pb - rb * XP_PC;
         Tl[XP_THREADS + tid] = (unsigned)(rb | cb4 << 8 | o4 << 16 | (tid < 400 ? 1 << 24 : 0));
-        Tl[2 * XP_THREADS + tid] = tid < 400 ? (unsigned)(o4 * XP_PLANE + pb * 16) : (unsigned)(3 * XP_PLANE + (XP_NPOS_PAD - 1) * 16);
         vcode[0] = inmask[0] = 0;
     }
     // (a thread reads back its own words only: no barrier needed for them)
@@ -273,7 +275,9 @@ __global__ void __launch_bounds__(XP_THREADS, 2) conv_x3p_kernel(ConvArgs p, X3p
                 const int iy = y0 + r - p.pad, ix = x0 + c - p.pad;
                 // (unsigned compares: one per extent, no short-circuit branches)
                 const bool ok = ((wh >> 24) != 0) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-                voff[k] = ok ? (unsigned)(o * 8 * in_plane + iy * p.W + ix) * 4u : XP_OOB;
+                const unsigned v = ok ? (unsigned)(o * 8 * in_plane + iy * p.W + ix) * 4u : XP_OOB;
+                if (k == 0) voff[0] = v;
+                else Tl[2 * XP_THREADS + tid] = v;  // (item 4's offset waits in LDS: the chunk reads it back for its eight loads)
             }
         }
     };
@@ -309,7 +313,7 @@ __global__ void __launch_bounds__(XP_THREADS, 2) conv_x3p_kernel(ConvArgs p, X3p
             for (int c = c_lo; c < c_hi; ++c)
 #pragma unroll
                 for (int k = 0; k < NI; ++k)  // (items 0-3: the octet's eight planes in the scalar offset)
-                    rp[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs.x, voff[k < 4 ? 0 : 1], ((k < 4 ? 8 * k : 0) + c) * st_plane * 4, 0));
+                    rp[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs.x, k < 4 ? voff[0] : voff[1], ((k < 4 ? 8 * k : 0) + c) * st_plane * 4, 0));
         }
     };
     auto publish_max = [&]() {
@@ -391,7 +395,11 @@ __global__ void __launch_bounds__(XP_THREADS, 2) conv_x3p_kernel(ConvArgs p, X3p
                              __builtin_bit_cast(unsigned, rp[k][3])};
             const u32x4 l = {__builtin_bit_cast(unsigned, rp[k][4]), __builtin_bit_cast(unsigned, rp[k][5]), __builtin_bit_cast(unsigned, rp[k][6]),
                              __builtin_bit_cast(unsigned, rp[k][7])};
-            const unsigned dst = k == NI - 1 ? Tl[2 * XP_THREADS + t_] : (unsigned)t_ * 16u + (unsigned)(XP_PLANE * k);
+            unsigned dst = (unsigned)t_ * 16u + (unsigned)(XP_PLANE * k);
+            if (k == NI - 1) {  // item 4: position 512 + tid % 100 of octet tid / 100; threads without one write zeros into a padding slot
+                const unsigned wh = Tl[XP_THREADS + t_];
+                dst = (wh >> 24) ? ((wh >> 16) & 0xffu) * XP_PLANE + ((wh & 0xffu) * XP_PC + ((wh >> 8) & 0xffu)) * 16u : (unsigned)(3 * XP_PLANE + (XP_NPOS_PAD - 1) * 16);
+            }
             *reinterpret_cast<u32x4*>(Pl + dst) = h;   // (threads without a fifth item write zeros into a padding slot)
             *reinterpret_cast<u32x4*>(Pl + 4 * XP_PLANE + dst) = l;
         }
@@ -510,14 +518,14 @@ __global__ void __launch_bounds__(XP_THREADS, 2) conv_x3p_kernel(ConvArgs p, X3p
             for (int g = 0; g < 4; ++g) row_ok[g] = fin.y0 + 2 * wv + (g >> 1) < p.OH;
         }
     };
-    float mk[3][4];  // OM: the mask values of the pieces in flight, [piece % 3][r]
+    float mk[2][4];  // OM: the mask values of the pieces in flight, [piece % 2][r]
     auto epi_load = [&](int k) {  // masks of piece k
         if constexpr (OM) {
             const int i = k >> 2, g = k & 3;
             const unsigned v = row_ok[g] ? vo[g & 1] : XP_OOB;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                mk[k % 3][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                mk[k % 2][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                     rs_aux, v, so_base + (unsigned)((16 * i + r) * out_plane + (g >> 1) * p.OW) * 4u, 0));
         }
     };
@@ -563,7 +571,7 @@ __global__ void __launch_bounds__(XP_THREADS, 2) conv_x3p_kernel(ConvArgs p, X3p
             for (int r = 0; r < 4; ++r) {
                 float val = master[i][g][r];
                 if (p.relu && !slab) val = val > 0.f ? val : 0.f;
-                if constexpr (OM) val = mk[k % 3][r] > 0.f ? val : 0.f;
+                if constexpr (OM) val = mk[k % 2][r] > 0.f ? val : 0.f;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rs_out, v,
                                                       so_base + (unsigned)((16 * i + r) * out_plane + (g >> 1) * p.OW) * 4u, 0);
             }
@@ -667,6 +675,7 @@ __global__ void __launch_bounds__(XP_THREADS, 2) conv_x3p_kernel(ConvArgs p, X3p
     set_tile(cur.x0, cur.y0);
     int ch = cur.cb;
     dma_filters(ch, cur.cot, 0, 9);
+    if constexpr (!UNPOOL) voff[1] = Tl[2 * XP_THREADS + tid];
     load_patch_part(patch_rsrc(cur.n, ch), 0, 8);
     publish_max();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -705,13 +714,14 @@ __global__ void __launch_bounds__(XP_THREADS, 2) conv_x3p_kernel(ConvArgs p, X3p
         };
         {
             const int t_ = my_tid();
+            if constexpr (!UNPOOL) voff[1] = Tl[2 * XP_THREADS + t_];
             b_base = ((t_ >> 4) & 3) * XP_PLANE + ((2 * wv) * XP_PC + (t_ & 15)) * 16;
             a_base = ((t_ >> 4) & 3) * 1024 + (t_ & 15) * 16;
         }
         const int ncot_ = it.cot;  // (the running item's tile: what the masters restart from)
         if constexpr (EPI) epi_begin();
         // pieces: plain / masked 16, pooling 8; the first XP_W1_PIECES (pooling: half as many) end with step 16, the others start with step 20
-        // (pooling: every other step); a masked piece's mask values are requested two pieces ahead
+        // (pooling: every other step); a masked piece's mask values are requested one piece ahead (behind the previous piece's use of the other slot)
         constexpr int NP = POOL ? 8 : 16;
         constexpr int P1 = xp_first_pieces(POOL);
         auto step_of = [](int k) { return xp_step_of(POOL, k); };
@@ -720,12 +730,12 @@ __global__ void __launch_bounds__(XP_THREADS, 2) conv_x3p_kernel(ConvArgs p, X3p
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {
                     if constexpr (OM) {
-                        if (k < 2 ? s == step_of(0) - 1 : s == step_of(k - 2)) epi_load(k);
+                        if (k < 1 ? s == step_of(0) - 1 : s == step_of(k - 1)) epi_load(k);
                     }
                 }
 #pragma unroll
                 for (int k = 0; k < NP; ++k)
-                    if (s == step_of(k)) epi_piece(k, ncot_);
+                    if (s == step_of(k) && fin_valid) epi_piece(k, ncot_);
             }
         };
         // stores issued behind the chunk's last load / LDS-DMA of each half (what the waits may leave in flight)
@@ -799,10 +809,11 @@ __global__ void __launch_bounds__(XP_THREADS, 2) conv_x3p_kernel(ConvArgs p, X3p
             step(8, 2, -1, KEEP, 0.f, V0, nothing);
             step(8, 3, -1, KEEP, 0.f, V0, nothing);
         } else {
-            step(5, 0, 6, FOLD, inv_cur, V2, nothing);
-            step(5, 1, 6, FOLD, inv_cur, V2, [&]() { if (more) dma_filters(nch, nx.cot, 0, 1, 0); });
-            step(5, 2, 6, FOLD, inv_cur, V2, nothing);
-            step(5, 3, 6, FOLD, inv_cur, V2, [&]() { if (more) dma_filters(nch, nx.cot, 0, 1, 1); });
+            constexpr std::integral_constant<bool, XP_MIDFOLD != 0> MID{};
+            step(5, 0, 6, MID, inv_cur, V2, nothing);
+            step(5, 1, 6, MID, inv_cur, V2, [&]() { if (more) dma_filters(nch, nx.cot, 0, 1, 0); });
+            step(5, 2, 6, MID, inv_cur, V2, nothing);
+            step(5, 3, 6, MID, inv_cur, V2, [&]() { if (more) dma_filters(nch, nx.cot, 0, 1, 1); });
             step(6, 0, 7, KEEP, 0.f, V4, [&]() { split_item(0); });
             step(6, 1, 7, KEEP, 0.f, V4, [&]() { split_item(1); });
             step(6, 2, 7, KEEP, 0.f, V4, [&]() { split_item(2); });
@@ -854,18 +865,15 @@ __global__ void __launch_bounds__(XP_THREADS, 2) conv_x3p_kernel(ConvArgs p, X3p
         rs = patch_rsrc(more ? nx.n : cur.n, more ? nch : chn);
     };
     while (true) {
-        int chn = cur.cb;
-        if (fin_valid) {  // (the workgroup's first item has no epilogue to carry: all its chunks are plain)
-            plan_next(chn);
-            chunk_body(std::true_type{}, cur, chn, later, more, nx, nch, rs);
-            ++chn;
-        }
-        for (; chn < cur.ce; ++chn) {
+        // (the first chunk of EVERY item runs the form without the fold at tap 5 - the workgroup's first item with no epilogue to carry
+        //  skips the pieces - so that a tile's arithmetic does not depend on where in a workgroup's list it sits)
+        plan_next(cur.cb);
+        chunk_body(std::true_type{}, cur, cur.cb, later, more, nx, nch, rs);
+        later = true;
+        for (int chn = cur.cb + 1; chn < cur.ce; ++chn) {
             plan_next(chn);
             chunk_body(std::false_type{}, cur, chn, later, more, nx, nch, rs);
-            later = true;
         }
-        later = true;
         if constexpr (GRAM) {
             if (cur.split == ksplit - 1) {
                 gram_phase(cur, inv_prev);
@@ -939,6 +947,18 @@ bool conv_x3p_supports(const ConvArgs& a) {
            (int64_t)a.Cout * a.OH * a.OW * 4 < (1ll << 31) && (int64_t)a.OH * a.OW <= (1ll << 24);
 }
 
+// workgroups of a launch: one per CU (MAUA_X3P_GROUPS / maua_conv_x3p_set_max_groups: fewer, so that small test shapes walk many items
+// per workgroup; a multiple of 8)
+static int g_xp_max_groups = 0;
+static int x3p_max_groups() {
+    if (g_xp_max_groups == 0) {
+        const char* e = getenv("MAUA_X3P_GROUPS");
+        const int v = e ? atoi(e) : 256;
+        g_xp_max_groups = v >= 8 ? v / 8 * 8 : 256;
+    }
+    return g_xp_max_groups;
+}
+
 #ifdef XP_STAMP
 static float* g_xp_stamp = nullptr;
 extern "C" void maua_xp_set_stamp_buffer(float* buf) { g_xp_stamp = buf; }
@@ -977,11 +997,7 @@ int conv_x3p_launch(const ConvArgs& a, int n, float w_scale, hipStream_t stream)
         return MAUA_E_UNSUPPORTED;
     }
     q.items = (int)items;
-    static const int max_groups = [] {
-        const char* e = getenv("MAUA_X3P_GROUPS");
-        const int v = e ? atoi(e) : 256;
-        return v >= 8 ? v / 8 * 8 : 256;
-    }();
+    const int max_groups = x3p_max_groups();
     q.groups = (int)(items >= max_groups ? max_groups : (items + 7) / 8 * 8);
     q.tiles_y = q.tiles / p.tiles_x;
     {
@@ -1044,6 +1060,12 @@ int maua_conv_x3p_split(int n, int cin, int h, int w, int cout, int pad) {
 size_t maua_conv_x3p_workspace_bytes(int n, int cin, int h, int w, int cout, int pad) {
     const int ks = maua_conv_x3p_split(n, cin, h, w, cout, pad);
     return ks > 1 ? (size_t)n * ks * cout * (h + 2 * pad - 2) * (w + 2 * pad - 2) * sizeof(float) : 0;
+}
+
+int maua_conv_x3p_set_max_groups(int groups) {
+    const int before = x3p_max_groups();
+    g_xp_max_groups = groups >= 8 ? groups / 8 * 8 : 256;
+    return before;
 }
 
 int maua_conv_x3p_preferred(int n, int cin, int h, int w, int cout, int pad) {

@@ -93,6 +93,7 @@ SIGNATURES = {
     "maua_conv_x3p_split": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "maua_conv_x3p_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "maua_conv_x3p_preferred": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    "maua_conv_x3p_set_max_groups": (c_i, [c_i]),
     "maua_conv3x3_x3p": (c_i, [c_p, c_p, c_i, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "maua_conv3x3_x3w_relu_pool": (c_i, [c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "maua_conv_x3w_dmat_bank_bytes": (c_sz, [c_i]),
@@ -401,6 +402,11 @@ def conv_x3p_split(n, cin, h, w, cout, pad):
 
 def conv_x3p_preferred(n, cin, h, w, cout, pad):
     return bool(lib().maua_conv_x3p_preferred(int(n), int(cin), int(h), int(w), int(cout), int(pad)))
+
+
+def conv_x3p_set_max_groups(groups):
+    """Tests: workgroups a conv_x3p launch may use (multiple of 8; 0 restores one per CU); returns the previous value."""
+    return int(lib().maua_conv_x3p_set_max_groups(int(groups)))
 
 
 def conv_x3p_workspace_bytes(n, cin, h, w, cout, pad):
