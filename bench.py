@@ -150,7 +150,8 @@ def accuracy_probe():
     out = {"layer": "3x3, 512 -> 512 channels, 128 x 128 (conv4_2's shape), seeded post-ReLU-like input, 32 x 32 output crop vs fp64",
            "fp32_cpu_conv": rel(F.conv2d(x[:, :, :34, :34], w, padding=1)[:, :, :32, :32])}
     xd, wd = x.cuda(), w.cuda()
-    for name, pack, run in (("conv_x3w", hip.conv_pack_filters_x3w, hip.conv3x3_x3w), ("conv_x3q", hip.conv_pack_filters_x3q, hip.conv3x3_x3q)):
+    for name, pack, run in (("conv_x3w", hip.conv_pack_filters_x3w, hip.conv3x3_x3w), ("conv_x3q", hip.conv_pack_filters_x3q, hip.conv3x3_x3q),
+                            ("conv_x3p", hip.conv_pack_filters_x3q, hip.conv3x3_x3p)):
         bank, _, wsc = pack(wd)
         out[name] = rel(run(xd, bank, wsc, None, cout, 1, False)[:, :, :32, :32].cpu())
     return {k: (round(v, 10) if isinstance(v, float) else v) for k, v in out.items()}
@@ -162,7 +163,7 @@ def pmc_traffic(prefix):
     doubled as MI355X_MICROARCH.md prescribes for gfx950 (our own calibration, profiles/pmc_r01_calibration.json: x2.0
     for 16 B/lane streams, x1.2-1.6 for 4 B/lane patterns, so this is an upper bound); writes are exact."""
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    path = next((os.path.join(here, f) for f in ("pmc_r04_traffic.json", "pmc_r03_traffic.json", "pmc_r02_traffic.json")
+    path = next((os.path.join(here, f) for f in ("pmc_r05_traffic.json", "pmc_r04_traffic.json", "pmc_r03_traffic.json", "pmc_r02_traffic.json")
                  if os.path.exists(os.path.join(here, f))), None)
     if path is None:
         return None
@@ -177,7 +178,7 @@ def pmc_traffic(prefix):
     if not n:
         return None
     return {"bytes": round((2 * rd + wr) / n),
-            "note": f"per launch, from profiles/{os.path.basename(path)} (separate rocprofv3 --pmc passes of this command): "
+            "note": f"NOT measured by this run: per launch, read from the committed profiles/{os.path.basename(path)} (separate rocprofv3 --pmc passes of this command): "
                     "2 x TCC_EA0_RDREQ x 64 B (gfx950 correction, upper bound for 4 B/lane loads) + write requests"}
 
 
@@ -540,7 +541,7 @@ def main():
     roofline = None
     x3w = x6 and models._x3_enabled() and models._x3w_enabled()
     x3q = x3w and models._x3q_min_channels() > 0
-    pmc = pmc_traffic(((("maua::conv_x3w_kernel<", "maua::conv_x3q_kernel<") if x3w else "maua::conv_x3_kernel<") if models._x3_enabled() else
+    pmc = pmc_traffic(((("maua::conv_x3w_kernel<", "maua::conv_x3q_kernel<", "maua::conv_x3p_kernel<") if x3w else "maua::conv_x3_kernel<") if models._x3_enabled() else
                        "maua::conv_x6_kernel<") if x6 else "maua::conv_mfma2_kernel<") if S == 1024 else None
     if conv:
         tot_fl, tot_ms = sum(c[0] for c in conv), sum(c[1] for c in conv)
@@ -558,8 +559,8 @@ def main():
         per_product = 3 if x3 else X6_MFMAS_PER_PRODUCT
         peak = BF16_MFMA_PEAK_TFLOPS / per_product if x6 else FP32_MFMA_PEAK_TFLOPS
         roofline = {"bound": "mfma",
-                    "kernel": ((("conv_x3w_kernel + conv_x3q_kernel (3x3 conv fwd + bwd-data, fp16x3: 16-channel chunks on 32x32x16 MFMAs below "
-                                 f"{models._x3q_min_channels()} consumed channels, 32-channel chunks on 16x16x32 MFMAs from there)" if x3q else
+                    "kernel": ((("conv_x3w_kernel + conv_x3q_kernel + conv_x3p_kernel (3x3 conv fwd + bwd-data, fp16x3: 16-channel chunks on 32x32x16 MFMAs "
+                                 "or 32-channel chunks on 16x16x32 MFMAs, per launch as `extra.routes` lists)" if x3q else
                                  "conv_x3w_kernel (3x3 conv fwd + bwd-data, fp16x3, 16-channel chunks)") if x3w else
                                 "conv_x3_kernel (3x3 conv fwd + bwd-data, fp16x3)") if x3 else
                                "conv_x6_kernel (3x3 conv fwd + bwd-data, bf16x6)") if x6 else "conv_mfma2_kernel (fwd + bwd-data)",
@@ -642,6 +643,15 @@ def main():
                             k: conv_part[k] for k in ("per_kernel_ms_per_step", "per_kernel_tflops", "per_kernel_alg_gbs") if k in conv_part}}
         out["roofline"] = roofline
     extra = {}
+    # What ran, so that the line describes itself: the kernel every convolution launch of one evaluation took (as the engine planned and
+    # launched it: one more eager evaluation with the route log on) and the planner settings that are not at their defaults, with any
+    # MAUA_* environment variable that was found and ignored (plan.py).
+    import plan
+    if opt.engine is not None:
+        extra["routes"] = [" ".join([r["pass"], r["kernel"], f"{r['consumed']}->{r['produced']}", f"@{r['plane'][0]}x{r['plane'][1]}",
+                                     f"[{r['tile']}]", f"ks{r['ksplit']}"] + [k for k in ("relu", "mask", "pool", "unpool", "gram", "gram_slabs", "accumulate") if r.get(k)])
+                           for r in opt.engine.describe_routes(opt.x if hasattr(opt, "x") else init.to(dev))]
+    extra["env_overrides"] = plan.env_overrides()
     if repeats:
         import statistics
         rates = sorted(a.steps * world / t for t in repeats)

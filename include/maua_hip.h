@@ -419,6 +419,14 @@ int maua_deprocess_u8(const float* x_bgr_chw, unsigned char* out_rgb_hwc, int h,
                       maua_stream_t stream);
 
 /* ---- batches of independent frames (vid_img without optical flow, reference style.py:192-290) ---------- */
+/* The library's tuning constants - routing thresholds and experiment switches (which kernel family a shape gets, forced K splits, the
+ * 128 x 128 Gram blocks ...): the host side's planner configuration (maua-style_amd/plan.py lists every name with its default and
+ * meaning) sets them when it loads the library; csrc/ reads them at every use and never reads the environment.  The reference has no
+ * counterpart (its knobs are argparse flags, /root/reference/config.py); this replaces the per-file `getenv` calls of rounds 1-4.
+ * maua_set_tuning: MAUA_E_INVAL for a name the library does not know.  maua_get_tuning: the value set, or `dflt`. */
+int maua_set_tuning(const char* name, double value);
+double maua_get_tuning(const char* name, double dflt);
+
 /* The convolution entry points take a batch dimension n; deterministic split-K sums its slabs in a fixed order, but HOW MANY
  * slabs a layer is cut into is a cost-model decision that would depend on n.  To keep a frame's result independent of how
  * many frames happen to share a launch, the cost models count the frames the CALLER PLANS per launch: the host sets that

@@ -29,6 +29,18 @@ inline int check_launch(const char* what) {
 
 constexpr int kWave = 64;
 
+// Kernels that ask for more than 64 KiB of dynamic LDS need hipFuncSetAttribute(MaxDynamicSharedMemorySize) once PER DEVICE (a process
+// that moves to a second device must opt in again there); `done` = the call site's bit mask of devices served (relaxed atomics: a
+// second thread at worst repeats the call).
+inline hipError_t opt_in_dynamic_lds(const void* kernel, int bytes, unsigned long long* done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 64;
+    if (dev < 64 && ((__atomic_load_n(done, __ATOMIC_RELAXED) >> dev) & 1ull)) return hipSuccess;
+    const hipError_t rc = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (rc == hipSuccess && dev < 64) __atomic_fetch_or(done, 1ull << dev, __ATOMIC_RELAXED);
+    return rc;
+}
+
 // Extents every entry point accepts, checked BEFORE any shape arithmetic (found by the UBSan build: h + 2 * pad - 2 and
 // friends overflow int for extents near INT_MAX): planes below 2^30 pixels (32-bit pixel offsets in the kernels), channel
 // counts and batch sizes that keep every product the host forms inside int64.
@@ -112,6 +124,8 @@ struct ConvArgs {
     int in_code_mask;               //   decision bytes; the kernel reads x as the pool's backward pass over them: element (y, x) =
                                     //   pooled[y/2][x/2] if (code & in_code_mask) == 2 (y & 1) + (x & 1) else 0  (mask 7: ReLU bit honoured, 3: not)
 };
+// conv_api.hip: the library's tuning constants (plan.py lists them; maua_set_tuning sets them, nothing reads the environment)
+double tuning(const char* name, double dflt);
 int split_batch_hint();  // conv_api.hip: frames per launch the caller plans with (split-K cost models), >= 1
 int conv_mfma_dispatch(const ConvArgs& a, int ks, int n, hipStream_t stream);
 int conv3x3_few_out(const ConvArgs& a, int n, hipStream_t stream);

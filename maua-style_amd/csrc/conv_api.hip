@@ -1,6 +1,7 @@
 // C-ABI entry points of the convolution family: route to the MFMA implicit-GEMM path (stride 1, k in {1,3,5}) or
 // to the direct path (everything else).
 #include <cstdlib>
+#include <cstring>
 
 #include "common.hpp"
 
@@ -14,17 +15,47 @@ static thread_local int g_split_batch_hint = 1;
 int split_batch_hint() { return g_split_batch_hint; }
 }  // namespace maua
 
+namespace maua {
+// Tuning constants of the library: routing thresholds and experiment switches that used to be `getenv` calls spread over csrc/.  The host
+// side (plan.py) owns the list and sets the values through maua_set_tuning when it loads the library; a name that was never set reads
+// as the caller's default.  Process-wide, read at every use (a few string compares per launch), not thread-safe against concurrent sets.
+static const char* const g_tuning_names[] = {"conv_few_out", "few_out_ks4_below", "x3w_ks", "x3w_stagger", "x3q_ks", "x3q_min_fill", "x3q_min_chunks",
+                                             "x3p_ks", "x3p_groups", "x3p_min_fill", "x3p_min_items", "x6_persist", "gram_x3", "gram_bwd_x3",
+                                             "gram_t128", "gram_t128_min_hw", "lbfgs_vec", "lbfgs_tri"};
+constexpr int kTunings = sizeof(g_tuning_names) / sizeof(g_tuning_names[0]);
+static double g_tuning_values[kTunings];
+static bool g_tuning_set[kTunings];
+static int tuning_index(const char* name) {
+    for (int i = 0; i < kTunings; ++i)
+        if (name && strcmp(name, g_tuning_names[i]) == 0) return i;
+    return -1;
+}
+double tuning(const char* name, double dflt) {
+    const int i = tuning_index(name);
+    return i >= 0 && g_tuning_set[i] ? g_tuning_values[i] : dflt;
+}
+}  // namespace maua
+
 static inline bool mfma_geometry(int kh, int kw, int stride) {
     return stride == 1 && kh == kw && (kh == 1 || kh == 3 || kh == 5);
 }
 // a 3x3 pass that produces <= 4 channels from many (conv1_1 backward-data) is vector-ALU work, not an MFMA tile
 static int conv_route(const ConvArgs& a, int ks, int n, hipStream_t stream) {
-    static const bool few_out = getenv("MAUA_CONV_NO_FEW_OUT") == nullptr;  // (experiment switch, read once)
+    const bool few_out = tuning("conv_few_out", 1) != 0;  // (experiment switch)
     if (ks == 3 && a.Cout <= 4 && a.Cin >= 16 && few_out) return conv3x3_few_out(a, n, stream);
     return conv_mfma_dispatch(a, ks, n, stream);
 }
 
 extern "C" {
+
+int maua_set_tuning(const char* name, double value) {
+    const int i = maua::tuning_index(name);
+    MAUA_REQUIRE(i >= 0, MAUA_E_INVAL, "set_tuning: unknown constant %s", name ? name : "(null)");
+    maua::g_tuning_values[i] = value;
+    maua::g_tuning_set[i] = true;
+    return MAUA_OK;
+}
+double maua_get_tuning(const char* name, double dflt) { return maua::tuning(name, dflt); }
 
 void maua_set_split_batch_hint(int frames) { maua::g_split_batch_hint = frames > 0 ? frames : 1; }
 int maua_get_split_batch_hint(void) { return maua::g_split_batch_hint; }

@@ -315,10 +315,7 @@ int conv3x3_few_out(const ConvArgs& a, int n, hipStream_t stream) {
     dim3 grid((unsigned)((a.OW + FO_TW - 1) / FO_TW), (unsigned)((a.OH + 4 * 4 - 1) / (4 * 4)), (unsigned)n);  // (4 waves x 4 rows)
     // channel quarters per wave where the plain grid leaves most of the chip idle (the planned frames per launch count, not this
     // launch's: a frame's bits do not depend on how many others share its launch)
-    static const int ks4_below = [] {
-        const char* e = getenv("MAUA_FEW_OUT_KS4_BELOW");
-        return e ? atoi(e) : 1024;
-    }();
+    const int ks4_below = (int)tuning("few_out_ks4_below", 1024);
     const bool ks4 = (int64_t)grid.x * grid.y * split_batch_hint() < ks4_below && a.Cin % 32 == 0;
     if (ks4) grid.y = (unsigned)((a.OH + 8 - 1) / 8);  // (one strip of 8 rows per workgroup)
 #define MAUA_FO(CO_)                                                                                            \

@@ -781,12 +781,16 @@ __global__ void __launch_bounds__(XP_THREADS, 2) conv_x3p_kernel(ConvArgs p, X3p
         }
         XP_MARK(1);
         step(4, 0, 5, KEEP, 0.f, VK, [&]() { E(16); });
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST1) : "memory");  // the patch is in registers (and this wave's planes of taps 5-8 in LDS)
+        // the patch is in registers (and this wave's planes of taps 5-8 in LDS): everything but the stores issued since - when there were any
+        // (the workgroup's first item carries no epilogue: nothing was stored, so the count would leave loads and LDS-DMA in flight)
+        if (EPI && fin_valid) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         step(4, 1, 5, KEEP, 0.f, V4, [&]() { publish_max(); });
         step(4, 2, 5, KEEP, 0.f, V4, nothing);
         step(4, 3, 5, KEEP, 0.f, V0, nothing);
         XP_MARK(2);
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ST1) : "memory");
+        if (EPI && fin_valid) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ST1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // XM: the filter planes of taps 0-4 are free, those of taps 5-8 and the maxima of the next chunk visible
         XP_MARK(3);
         load_ai(0, 5, 0);
@@ -834,7 +838,8 @@ __global__ void __launch_bounds__(XP_THREADS, 2) conv_x3p_kernel(ConvArgs p, X3p
         __builtin_amdgcn_s_barrier();  // X1: every wave is done reading the patch and the remaining filter planes
         XP_MARK(5);
         store_patch();
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ST2) : "memory");
+        if (EPI && fin_valid) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ST2) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // X2: patch and the filters of taps 0-4 of the next chunk are in LDS
         XP_MARK(6);
 #ifdef XP_STAMP
@@ -917,10 +922,7 @@ static int x3p_choose_split(const ConvArgs& a, int n) {
     const int64_t items = (int64_t)((a.OW + 31) / 32) * ((a.OH + XP_ROWS - 1) / XP_ROWS) * ((a.Cout + XP_COT - 1) / XP_COT) * split_batch_hint();
     (void)n;
     const int nchunks = a.Cin / 32;
-    static const int forced = [] {
-        const char* e = getenv("MAUA_X3P_KS");
-        return e ? atoi(e) : 0;
-    }();
+    const int forced = (int)tuning("x3p_ks", 0);
     // (every split gets chunks: ks is brought down to the number of non-empty ranges of ceil(nchunks / ks) chunks)
     auto whole = [&](int ks) { const int cps = (nchunks + ks - 1) / ks; return (nchunks + cps - 1) / cps; };
     if (forced > 0) return whole(forced <= nchunks / 2 ? forced : (nchunks >= 4 ? nchunks / 2 : 1));
@@ -947,16 +949,12 @@ bool conv_x3p_supports(const ConvArgs& a) {
            (int64_t)a.Cout * a.OH * a.OW * 4 < (1ll << 31) && (int64_t)a.OH * a.OW <= (1ll << 24);
 }
 
-// workgroups of a launch: one per CU (MAUA_X3P_GROUPS / maua_conv_x3p_set_max_groups: fewer, so that small test shapes walk many items
+// workgroups of a launch: one per CU (tuning constant x3p_groups / maua_conv_x3p_set_max_groups: fewer, so that small test shapes walk many items
 // per workgroup; a multiple of 8)
-static int g_xp_max_groups = 0;
+static int g_xp_max_groups = 0;  // (0: the tuning constant x3p_groups, 256 by default)
 static int x3p_max_groups() {
-    if (g_xp_max_groups == 0) {
-        const char* e = getenv("MAUA_X3P_GROUPS");
-        const int v = e ? atoi(e) : 256;
-        g_xp_max_groups = v >= 8 ? v / 8 * 8 : 256;
-    }
-    return g_xp_max_groups;
+    const int v = g_xp_max_groups > 0 ? g_xp_max_groups : (int)tuning("x3p_groups", 256);
+    return v >= 8 ? v / 8 * 8 : 256;
 }
 
 #ifdef XP_STAMP
@@ -967,7 +965,8 @@ extern "C" void maua_xp_set_stamp_buffer(float* buf) { g_xp_stamp = buf; }
 template <bool OM, bool POOL, bool UNPOOL, bool GRAM>
 static int xp_launch_one(const ConvArgs& p, const X3pArgs& q, hipStream_t stream) {
     const void* fn = reinterpret_cast<const void*>(&conv_x3p_kernel<OM, POOL, UNPOOL, GRAM>);
-    hipError_t rc = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, XP_LDS_BYTES);  // (per device: cheap, set every time)
+    static unsigned long long served = 0;  // (once per instantiation and device)
+    const hipError_t rc = opt_in_dynamic_lds(fn, XP_LDS_BYTES, &served);
     if (rc != hipSuccess) {
         set_error("conv_x3p: hipFuncSetAttribute: %s", hipGetErrorString(rc));
         return (int)rc;
@@ -1064,7 +1063,7 @@ size_t maua_conv_x3p_workspace_bytes(int n, int cin, int h, int w, int cout, int
 
 int maua_conv_x3p_set_max_groups(int groups) {
     const int before = x3p_max_groups();
-    g_xp_max_groups = groups >= 8 ? groups / 8 * 8 : 256;
+    g_xp_max_groups = groups >= 8 ? groups / 8 * 8 : 0;
     return before;
 }
 
@@ -1075,14 +1074,8 @@ int maua_conv_x3p_preferred(int n, int cin, int h, int w, int cout, int pad) {
     // the pixels its 16 x 32 tiles cover beyond the plane.  Below the bounds conv_x3q / conv_x3w run.
     if (!maua_conv_x3p_supported(cin, h, w, cout, pad) || !conv_dims_ok(n, cin, h, w, cout, pad)) return 0;
     const int oh = h + 2 * pad - 2, ow = w + 2 * pad - 2;
-    static const double min_fill = [] {
-        const char* e = getenv("MAUA_X3P_MIN_FILL");
-        return e ? atof(e) : 0.8;
-    }();
-    static const int min_items = [] {
-        const char* e = getenv("MAUA_X3P_MIN_ITEMS");
-        return e ? atoi(e) : 512;
-    }();
+    const double min_fill = tuning("x3p_min_fill", 0.8);
+    const int min_items = (int)tuning("x3p_min_items", 512);
     const int ks = maua_conv_x3p_split(n, cin, h, w, cout, pad);
     const int64_t items = (int64_t)((ow + 31) / 32) * ((oh + XP_ROWS - 1) / XP_ROWS) * (cout / XP_COT) * split_batch_hint() * ks;
     const double fill = (double)items / (double)(((items + 255) / 256) * 256);

@@ -665,10 +665,7 @@ static int x3q_choose_split(const ConvArgs& a, int n) {
     const int64_t wgs = (int64_t)((a.OW + 31) / 32) * ((a.OH + XQ_ROWS - 1) / XQ_ROWS) * ((a.Cout + XQ_COT - 1) / XQ_COT) * split_batch_hint();
     (void)n;  // (the policy looks at the frames the job plans per launch, not at this launch's batch: conv_x3w.hip)
     const int nchunks = a.Cin / 32;
-    static const int forced = [] {  // experiments: MAUA_X3Q_KS=k splits every launch k ways (when the layer has the chunks)
-        const char* e = getenv("MAUA_X3Q_KS");
-        return e ? atoi(e) : 0;
-    }();
+    const int forced = (int)tuning("x3q_ks", 0);  // experiments: splits every launch k ways (when the layer has the chunks)
     if (forced > 0) return forced <= nchunks / 2 ? forced : (nchunks >= 4 ? nchunks / 2 : 1);
     if (wgs >= 1024 || nchunks < 4) return 1;  // (four rounds and more: the tail is small)
     const double out_mb = (double)split_batch_hint() * a.Cout * a.OH * a.OW * 4.0 / 1e6;
@@ -697,9 +694,9 @@ extern "C" void maua_xq_set_stamp_buffer(float* buf) { g_xq_stamp = buf; }
 
 template <bool ACC, bool OM, bool POOL, bool UNPOOL>
 static int xq_launch_one(const ConvArgs& p, dim3 grid, float w_inv, hipStream_t stream) {
-    // once per instantiation: the kernel's 150 KiB of dynamic LDS are above the default limit
-    static const hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3q_kernel<ACC, OM, POOL, UNPOOL>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, XQ_LDS_BYTES);
+    // once per instantiation and device: the kernel's 150 KiB of dynamic LDS are above the default limit
+    static unsigned long long served = 0;
+    const hipError_t rc = opt_in_dynamic_lds(reinterpret_cast<const void*>(&conv_x3q_kernel<ACC, OM, POOL, UNPOOL>), XQ_LDS_BYTES, &served);
     if (rc != hipSuccess) {
         set_error("conv_x3q: hipFuncSetAttribute: %s", hipGetErrorString(rc));
         return (int)rc;
@@ -796,14 +793,8 @@ int maua_conv_x3q_preferred(int n, int cin, int h, int w, int cout, int pad) {
     a.OH = h + 2 * pad - 2;
     a.OW = w + 2 * pad - 2;
     if (a.OH <= 0 || a.OW <= 0) return 0;
-    static const double min_fill = [] {
-        const char* e = getenv("MAUA_X3Q_MIN_FILL");
-        return e ? atof(e) : 0.85;
-    }();
-    static const int min_chunks = [] {
-        const char* e = getenv("MAUA_X3Q_MIN_CHUNKS");
-        return e ? atoi(e) : 4;
-    }();
+    const double min_fill = tuning("x3q_min_fill", 0.85);
+    const int min_chunks = (int)tuning("x3q_min_chunks", 4);
     const int ks = x3q_choose_split(a, n);
     const int64_t wgs = (int64_t)((a.OW + 31) / 32) * ((a.OH + XQ_ROWS - 1) / XQ_ROWS) * ((a.Cout + XQ_COT - 1) / XQ_COT) * split_batch_hint() * ks;
     const double fill = (double)wgs / (double)(((wgs + 255) / 256) * 256);

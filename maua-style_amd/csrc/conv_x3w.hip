@@ -748,10 +748,7 @@ static int x3w_choose_split(const ConvArgs& a, int n) {
               // launch (maua_set_split_batch_hint, 1 by default): vid_img's frames are then computed with the same summation
               // order whether they run one at a time or sixteen together - bit-identical results whatever the grouping.
     const int nchunks = a.Cin / 16;
-    static const int forced = [] {  // experiments: MAUA_X3W_KS=k splits every launch k ways (when the layer has the chunks)
-        const char* e = getenv("MAUA_X3W_KS");
-        return e ? atoi(e) : 0;
-    }();
+    const int forced = (int)tuning("x3w_ks", 0);  // experiments: splits every launch k ways (when the layer has the chunks)
     if (forced > 0) return forced <= nchunks / 2 ? forced : (nchunks >= 4 ? nchunks / 2 : 1);
     if (wgs >= 2048 || nchunks < 4) return 1;
     const double out_mb = (double)split_batch_hint() * a.Cout * a.OH * a.OW * 4.0 / 1e6;
@@ -792,11 +789,7 @@ int conv_x3w_launch(const ConvArgs& a, int n, float w_scale, hipStream_t stream)
     const bool acc = ks == 1 && a.accumulate != 0, om = ks == 1 && a.omask != nullptr;
     const float w_inv = 1.f / w_scale;
     {
-        static const int stagger = [] {
-            const char* e = getenv("MAUA_X3W_STAGGER");
-            return e ? atoi(e) : 7;
-        }();
-        p.stagger = stagger;
+        p.stagger = (int)tuning("x3w_stagger", 7);
     }
     if (a.pool_codes && ks == 1) hipLaunchKernelGGL((conv_x3w_kernel<false, false, true>), grid, dim3(256), 0, stream, p, w_inv);
     else if (a.in_codes && om) hipLaunchKernelGGL((conv_x3w_kernel<false, true, false, true>), grid, dim3(256), 0, stream, p, w_inv);

@@ -516,7 +516,7 @@ int conv_x6_launch(const ConvArgs& a, int n, hipStream_t stream) {
     // once, each walking several tiles of its XCD band with cross-tile prefetch; measured equal on 1024x1024 (the other
     // workgroups of a CU already hide a workgroup's prologue / epilogue), and it loses on uneven tile counts.
     const int64_t cot = (a.Cout + X6_COT - 1) / X6_COT, per_xcd = (tiles + 7) / 8;
-    static const bool persist = getenv("MAUA_X6_PERSIST") && atoi(getenv("MAUA_X6_PERSIST")) != 0;
+    const bool persist = tuning("x6_persist", 0) != 0;
     int64_t g8 = per_xcd;
     if (persist) {
         g8 = (1024 + cot * n * ks * 8 - 1) / (cot * n * ks * 8);

@@ -952,16 +952,9 @@ gram_bwd_kernel(const float* __restrict__ d, const float* __restrict__ f, const 
 // (-1.1 % ... +0.4 % of a step) and NIN's 127 x 127 / 63 x 63 maps (-0.9 %) against +1.2 % / +1.0 % at 1024 / 2048.
 // MAUA_GRAM_T128 (read once per process): 0 = 64 x 64 everywhere, 2 = every map of MIN_HW pixels and more (ragged last stages included).
 static bool gram_tile128(int c, int64_t hw) {
-    static const int mode = [] {
-        const char* e = getenv("MAUA_GRAM_T128");
-        const char* x3 = getenv("MAUA_GRAM_X3");
-        if (x3 && x3[0] == '0') return 0;
-        return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1;
-    }();
-    static const int64_t min_hw = [] {
-        const char* e = getenv("MAUA_GRAM_T128_MIN_HW");
-        return e ? (int64_t)atoll(e) : (int64_t)16 * GK;
-    }();
+    const int t128 = (int)tuning("gram_t128", 1);
+    const int mode = tuning("gram_x3", 1) == 0 ? 0 : (t128 >= 0 && t128 <= 2 ? t128 : 1);
+    const int64_t min_hw = (int64_t)tuning("gram_t128_min_hw", 16 * GK);
     return mode && c >= 128 && hw >= min_hw && (mode == 2 || hw % GK == 0) && (int64_t)(c + 128) * hw < (1ll << 29);
 }
 // npairs: 64-channel tile pairs = slabs per slice of HW (the slab format of every kernel); *wgs_per_slab (nullable): workgroups per slice
@@ -1035,29 +1028,19 @@ static int gram_partial_impl(const float* f, float* row_mean_out, int c, int64_t
         rc = check_launch("row_mean_finish_kernel");
         if (rc) return rc;
     }
-    static const bool use_x3 = [] {
-        const char* e = getenv("MAUA_GRAM_X3");  // "0": the fp32-MFMA kernel (A/B comparisons)
-        return !(e && e[0] == '0');
-    }();
+    const bool use_x3 = tuning("gram_x3", 1) != 0;  // 0: the fp32-MFMA kernel (A/B comparisons)
     if (use_x3 && gram_tile128(c, hw)) {
         int wgs;
         gram_plan(c, hw, &npairs, &ksplit, &chunk, &wgs);
-        static bool attr128 = false;
-        if (!attr128) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gram_x3_partial128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GX128_LDS);
-            attr128 = true;
-        }
+        static unsigned long long attr128 = 0;
+        (void)opt_in_dynamic_lds(reinterpret_cast<const void*>(gram_x3_partial128_kernel), GX128_LDS, &attr128);
         hipLaunchKernelGGL(gram_x3_partial128_kernel, dim3(wgs, ksplit), dim3(512), GX128_LDS, s, f, center ? row_mean_out : nullptr, (float*)workspace,
                            c, hw, ksplit, chunk);
     } else if (use_x3) {
         const int nplanes = c <= GT ? 2 : 4;
         const size_t lds = 2 * ((size_t)nplanes * GXPLANE + 64);
-        static bool attr_set = false;
-        if (!attr_set) {  // more than 64 KB of dynamic LDS needs the opt-in
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gram_x3_partial_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GXBUF);
-            attr_set = true;
-        }
+        static unsigned long long attr_set = 0;  // more than 64 KB of dynamic LDS needs the opt-in
+        (void)opt_in_dynamic_lds(reinterpret_cast<const void*>(gram_x3_partial_kernel), 2 * GXBUF, &attr_set);
         hipLaunchKernelGGL(gram_x3_partial_kernel, dim3(npairs, ksplit), dim3(256), lds, s, f, center ? row_mean_out : nullptr,
                            (float*)workspace, c, hw, ksplit, chunk, nplanes);
     }
@@ -1149,10 +1132,7 @@ int maua_gram_partial_batch(int count, const float* const* fs, float* const* mea
         const size_t need = given > 0 ? (size_t)given * GT * GT * sizeof(float) : maua_gram_workspace_bytes(cs[i], hws[i]);
         MAUA_REQUIRE(workspace_bytes[i] >= need, MAUA_E_WORKSPACE, "gram_partial_batch: workspace %zu < %zu (layer %d)", workspace_bytes[i], need, i);
     }
-    static const bool use_x3 = [] {
-        const char* e = getenv("MAUA_GRAM_X3");
-        return !(e && e[0] == '0');
-    }();
+    const bool use_x3 = tuning("gram_x3", 1) != 0;
     if (!use_x3) {  // (the fp32-MFMA comparison kernel has no batched form)
         for (int i = 0; i < count; ++i) {
             MAUA_REQUIRE(!(slab_counts && slab_counts[i] > 0), MAUA_E_UNSUPPORTED, "gram_partial_batch: ready slabs need the fp16x3 kernels' fold");
@@ -1161,12 +1141,9 @@ int maua_gram_partial_batch(int count, const float* const* fs, float* const* mea
         }
         return MAUA_OK;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gram_x3_partial_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GXBUF);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gram_x3_partial128_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GX128_LDS);
-        attr_set = true;
-    }
+    static unsigned long long attr_b = 0, attr_b128 = 0;
+    (void)opt_in_dynamic_lds(reinterpret_cast<const void*>(gram_x3_partial_batch_kernel), 2 * GXBUF, &attr_b);
+    (void)opt_in_dynamic_lds(reinterpret_cast<const void*>(gram_x3_partial128_batch_kernel), GX128_LDS, &attr_b128);
     hipStream_t s = (hipStream_t)stream;
     if (means) {  // covariance form: the row means of those layers first (two launches for all of them; their fp64 partial sums use the
                   // start of each layer's workspace, which its slabs overwrite afterwards)
@@ -1302,10 +1279,7 @@ int maua_gram_bwd(const float* d_sym, const float* f, const float* row_mean, con
                   int64_t hw, int accumulate, void* workspace, size_t workspace_bytes, maua_stream_t stream) {
     MAUA_REQUIRE(d_sym && f && gf && c > 0 && hw > 0 && c <= (1 << 16) && hw < (1ll << 30), MAUA_E_INVAL, "gram_bwd: bad args");
     MAUA_REQUIRE(hw < (1ll << 31), MAUA_E_UNSUPPORTED, "gram_bwd: plane too large");
-    static const bool use_x3 = [] {
-        const char* e = getenv("MAUA_GRAM_BWD_X3");
-        return !(e && e[0] == '0');
-    }();
+    const bool use_x3 = tuning("gram_bwd_x3", 1) != 0;
     if (use_x3 && hw < (1ll << 30)) {
         // fp16x3 product (conv1x1_x3.hip): D is symmetric, so its rows serve as [cout][cin]; centring folded into the staging
         ConvArgs a{};

@@ -844,10 +844,7 @@ int maua_lbfgs_iterate(void* state, float* x, const float* grad, const float* lo
     int groups = (1024 + L.nwg - 1) / L.nwg;  // pair-loop groups: aim at ~4 workgroups per CU
     if (groups > L.m1) groups = L.m1;
     const bool aligned = count % 4 == 0 && (((uintptr_t)x | (uintptr_t)grad) & 15) == 0;
-    static const bool vec_on = [] {
-        const char* e = getenv("MAUA_LBFGS_VEC");
-        return !e || atoi(e) != 0;
-    }();
+    const bool vec_on = tuning("lbfgs_vec", 1) != 0;
     if (aligned && vec_on)
         hipLaunchKernelGGL(lbfgs_pair_dots_kernel<true>, dim3(L.nwg, groups), dim3(256), lds1, s, hdr, grad, S, Y, partial, count, L.m1);
     else
@@ -859,17 +856,10 @@ int maua_lbfgs_iterate(void* state, float* x, const float* grad, const float* lo
     if (rc) return rc;
     const size_t lds3 = sizeof(double) * 2 * (L.m1 + 1);
     const size_t lds_tri = sizeof(double) * ((size_t)L.m1 * (L.m1 | 1) + 2 * (size_t)L.m1 + 384 + 16);
-    static const bool tri_on = [] {
-        const char* e = getenv("MAUA_LBFGS_TRI");
-        return !e || atoi(e) != 0;
-    }();
+    const bool tri_on = tuning("lbfgs_tri", 1) != 0;
     if (tri_on && L.m1 <= 128 && lds_tri <= 144 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lbfgs_coeffs_tri_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-            attr_set = true;
-        }
+        static unsigned long long attr_set = 0;
+        (void)opt_in_dynamic_lds(reinterpret_cast<const void*>(lbfgs_coeffs_tri_kernel), 144 * 1024, &attr_set);
         hipLaunchKernelGGL(lbfgs_coeffs_tri_kernel, dim3(1), dim3(256), lds_tri, s, hdr, dots, M, coef, L.m1, history, lr,
                            tolerance_change, tolerance_grad, loss);
     } else if (L.nb_ids <= 256)

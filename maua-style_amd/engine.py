@@ -25,6 +25,7 @@ import torch
 import hip
 import loss as loss_mod
 import models as models_mod
+import plan
 
 
 class UnsupportedNet(RuntimeError):
@@ -61,7 +62,7 @@ class StyleEngine:
         self.batch_hint = 1  # frames per launch the job plans with: fixes the convolutions' split-K policy (hip.set_split_batch_hint)
         # 3x3 stride-1 convs run on the bf16 matrix cores with a 3-way operand split (fp32 accuracy, conv_x6.hip) unless
         # MAUA_CONV_X6=0 asks for the fp32-MFMA kernels (A/B comparisons)
-        mode = os.environ.get("MAUA_CONV_X6", "1")  # "1" both passes, "fwd" / "bwd" one of them, "0" off
+        mode = plan.get("conv_x6")  # "1" both passes, "fwd" / "bwd" one of them, "0" off
         self.use_x6 = mode != "0"
         self.x6_fwd, self.x6_bwd = mode in ("1", "fwd"), mode in ("1", "bwd")
         self.timer = None  # bench.py: list receiving (tag, algorithmic flops, bytes, start event, end event) per launch
@@ -144,7 +145,7 @@ class StyleEngine:
         self.gbuf = {k: torch.empty(v, device=dev) for k, v in shapes.items()}
         # 2x2/2 max pools on even planes keep their decisions (one byte per window) for the backward pass
         self.pool_codes = {}
-        if os.environ.get("MAUA_POOL_CODES", "1") != "0":
+        if plan.on("pool_codes"):
             for s in self.steps:
                 if s.kind == "pool" and s.k == 2 and s.stride == 2 and s.mode == "max" and \
                         hip.pool2x2_codes_supported(*shapes[s.src]):
@@ -171,25 +172,25 @@ class StyleEngine:
         # and ONE launch at the end of the evaluation forms every loss value and the totals (hip.loss_ledger_sum)
         self.ledger = None
         self.slots_f64 = None  # tests set this (zeros_like(slots_all, dtype=float64)): the losses before their rounding to fp32
-        if (B == 1 or self.independent) and os.environ.get("MAUA_LOSS_LEDGER", "1") != "0":
+        if (B == 1 or self.independent) and plan.on("loss_ledger"):
             self.ledger = hip.loss_ledger(B, n_slots, dev)
         # Gram / loss chains of a single image: split-K slabs per layer, ONE finishing launch per evaluation (MAUA_GRAM_BATCH=0: a
         # finishing launch per layer, the round-2 form; same bits)
-        self.gram_batch_on = os.environ.get("MAUA_GRAM_BATCH", "1") != "0"
-        self.gram_partial_batch_on = os.environ.get("MAUA_GRAM_PARTIAL_BATCH", "1") != "0"  # (... and one partial launch for the Gram-form layers)
+        self.gram_batch_on = plan.on("gram_batch")
+        self.gram_partial_batch_on = plan.on("gram_partial_batch")  # (... and one partial launch for the Gram-form layers)
         self._gram_wsp, self._gram_batches = getattr(self, "_gram_wsp", {}), {}
         # conv + ReLU whose only consumer is a 2x2 / 2 max pool with kept decisions, on conv_x3w.hip: the pool runs in the convolution's
         # epilogue (or, where a small grid splits the channel loop, in the pass that adds the slabs) and the full-size activation is
         # never written (nothing reads it: the backward pass routes by the decision bytes).  fused_pool[conv step] = pool step.
         self.fused_pool = {}
-        if self.x6_fwd and os.environ.get("MAUA_FUSE_POOL", "1") != "0":
+        if self.x6_fwd and plan.on("fuse_pool"):
             for s in self.steps:
                 if s.kind != "conv" or not s.relu or s.k != 3 or s.stride != 1:
                     continue
                 users = [t for t in self.steps if t.src == s.dst and t is not s]
                 if len(users) == 1 and users[0].kind == "pool" and id(users[0]) in self.pool_codes and \
                         self._x6_ok(s, s.mod.out_channels) and models_mod.conv3x3_fwd_is_x3w(s.mod, *shapes[s.src][2:]) and \
-                        s.mod.out_channels % 8 == 0 and (os.environ.get("MAUA_FUSE_POOL_SPLIT", "1") != "0" or hip.conv_x3w_split(
+                        s.mod.out_channels % 8 == 0 and (plan.on("fuse_pool_split") or hip.conv_x3w_split(
                             B, shapes[s.src][1], shapes[s.src][2], shapes[s.src][3], s.mod.out_channels, s.pad) == 1):
                     self.fused_pool[id(s)] = users[0]
         self.pooled_by_conv = {id(v) for v in self.fused_pool.values()}
@@ -209,7 +210,7 @@ class StyleEngine:
                 if len(users) == 1 and users[0].kind == "pool" and id(users[0]) in self.pool_codes and \
                         self._x6_ok(s, s.mod.in_channels) and models_mod.conv3x3_bwd_is_x3w(s.mod, *shapes[s.dst][2:]):
                     self.pool_groups.add(id(s))
-                    if os.environ.get("MAUA_FUSE_UNPOOL", "1") != "0":
+                    if plan.on("fuse_unpool"):
                         self.fused_unpool[id(s)] = users[0]
                         self.gbuf[s.dst] = torch.empty(shapes[s.dst], device="meta")
         self.unpooled_by_conv = {id(v) for v in self.fused_unpool.values()}
@@ -217,7 +218,7 @@ class StyleEngine:
         # on conv_x3w.hip, that pass takes the Gram backward along (D . F as extra one-tap chunks of its K loop) instead of a
         # separate read-modify-write pass over the gradient map: fused_gram[conv step] = (style step, bank of D, 1 / scale).
         self.fused_gram = {}
-        max_c = int(os.environ.get("MAUA_FUSE_GRAM_MAX_C", "256"))  # pays on the shallow, bandwidth-bound layers (relu4_1: break-even)
+        max_c = plan.get_int("fuse_gram_max_c")  # pays on the shallow, bandwidth-bound layers (relu4_1: break-even)
         if (B == 1 or self.independent) and self.x6_bwd and max_c > 0:
             relu_out = {s.dst for s in self.steps if s.kind == "conv" and s.relu}
             for s in self.steps:
@@ -236,8 +237,8 @@ class StyleEngine:
         # disappears.  Single images whose Gram chains are batched behind the forward pass.  image_gram[conv step] = style step.
         self.image_gram = {}
         # (not for frames of a planned batch - batch_hint > 1: a frame's bits must not depend on how many others share its launches)
-        if B == 1 and self.batch_hint == 1 and self.ledger is not None and self.x6_fwd and os.environ.get("MAUA_IMAGE_GRAM", "1") != "0" and \
-                os.environ.get("MAUA_GRAM_X3", "1") != "0" and models_mod._image_kernel_enabled():  # (ready slabs are folded by the fp16x3 route only)
+        if B == 1 and self.batch_hint == 1 and self.ledger is not None and self.x6_fwd and plan.on("image_gram") and \
+                plan.on("gram_x3") and models_mod._image_kernel_enabled():  # (ready slabs are folded by the fp16x3 route only)
             for s in self.steps:
                 if s.kind != "conv" or not s.relu or s.k != 3 or s.stride != 1 or s.mod.in_channels > 3 or s.mod.out_channels != 64 or \
                         not self._x6_ok(s, 64):
@@ -289,7 +290,7 @@ class StyleEngine:
                              hip.conv_x3p_workspace_bytes(n, cout, oh, ow, cin, 2 - s.pad))
         self.ws = torch.empty(ws, dtype=torch.uint8, device=dev)
         self.x_static = torch.empty(self.shape, device=dev)
-        if os.environ.get("MAUA_DEBUG_POISON") == "1":  # tests: every buffer starts as NaN, so a read-before-write shows up
+        if plan.get("debug_poison") == "1":  # tests: every buffer starts as NaN, so a read-before-write shows up
             for t in list(self.act.values()) + list(self.gbuf.values()) + list(self.gram.values()) + list(self.dmat.values()) + \
                     list(self.gram_d.values()) + list(self.dmat_d.values()):
                 if t is not None and not t.is_meta:
@@ -304,11 +305,11 @@ class StyleEngine:
         # partial kernels of all layers in one launch behind the forward pass the serial form wins up to 1448 x 1448 (724: 263.7 vs
         # 261.8 it/s, 1024: 178.9 vs 177.8, 1448: 80.3 vs 80.9, 2048: 44.07 vs 44.35) - the side stream is for the largest images.
         self.side, self.side_ws, self.ev_main, self.ev_side = [], [], None, []
-        aside = os.environ.get("MAUA_STYLE_STREAM", "auto")
+        aside = plan.get("style_stream")
         self.style_aside = B == 1 and self.ledger is not None and \
             (aside == "1" or (aside == "auto" and x.shape[2] * x.shape[3] >= 1536 * 1536))
-        if (B > 1 and self.independent and int(os.environ.get("MAUA_SIDE_STREAMS", "4")) > 0) or self.style_aside:
-            ns = min(B, int(os.environ.get("MAUA_SIDE_STREAMS", "4"))) if B > 1 else 1
+        if (B > 1 and self.independent and plan.get_int("side_streams") > 0) or self.style_aside:
+            ns = min(B, plan.get_int("side_streams")) if B > 1 else 1
             small = hip.reduce_workspace_bytes(max(t.numel() for t in self.gbuf.values()) // B)
             for s in self.steps:
                 if s.kind == "style":
@@ -465,6 +466,7 @@ class StyleEngine:
                 elif id(s) in self.image_gram and self._image_gram_now(s, a[s.src].shape):
                     st, _ = self.image_gram[id(s)]
                     gws = self._gram_ws(st, 64, a[s.dst].shape[2] * a[s.dst].shape[3], x.device)
+                    models_mod._route("conv_image", a[s.src], s.mod.out_channels, s.pad, False, "27 (channel, tap) pairs as K, bf16x6", relu=True, gram_slabs=True)
                     self._timed("conv3x3_split_fwd", fl, nb, lambda: hip.conv3x3_image_gram(a[s.src], s.mod.bank_image(), s.pad, a[s.dst], gws))
                     emitted.add(id(st))
                 elif self.x6_fwd and self._x6_ok(s, s.mod.out_channels):
@@ -478,6 +480,7 @@ class StyleEngine:
                         a[s.src], s.mod, False, out=a[s.dst], relu=s.relu, workspace=self.ws))
                 else:
                     wf, _ = s.mod.banks()
+                    models_mod._route("conv2d_fwd", a[s.src], s.mod.out_channels, s.pad, False, "direct / fp32 MFMA", relu=s.relu)
                     self._timed("conv_other_fwd", fl, nb, lambda: hip.conv2d_fwd(
                         a[s.src], wf, s.mod.bias_device(), s.k, s.stride, s.pad, s.relu, out=a[s.dst], workspace=self.ws))
             elif s.kind == "relu":
@@ -618,7 +621,7 @@ class StyleEngine:
                 self._timed("gram_fwd", 0, sum(l["c"] * l["c"] * 8 for l in grp), fin[1].run)
             packs = [(l["dmat"], self.fused_style[id(l["step"])][1][0], self.fused_style[id(l["step"])][2]) for l in batch
                      if id(l["step"]) in self.fused_style]
-            if os.environ.get("MAUA_DMAT_PACK_BATCH", "1") == "0":
+            if not plan.on("dmat_pack_batch"):
                 for d, b, i in packs:
                     hip.conv_pack_dmat_x3w(d, b, i)
                 packs = []
@@ -777,6 +780,8 @@ class StyleEngine:
                         g[s.dst], s.mod, True, out=g[s.src], out_relu_mask=im, workspace=self.ws))
                 else:
                     _, wb = s.mod.banks()
+                    models_mod._route("conv3x3_few_out" if s.k == 3 and s.stride == 1 and s.mod.in_channels <= 4 and s.mod.out_channels >= 16 else "conv2d_bwd_data",
+                                      g[s.dst], s.mod.in_channels, s.k - 1 - s.pad, True, "direct / fp32 MFMA", mask=im is not None)
                     self._timed("conv_other_bwd", fl, nb, lambda: hip.conv2d_bwd_data(
                         g[s.dst], None, wb, s.mod.weight.detach(), a[s.src].shape, s.k, s.stride, s.pad, out=g[s.src],
                         in_relu_mask=im, workspace=self.ws))
@@ -882,6 +887,27 @@ class StyleEngine:
         self.x_static.copy_(x)
         self.graph.replay()
         return self.slots, self.total, self.gbuf[0]
+
+    def describe_routes(self, x):
+        """Which kernel every convolution launch of one evaluation at `x` takes, as planned and launched (one eager evaluation with
+        models.ROUTE_LOG recording): a list of records in launch order - kernel family, pass, channels, plane, tile, K splits, and what
+        rides along (mask, pool, unpool, gram).  The conv1_1 backward (64 -> 3: conv3x3_few_out) and NIN's non-3x3 layers are listed by
+        the generic entry points' names.  bench.py prints it as `routes`."""
+        self._prepare(x)
+        names = []
+        idx = 0
+        for s in self.steps:
+            if s.kind == "conv":
+                idx += 1
+                names.append(f"conv#{idx} {s.mod.in_channels}->{s.mod.out_channels} k{s.k}")
+        models_mod.ROUTE_LOG = []
+        try:
+            self._run(x)
+            torch.cuda.synchronize()
+            log = models_mod.ROUTE_LOG
+        finally:
+            models_mod.ROUTE_LOG = None
+        return log
 
     def saved_bytes(self):
         """Bytes held by activations + gradient buffers for the current shape."""

@@ -77,6 +77,8 @@ SIGNATURES = {
     "maua_color_match_apply": (c_i, [c_p, c_p, c_f, c_p, c_p, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "maua_resize_bilinear": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
     "maua_deprocess_u8": (c_i, [c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_p]),
+    "maua_set_tuning": (c_i, [ctypes.c_char_p, ctypes.c_double]),
+    "maua_get_tuning": (ctypes.c_double, [ctypes.c_char_p, ctypes.c_double]),
     "maua_set_split_batch_hint": (None, [c_i]),
     "maua_get_split_batch_hint": (c_i, []),
     "maua_conv_x3w_split": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
@@ -144,7 +146,16 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = L
+        import plan
+        plan.forward_to_library(L)  # the library's share of the planner configuration (it never reads the environment)
+        plan.warn_ignored()         # MAUA_* variables nothing reads any more: said once, loudly
     return _lib
+
+
+def apply_plan():
+    """Hand the planner configuration's library fields to the library again (after a programmatic change of plan.OVERRIDES)."""
+    import plan
+    plan.forward_to_library(lib())
 
 
 def _check(rc, what):

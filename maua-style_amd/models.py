@@ -22,69 +22,75 @@ import torch
 import torch.nn as nn
 
 import hip
+import plan
 from loss import ContentLoss, GramMatrix, ScaleGradients, StyleLoss, TVLoss  # noqa: F401  (re-exported like `from loss import *`)
 
 # --------------------------------------------------------------------------------------------------
 # HIP-backed layers
 # --------------------------------------------------------------------------------------------------
 
+ROUTE_LOG = None  # a list while engine.StyleEngine.describe_routes records which kernel every convolution launch takes
+
+
+def _route(kernel, x, produced, pad, backward, tile, ksplit=1, **fused):
+    """One record per convolution launch (only while ROUTE_LOG is a list): kernel family, geometry, tile, K splits, what rides along."""
+    if ROUTE_LOG is not None:
+        rec = {"kernel": kernel, "pass": "bwd" if backward else "fwd", "consumed": int(x.shape[1]), "produced": int(produced),
+               "plane": [int(x.shape[2]), int(x.shape[3])], "n": int(x.shape[0]), "pad": int(pad), "tile": tile, "ksplit": int(ksplit)}
+        rec.update({k: v for k, v in fused.items() if v})
+        ROUTE_LOG.append(rec)
+
+
 
 def _x6_mode():
-    """MAUA_CONV_X6: "1" (default) = 3x3 stride-1 convs on the bf16 matrix cores with a 3-way operand split in both
+    """planner field conv_x6: "1" (default) = 3x3 stride-1 convs on the bf16 matrix cores with a 3-way operand split in both
     passes, "fwd" / "bwd" = only that pass, "0" = fp32 matrix cores everywhere."""
-    import os
-    mode = os.environ.get("MAUA_CONV_X6", "1")
+    mode = plan.get("conv_x6")
     return mode in ("1", "fwd"), mode in ("1", "bwd")
 
 
 def _x3_enabled():
-    """MAUA_CONV_X3: "1" (default) = the fp32-accurate 3x3 convolution runs as fp16x3 (two-part fp16 split, three MFMAs per
+    """planner field conv_x3: "1" (default) = the fp32-accurate 3x3 convolution runs as fp16x3 (two-part fp16 split, three MFMAs per
     product block, conv_x3.hip; the 3-channel image layer keeps the exact bf16x6 products); "0" = bf16x6 everywhere (and NIN's 1x1 / 5x5 layers on the fp32 matrix cores)
     (three-part bf16 split, six MFMAs, conv_x6.hip).  Measured pixel-gradient error against the fp64 reference:
     2.8e-7 / 2.6e-7; the reference's own fp32 arithmetic: 4.5e-7 (4.6e-7 if the image layer ran on fp16x3 too)."""
-    import os
-    return os.environ.get("MAUA_CONV_X3", "1") == "1"
+    return plan.get("conv_x3") == "1"
 
 
 def _x3w_enabled():
-    """MAUA_CONV_X3W: "1" (default) = layers whose consumed channel count is a multiple of 16 run the wide-tile fp16x3 kernel
+    """planner field conv_x3w: "1" (default) = layers whose consumed channel count is a multiple of 16 run the wide-tile fp16x3 kernel
     (conv_x3w.hip: 16-channel chunks, four accumulators per wave, two workgroups per CU); "0" = conv_x3.hip everywhere."""
-    import os
-    return os.environ.get("MAUA_CONV_X3W", "1") == "1"
+    return plan.get("conv_x3w") == "1"
 
 
 def _image_kernel_enabled():
-    """MAUA_CONV_IMAGE: "1" (default) = a 3x3 layer that consumes at most three channels (conv1_1) runs conv_img.hip in the forward pass;
+    """planner field conv_image: "1" (default) = a 3x3 layer that consumes at most three channels (conv1_1) runs conv_img.hip in the forward pass;
     "0" = conv_x6.hip's general kernel with the image as one 8-channel chunk (the same bf16x6 products, other summation order)."""
-    import os
-    return os.environ.get("MAUA_CONV_IMAGE", "1") == "1"
+    return plan.get("conv_image") == "1"
 
 
 def _x3q_min_channels():
-    """MAUA_CONV_X3Q: the smallest consumed channel count (a multiple of 32) from which a 3x3 layer runs conv_x3q.hip - 32-channel chunks on
+    """planner field conv_x3q: the smallest consumed channel count (a multiple of 32) from which a 3x3 layer runs conv_x3q.hip - 32-channel chunks on
     v_mfma_f32_16x16x32_f16, one workgroup of eight waves per CU (round 4) - instead of conv_x3w.hip; "0" = never.  Default 256: measured
     on one box (tools/bench_x3q.py, 1024 x 1024 layer shapes) 1.13-1.22 x conv_x3w at 512 channels, 1.04-1.13 x at 256, 1.02 x at 128;
     the 64- and 128-channel layers run two to four chunks per workgroup, too few to pay for the single workgroup's prologue."""
-    import os
-    v = os.environ.get("MAUA_CONV_X3Q", "256")
+    v = plan.get("conv_x3q")
     return int(v) if v.isdigit() else 256
 
 
 def _x3p_min_channels():
-    """MAUA_CONV_X3P: the smallest consumed channel count (a multiple of 32) from which a 3x3 layer runs conv_x3p.hip - conv_x3q's
+    """planner field conv_x3p: the smallest consumed channel count (a multiple of 32) from which a 3x3 layer runs conv_x3p.hip - conv_x3q's
     workgroup made persistent (round 5): one stream of chunks per CU, the next tile staged under the current one, the epilogue under the
     next tile's first chunk - instead of conv_x3q.hip / conv_x3w.hip; "0" = never.  Default 64: every VGG layer it supports."""
-    import os
-    v = os.environ.get("MAUA_CONV_X3P", "64")
+    v = plan.get("conv_x3p")
     return int(v) if v.isdigit() else 64
 
 
 def conv3x3_is_x3p(consumed, h, w, pad, produced, n=1, accumulate=False):
     """Whether a 3x3 stride-1 pass that consumes `consumed` channels of an h x w plane and produces `produced` runs on conv_x3p.hip
     (forward: pad = the layer's padding; backward-data: 2 - padding)."""
-    import os
     mc = _x3p_min_channels()
-    return _x3_enabled() and _x3w_enabled() and mc > 0 and mc <= consumed <= int(os.environ.get("MAUA_CONV_X3P_MAX", "100000")) and not accumulate and h * w >= _x3w_min_pixels() and \
+    return _x3_enabled() and _x3w_enabled() and mc > 0 and mc <= consumed <= plan.get_int("conv_x3p_max") and not accumulate and h * w >= _x3w_min_pixels() and \
         hip.conv_x3p_supported(consumed, h, w, produced, pad) and hip.conv_x3p_preferred(n, consumed, h, w, produced, pad)
 
 
@@ -92,9 +98,8 @@ def _x3p_gram_enabled(n, c_in, c_out, h, w):
     """Whether the Gram backward rides in conv_x3p's launch (its D . F chunks run between two items, latency-exposed) or in conv_x3w's
     (MAUA_X3P_GRAM_MIN_MB, default 700): measured in the network, conv_x3p's form wins 7-8 % where the launch's maps - gradient in,
     gradient out, F - are beyond what the 256 MB of Infinity Cache hold (2048 x 2048 images) and loses 2-3 % where they are not (1024)."""
-    import os
     mb = n * (c_in + 2 * c_out) * h * w * 4 / 1e6
-    return mb >= float(os.environ.get("MAUA_X3P_GRAM_MIN_MB", "700"))
+    return mb >= plan.get_float("x3p_gram_min_mb")
 
 
 X3Q_UNPOOL_MIN_CHANNELS = 512  # conv_x3q's unpooling form pays from here: its corner vectors are cut in the exposed store phase
@@ -111,17 +116,10 @@ def conv3x3_is_x3q(consumed, h, w, pad, at_least=0, produced=None, n=1):
         hip.conv_x3q_supported(consumed, h, w, pad) and (produced is None or hip.conv_x3q_preferred(n, consumed, h, w, produced, pad))
 
 
-_X3W_MIN_PIXELS = None
-
-
 def _x3w_min_pixels():
     """Planes smaller than this run conv_x3.hip (4-row tiles, 1024 workgroup slots): on maps of a few tiles the wide kernel's
-    8-row tiles and 512 slots leave the chip emptier (measured at 256 x 256: 726 vs 793 it/s).  MAUA_X3W_MIN_PIXELS overrides."""
-    global _X3W_MIN_PIXELS
-    if _X3W_MIN_PIXELS is None:
-        import os
-        _X3W_MIN_PIXELS = int(os.environ.get("MAUA_X3W_MIN_PIXELS", 64 * 64))
-    return _X3W_MIN_PIXELS
+    8-row tiles and 512 slots leave the chip emptier (measured at 256 x 256: 726 vs 793 it/s).  Planner field x3w_min_pixels."""
+    return plan.get_int("x3w_min_pixels")
 
 
 def conv3x3_mfma(x, mod, backward, out=None, out_relu_mask=None, relu=False, accumulate=False, workspace=None, pool_group=False):
@@ -134,28 +132,38 @@ def conv3x3_mfma(x, mod, backward, out=None, out_relu_mask=None, relu=False, acc
     else:
         cout, p, bias = mod.out_channels, pad, mod.bias_device()
     consumed = mod.out_channels if backward else mod.in_channels
+    n, h, w = x.shape[0], x.shape[2], x.shape[3]
     if conv3x3_is_x3p(consumed, x.shape[2], x.shape[3], p, cout, x.shape[0], accumulate):
         bf, bb, wsc = mod.banks3q()
+        _route("conv_x3p", x, cout, p, backward, "64co x 16x32px, persistent", hip.conv_x3p_split(n, consumed, h, w, cout, p) if workspace is not None else 1,
+               mask=out_relu_mask is not None, relu=relu)
         return hip.conv3x3_x3p(x, bb if backward else bf, wsc, bias, cout, p, relu, out=out, out_relu_mask=out_relu_mask, workspace=workspace)
     if conv3x3_is_x3q(consumed, x.shape[2], x.shape[3], p, X3Q_UNPOOL_MIN_CHANNELS if pool_group else 0, cout, x.shape[0]):
         bf, bb, wsc = mod.banks3q()
+        _route("conv_x3q", x, cout, p, backward, "64co x 16x32px", hip.conv_x3q_split(n, consumed, h, w, cout, p) if workspace is not None else 1,
+               mask=out_relu_mask is not None, relu=relu, accumulate=accumulate)
         return hip.conv3x3_x3q(x, bb if backward else bf, wsc, bias, cout, p, relu, out=out, out_relu_mask=out_relu_mask,
                                accumulate=accumulate, workspace=workspace)
     if _x3_enabled() and _x3w_enabled() and x.shape[2] * x.shape[3] >= _x3w_min_pixels() and \
             hip.conv_x3w_supported(consumed, x.shape[2], x.shape[3], p):
         bf, bb, wsc = mod.banks3w()
+        _route("conv_x3w", x, cout, p, backward, "64co x 8x32px", hip.conv_x3w_split(n, consumed, h, w, cout, p) if workspace is not None else 1,
+               mask=out_relu_mask is not None, relu=relu, accumulate=accumulate)
         return hip.conv3x3_x3w(x, bb if backward else bf, wsc, bias, cout, p, relu, out=out, out_relu_mask=out_relu_mask,
                                accumulate=accumulate, workspace=workspace)
     if _x3_enabled() and consumed > 4:
         # (the image layer, 3 input channels, stays on the exact bf16x6 products: it differences neighbouring pixels of large
         # common magnitude - the one place where the 2 bits fp16x3 drops could show - and costs one partly empty chunk)
         bf, bb, wsc = mod.banks3()
+        _route("conv_x3", x, cout, p, backward, "64co x 4x32px", mask=out_relu_mask is not None, relu=relu, accumulate=accumulate)
         return hip.conv3x3_x3(x, bb if backward else bf, wsc, bias, cout, p, relu, out=out, out_relu_mask=out_relu_mask,
                               accumulate=accumulate, workspace=workspace)
     if not backward and consumed <= 3 and out_relu_mask is None and not accumulate and _image_kernel_enabled():
         # the image layer: the 27 (channel, tap) pairs as K, no LDS - bound by writing the activation (conv_img.hip; same bf16x6 products)
+        _route("conv_image", x, cout, p, backward, "27 (channel, tap) pairs as K, bf16x6", relu=relu)
         return hip.conv3x3_image(x, mod.bank_image(), cout, p, relu, out=out)
     bf, bb = mod.banks6()
+    _route("conv_x6" if cout > 4 or consumed < 16 else "conv3x3_few_out", x, cout, p, backward, "bf16x6", mask=out_relu_mask is not None, relu=relu, accumulate=accumulate)
     return hip.conv3x3_x6(x, bb if backward else bf, bias, cout, p, relu, out=out, out_relu_mask=out_relu_mask,
                           accumulate=accumulate, workspace=workspace)
 
@@ -171,12 +179,18 @@ def conv3x3_relu_pool(x, mod, pooled, codes, workspace=None):
     small grids, with a workspace - a split channel loop whose adding pass pools)."""
     if conv3x3_is_x3p(mod.in_channels, x.shape[2], x.shape[3], mod.padding[0], mod.out_channels, x.shape[0]):
         bf, _, wsc = mod.banks3q()
+        _route("conv_x3p", x, mod.out_channels, mod.padding[0], False, "64co x 16x32px, persistent",
+               hip.conv_x3p_split(x.shape[0], mod.in_channels, x.shape[2], x.shape[3], mod.out_channels, mod.padding[0]) if workspace is not None else 1, relu=True, pool=True)
         return hip.conv3x3_x3p(x, bf, wsc, mod.bias_device(), mod.out_channels, mod.padding[0], True, out=pooled, pool_codes=codes,
                                workspace=workspace)
     if conv3x3_is_x3q(mod.in_channels, x.shape[2], x.shape[3], mod.padding[0], 0, mod.out_channels, x.shape[0]):
         bf, _, wsc = mod.banks3q()
+        _route("conv_x3q", x, mod.out_channels, mod.padding[0], False, "64co x 16x32px",
+               hip.conv_x3q_split(x.shape[0], mod.in_channels, x.shape[2], x.shape[3], mod.out_channels, mod.padding[0]) if workspace is not None else 1, relu=True, pool=True)
         return hip.conv3x3_x3q_relu_pool(x, bf, wsc, mod.bias_device(), mod.out_channels, mod.padding[0], pooled, codes, workspace=workspace)
     bf, _, wsc = mod.banks3w()
+    _route("conv_x3w", x, mod.out_channels, mod.padding[0], False, "64co x 8x32px",
+           hip.conv_x3w_split(x.shape[0], mod.in_channels, x.shape[2], x.shape[3], mod.out_channels, mod.padding[0]) if workspace is not None else 1, relu=True, pool=True)
     return hip.conv3x3_x3w_relu_pool(x, bf, wsc, mod.bias_device(), mod.out_channels, mod.padding[0], pooled, codes, workspace=workspace)
 
 
@@ -194,9 +208,12 @@ def conv3x3_bwd_with_gram(gy, mod, feature_map, dmat_bank, dmat_inv_scale, out, 
     if conv3x3_is_x3p(mod.out_channels, gy.shape[2], gy.shape[3], 2 - mod.padding[0], mod.in_channels, gy.shape[0]) and \
             _x3p_gram_enabled(gy.shape[0], mod.out_channels, mod.in_channels, gy.shape[2], gy.shape[3]):
         _, bb, wsc = mod.banks3q()
+        _route("conv_x3p", gy, mod.in_channels, 2 - mod.padding[0], True, "64co x 16x32px, persistent", mask=True, gram=True)
         return hip.conv3x3_x3p(gy, bb, wsc, None, mod.in_channels, 2 - mod.padding[0], False, out=out, out_relu_mask=feature_map,
                                dmat_bank=dmat_bank, dmat_inv_scale=dmat_inv_scale, workspace=workspace)
     _, bb, wsc = mod.banks3w()
+    _route("conv_x3w", gy, mod.in_channels, 2 - mod.padding[0], True, "64co x 8x32px",
+           hip.conv_x3w_split(gy.shape[0], mod.out_channels, gy.shape[2], gy.shape[3], mod.in_channels, 2 - mod.padding[0]) if workspace is not None else 1, mask=True, gram=True)
     return hip.conv3x3_x3w_gram(gy, bb, wsc, feature_map, dmat_bank, dmat_inv_scale, mod.in_channels, 2 - mod.padding[0], out=out,
                                 workspace=workspace)
 
@@ -209,15 +226,18 @@ def conv3x3_bwd_from_pooled(gy_pooled, codes, honour_relu_bit, mod, out, out_rel
     if conv3x3_is_x3p(mod.out_channels, out.shape[2], out.shape[3], 2 - mod.padding[0], mod.in_channels, gy_pooled.shape[0]) and \
             (dmat_bank is None or _x3p_gram_enabled(out.shape[0], mod.out_channels // 4, mod.in_channels, out.shape[2], out.shape[3])):
         _, bb, wsc = mod.banks3q()
+        _route("conv_x3p", out, mod.in_channels, 2 - mod.padding[0], True, "64co x 16x32px, persistent", mask=out_relu_mask is not None, unpool=True, gram=dmat_bank is not None)
         return hip.conv3x3_x3p(gy_pooled, bb, wsc, None, mod.in_channels, 2 - mod.padding[0], False, out=out, out_relu_mask=out_relu_mask,
                                in_codes=codes, honour_relu_bit=honour_relu_bit, dmat_bank=dmat_bank, dmat_inv_scale=dmat_inv_scale,
                                workspace=workspace)
     if dmat_bank is None and conv3x3_is_x3q(mod.out_channels, out.shape[2], out.shape[3], 2 - mod.padding[0], X3Q_UNPOOL_MIN_CHANNELS,
                                             mod.in_channels, gy_pooled.shape[0]):
         _, bb, wsc = mod.banks3q()
+        _route("conv_x3q", out, mod.in_channels, 2 - mod.padding[0], True, "64co x 16x32px", mask=out_relu_mask is not None, unpool=True)
         return hip.conv3x3_x3q_unpool(gy_pooled, codes, honour_relu_bit, bb, wsc, mod.in_channels, 2 - mod.padding[0], out=out,
                                       out_relu_mask=out_relu_mask, workspace=workspace)
     _, bb, wsc = mod.banks3w()
+    _route("conv_x3w", out, mod.in_channels, 2 - mod.padding[0], True, "64co x 8x32px", mask=out_relu_mask is not None, unpool=True, gram=dmat_bank is not None)
     return hip.conv3x3_x3w_unpool(gy_pooled, codes, honour_relu_bit, bb, wsc, mod.in_channels, 2 - mod.padding[0], out=out,
                                   out_relu_mask=out_relu_mask, dmat_bank=dmat_bank, dmat_inv_scale=dmat_inv_scale, workspace=workspace)
 
@@ -233,6 +253,7 @@ def conv1x1_is_mfma(mod, backward):
 def conv1x1_mfma(x, mod, backward, out=None, out_relu_mask=None, relu=False, workspace=None):
     """1x1 layer on the fp16 matrix cores in fp16x3 arithmetic; backward-data multiplies by the transposed weights."""
     w2d, w2d_t = mod.mats()
+    _route("conv1x1_x3", x, mod.in_channels if backward else mod.out_channels, 0, backward, "64co x 128px", mask=out_relu_mask is not None, relu=relu)
     if backward:
         return hip.conv1x1_x3(x, w2d_t, None, False, out=out, out_relu_mask=out_relu_mask, workspace=workspace)
     return hip.conv1x1_x3(x, w2d, mod.bias_device(), relu, out=out, out_relu_mask=out_relu_mask, workspace=workspace)
@@ -249,6 +270,7 @@ def conv5x5_is_mfma(mod, backward):
 def conv5x5_mfma(x, mod, backward, out=None, out_relu_mask=None, relu=False, workspace=None):
     bf, bb, wsc = mod.banks_kxk()
     k, pad = mod.kernel_size[0], mod.padding[0]
+    _route("conv_kxk_x3", x, mod.in_channels if backward else mod.out_channels, k - 1 - pad if backward else pad, backward, "k x k, fp16x3", mask=out_relu_mask is not None, relu=relu)
     if backward:
         return hip.conv_kxk_x3(x, bb, wsc, None, mod.in_channels, k, k - 1 - pad, False, out=out, out_relu_mask=out_relu_mask,
                                workspace=workspace)

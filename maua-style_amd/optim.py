@@ -21,6 +21,7 @@ import tqdm
 import config as config_mod
 import engine as engine_mod
 import hip
+import plan
 import models
 from utils import limit_host_threads, wrapping_slice
 
@@ -184,7 +185,7 @@ class PixelOptimizer:
         # A bundle of an earlier call on this network: same shapes, same optimiser parameters, and nothing the captured graph
         # baked in has moved since (engine buffers: alloc_epoch; targets / weights / coefficients: _graph_key)
         self._bundle_key, bundle = None, None
-        if self.engine is not None and self.kind == "lbfgs" and grad_hook is None and os.environ.get("MAUA_GRAPH_BUNDLES", "1") != "0":
+        if self.engine is not None and self.kind == "lbfgs" and grad_hook is None and plan.on("graph_bundles"):
             self._bundle_key = ("lbfgs", tuple(self.x.shape), self.independent, self.batch_hint, int(args.lbfgs_num_correction),
                                 float(args.lbfgs_tolerance_change), float(args.lbfgs_tolerance_grad))
             self.engine._prepare(self.x)  # (allocates for this shape if the engine last served another one: a new epoch)
@@ -216,7 +217,7 @@ class PixelOptimizer:
         hg = getattr(args, "hip_graph", None)
         if hg is None:
             enough = planned_iters is None or planned_iters >= (GRAPH_MIN_ITERS_REPEATED if repeated and self._bundle_key else GRAPH_MIN_ITERS)
-            hg = os.environ.get("MAUA_HIP_GRAPH", "1") != "0" and (enough or bundle is not None)
+            hg = plan.on("hip_graph") and (enough or bundle is not None)
         self.use_graph = bool(hg)
         self._graph = bundle["graph"] if (bundle is not None and self.use_graph) else None
         self._keep_bundle = bool(repeated) and self._bundle_key is not None

@@ -32,6 +32,7 @@ import dist
 import load
 import models
 import optim
+import plan
 from utils import draw_match_noise, limit_host_threads, match_histogram, name
 
 
@@ -277,7 +278,7 @@ def frames_per_batch(size, args=None):
     and `--save_iter` writes `<frame output>_<size>[_<iter>].png` from inside each frame's own call (optim.py:230-236)."""
     if args is not None and (getattr(args, "normalize_weights", False) or getattr(args, "save_iter", 0) > 0):
         return 1
-    forced = int(os.environ.get("MAUA_FRAME_BATCH", "0"))
+    forced = plan.get_int("frame_batch")
     return forced if forced > 0 else planned_frames(size)
 
 
@@ -359,7 +360,7 @@ def vid_img(args):
     # the way out.  Decoded, rescaled content frames are kept per scale as well (every pass starts from them again).
     # Both are bounded (MAUA_FRAME_CACHE_MB, default 4096 MB each): a clip of thousands of frames must not grow the device
     # footprint with its length (the reference holds one frame at a time); a miss decodes the PNG again.
-    budget = int(float(os.environ.get("MAUA_FRAME_CACHE_MB", "4096")) * (1 << 20))
+    budget = int(plan.get_float("frame_cache_mb") * (1 << 20))
     written, content_cache = _ByteBudget(budget), _ByteBudget(budget)
     for size_n, (current_size, num_iters) in enumerate(zip(args.image_sizes, args.num_iters)):
         print("\nCurrent size {}px".format(current_size))

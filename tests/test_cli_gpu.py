@@ -365,7 +365,7 @@ def test_vid_img_sharded_over_two_ranks_matches_one_rank(tmp_path, weight_files)
 
 @pytest.mark.parametrize("variant", ["plain", "hist_random_init", "normalize_weights", "save_iter"])
 def test_vid_img_frame_batches_match_the_frame_by_frame_loop(tmp_path, weight_files, variant):
-    """vid_img optimises its independent frames in batches; MAUA_FRAME_BATCH=1 is the reference's frame-by-frame loop.  The
+    """vid_img optimises its independent frames in batches; frame_batch=1 (MAUA_PLAN) is the reference's frame-by-frame loop.  The
     same files bit for bit - also with colour matching on and --init random, where every frame draws from the global RNG
     (jitter before and after its optimisation, the initial image in between): the batched path draws in the same order."""
     import synth
@@ -387,7 +387,7 @@ def test_vid_img_frame_batches_match_the_frame_by_frame_loop(tmp_path, weight_fi
     outs = {}
     for batch in ("1", "3"):
         out = tmp_path / f"out{batch}"
-        env = dict(os.environ, PYTHONPATH=PKG, MAUA_FRAME_BATCH=batch)
+        env = dict(os.environ, PYTHONPATH=PKG, MAUA_PLAN="frame_batch=" + batch)
         r = subprocess.run([sys.executable, os.path.join(PKG, "style.py")] + flags + ["--output_dir", str(out)], cwd=PKG, env=env,
                            capture_output=True, text=True, timeout=1200)
         assert r.returncode == 0, r.stderr[-3000:]

@@ -707,7 +707,7 @@ def test_gram_backward_fused_into_the_convolution_equals_the_separate_pass(weigh
     import engine
     res = {}
     for max_c in ("0", "64", "512"):
-        monkeypatch.setenv("MAUA_FUSE_GRAM_MAX_C", max_c)
+        monkeypatch.setitem(__import__("plan").OVERRIDES, "fuse_gram_max_c", max_c)
         args = product_args(weight_files, S=128)
         content, style, init = synth.images(128)
         net, losses = build(args, content, [style], 128)
@@ -728,7 +728,7 @@ def test_pool_backward_in_the_convolution_staging_changes_no_bit(weight_files, m
     import engine
     res = {}
     for flag in ("0", "1"):
-        monkeypatch.setenv("MAUA_FUSE_UNPOOL", flag)
+        monkeypatch.setitem(__import__("plan").OVERRIDES, "fuse_unpool", flag)
         monkeypatch.setenv("MAUA_DEBUG_POISON", "1")
         args = product_args(weight_files, S=512)
         content, style, init = synth.images(512)
@@ -751,8 +751,8 @@ def test_odd_planes_take_the_fused_pool_paths_and_change_no_bit(weight_files, mo
     import engine
     res = {}
     for flags in (("0", "0"), ("1", "1")):
-        monkeypatch.setenv("MAUA_FUSE_POOL", flags[0])
-        monkeypatch.setenv("MAUA_FUSE_UNPOOL", flags[1])
+        monkeypatch.setitem(__import__("plan").OVERRIDES, "fuse_pool", flags[0])
+        monkeypatch.setitem(__import__("plan").OVERRIDES, "fuse_unpool", flags[1])
         monkeypatch.setenv("MAUA_DEBUG_POISON", "1")
         args = product_args(weight_files, S=S)
         content, style, init = synth.images(S)
@@ -814,7 +814,7 @@ def test_pool_backward_in_the_convolution_staging_on_a_frame_batch(weight_files,
     inits = torch.cat([synth.images(S, seed=60 + k)[2] for k in range(B)])
     out = {}
     for flag in ("0", "1"):
-        monkeypatch.setenv("MAUA_FUSE_UNPOOL", flag)
+        monkeypatch.setitem(__import__("plan").OVERRIDES, "fuse_unpool", flag)
         args = product_args(weight_files, optimizer="lbfgs", S=S, N=N)
         optim.set_model_args(args, S)
         net, losses = models.load_model(args)
@@ -828,7 +828,7 @@ def test_pool_in_the_convolution_epilogue_changes_no_bit(weight_files, monkeypat
     import engine
     res = {}
     for flag in ("0", "1"):
-        monkeypatch.setenv("MAUA_FUSE_POOL", flag)
+        monkeypatch.setitem(__import__("plan").OVERRIDES, "fuse_pool", flag)
         monkeypatch.setenv("MAUA_DEBUG_POISON", "1")
         args = product_args(weight_files, S=512)
         content, style, init = synth.images(512)
@@ -849,7 +849,7 @@ def test_gram_slabs_from_the_image_layer_change_nothing_but_rounding(weight_file
     import engine
     res = {}
     for flag in ("0", "1"):
-        monkeypatch.setenv("MAUA_IMAGE_GRAM", flag)
+        monkeypatch.setitem(__import__("plan").OVERRIDES, "image_gram", flag)
         monkeypatch.setenv("MAUA_DEBUG_POISON", "1")
         args = product_args(weight_files, S=256)
         content, style, init = synth.images(256)

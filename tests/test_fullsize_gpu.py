@@ -130,19 +130,28 @@ def test_full_size_pool_backward_routes_every_gradient_once():
 
 
 def test_full_size_lbfgs_descends(setup):
+    """torch.optim.LBFGS without a line search (what the reference runs, /root/reference/optim.py:170-199) on this objective is chaotic in
+    its first steps: the pair (s, y) of the first tiny move amplifies whatever the gradient's ReLU / max-pool decisions do between two
+    nearby images, and the third evaluation lands on a spike whose height varies by two orders of magnitude under a 1e-6 relative change of
+    the start image or any change of a kernel route (measured, tools/_build/dbg4.py in round 5: 5.6e5 ... 5.9e7 from 5.41e5, the
+    reference's own arithmetic included).  The update recovers from every one of them; how many iterations that takes depends on the
+    spike.  So: forty iterations (a spike of 6e7 is back under the start value after ~25), a finite loss at every step, descent at the end."""
     import optim
     args, net, losses, eng, x = setup
     _, before, _ = eng.feval(x)
     before = float(before)
     opt = optim.PixelOptimizer(net, losses, x.cpu(), args)
-    for _ in range(15):
+    totals = []
+    for _ in range(40):
         _, total = opt.step()
+        totals.append(total)
     torch.cuda.synchronize()
+    assert all(math.isfinite(float(t)) for t in totals)
     _, after, _ = eng.feval(opt.x)
     after = float(after)
     st = opt.state.status()
-    assert math.isfinite(after) and after < 0.99 * before, (before, after)  # no line search, first step 1/|g|_1: slow start
-    assert st["n_iter"] == 15 and st["history_len"] >= 10 and not st["stopped"]
+    assert math.isfinite(after) and after < 0.99 * before, (before, after, [float(t) for t in totals])
+    assert st["n_iter"] == 40 and st["history_len"] >= 10 and not st["stopped"]
 
 
 # ---------------------------------------------------------------------------------------------------------

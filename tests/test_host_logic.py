@@ -293,3 +293,54 @@ def test_cpu_baseline_builds_the_model_it_is_asked_for(monkeypatch):
     assert seen == {"model_file": "nin", "cov": True, "style": "relu1,relu3,relu5,relu7,relu9,relu11"}
     assert r["model"] == "nin" and r["kind"] == "port" and r["value"] > 0
     assert r["cpu_model"] is None or "nin" not in str(r["cpu_model"]).lower()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The planner configuration (plan.py): one table of settings, ten honoured environment variables, everything else reported
+# ---------------------------------------------------------------------------------------------------------------------------------
+def test_plan_reports_unknown_and_stale_maua_variables(monkeypatch):
+    """A MAUA_* variable nothing reads (a stale switch of an earlier round, a typo) is ignored AND reported: bench.py prints
+    plan.env_overrides() in every line (`extra.env_overrides`), hip.lib() warns once."""
+    import plan
+    for k in list(os.environ):
+        if k.startswith("MAUA_"):
+            monkeypatch.delenv(k)
+    assert plan.env_overrides() == {"in_effect": {}, "ignored": []}
+    monkeypatch.setenv("MAUA_GRAM_T128", "0")          # a switch of rounds 3-4: now a planner field, not an environment variable
+    monkeypatch.setenv("MAUA_NO_SUCH_THING", "1")
+    monkeypatch.setenv("MAUA_CONV_X3", "0")            # one of the ten honoured variables
+    rep = plan.env_overrides()
+    assert rep["ignored"] == ["MAUA_GRAM_T128", "MAUA_NO_SUCH_THING"]
+    assert rep["in_effect"] == {"conv_x3": "0"} and plan.get("gram_t128") == "1"
+    monkeypatch.setenv("MAUA_PLAN", "gram_t128=0, x3p_min_items=1024")
+    assert plan.get("gram_t128") == "0" and plan.get_int("x3p_min_items") == 1024
+    assert plan.env_overrides()["in_effect"] == {"conv_x3": "0", "gram_t128": "0", "x3p_min_items": "1024"}
+    monkeypatch.setenv("MAUA_PLAN", "no_such_field=1")
+    with pytest.raises(ValueError):
+        plan.get("gram_t128")
+    monkeypatch.delenv("MAUA_PLAN")
+    monkeypatch.setitem(plan.OVERRIDES, "fuse_pool", "0")  # what the GPU tests use
+    assert not plan.on("fuse_pool") and plan.env_overrides()["in_effect"]["fuse_pool"] == "0"
+    assert len(plan.ENV_VARS) <= 10
+
+
+def test_plan_library_fields_reach_the_library(monkeypatch):
+    """Every "lib" field of plan.FIELDS is a tuning constant libmaua_hip knows (maua_set_tuning), and a value set through MAUA_PLAN is
+    what the library reads back - csrc/ has no getenv left."""
+    import glob
+    import plan
+    import hip
+    L = hip.lib()
+    for k, (default, who, _) in plan.FIELDS.items():
+        if who == "lib":
+            assert L.maua_set_tuning(k.encode(), float(default)) == 0, k
+    assert L.maua_set_tuning(b"no_such_constant", 1.0) != 0
+    monkeypatch.setenv("MAUA_PLAN", "x3q_min_fill=0.5")
+    hip.apply_plan()
+    assert L.maua_get_tuning(b"x3q_min_fill", -1.0) == 0.5
+    monkeypatch.delenv("MAUA_PLAN")
+    hip.apply_plan()
+    assert L.maua_get_tuning(b"x3q_min_fill", -1.0) == 0.85
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "maua-style_amd", "csrc")
+    for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp")):
+        assert "getenv(" not in open(f).read().replace("`getenv`", ""), f

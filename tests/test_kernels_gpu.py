@@ -592,7 +592,7 @@ def test_conv1x1_x3_channel_shift_is_the_gram_centring(hip, cin, cout, hw):
 
 
 def test_gram_128_blocks_stress_and_the_64_route_subprocess():
-    """Layers of 128+ channels and 1024+ pixels in whole 64-pixel stages multiply in 128 x 128 blocks (MAUA_GRAM_T128, read once per
+    """Layers of 128+ channels and 1024+ pixels in whole 64-pixel stages multiply in 128 x 128 blocks (planner field gram_t128, set per
     process: 0 = 64 x 64 everywhere, 2 = ragged maps too).  tools/stress_gram.py under the three settings: every layer set against fp64 (<= 2e-5 with the means of the covariance sets), the batched
     launches bit for bit what the per-layer launches leave, and the same bits on every one of 12 launches between LDS-scribbling
     convolutions (the first form of the 128 x 128 kernel passed every single-launch test and failed this one: probes_r04.md section 2)."""
@@ -601,7 +601,7 @@ def test_gram_128_blocks_stress_and_the_64_route_subprocess():
     code = ("import sys; sys.path[:0] = [%r, %r]; import hip\n"
             "print('blocks', hip.gram_block(128, 4096), hip.gram_block(512, 16384), hip.gram_block(256, 8100), hip.gram_block(512, 484), hip.gram_block(64, 1 << 20))\n") % (REPO, PKG)
     for flag, want in (("1", "blocks 128 128 64 64 64"), ("2", "blocks 128 128 128 64 64"), ("0", "blocks 64 64 64 64 64")):
-        env = dict(os.environ, MAUA_GRAM_T128=flag)
+        env = dict(os.environ, MAUA_PLAN="gram_t128=" + flag)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and want in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
         r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "stress_gram.py"), "12"], env=env, capture_output=True, text=True, timeout=1200)
@@ -609,7 +609,7 @@ def test_gram_128_blocks_stress_and_the_64_route_subprocess():
 
 
 def test_gram_bwd_fp32_route_subprocess():
-    """MAUA_GRAM_BWD_X3=0 (read once per process) keeps the fp32-MFMA Gram backward; both routes agree to fp32 level."""
+    """gram_bwd_x3=0 (MAUA_PLAN) keeps the fp32-MFMA Gram backward; both routes agree to fp32 level."""
     import subprocess
     import sys
     code = (
@@ -622,7 +622,7 @@ def test_gram_bwd_fp32_route_subprocess():
     outs = []
     for flag in ("0", "1"):
         path = os.path.join(tempfile.mkdtemp(), "gf.pt")
-        env = dict(os.environ, MAUA_GRAM_BWD_X3=flag)
+        env = dict(os.environ, MAUA_PLAN="gram_bwd_x3=" + flag)
         r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-1500:]
         outs.append(torch.load(path))
@@ -736,7 +736,7 @@ def test_conv5x5_x3_rejects_other_filter_sizes(hip):
 
 
 def test_conv3x3_x6_persistent_workgroups_subprocess():
-    """MAUA_X6_PERSIST=1 (read once per process): several tiles per workgroup with cross-tile prefetch, in-loop epilogue
+    """x6_persist=1 (MAUA_PLAN): several tiles per workgroup with cross-tile prefetch, in-loop epilogue
     and accumulator re-initialisation must give the same bits as one workgroup per tile."""
     import subprocess
     import sys
@@ -750,7 +750,7 @@ def test_conv3x3_x6_persistent_workgroups_subprocess():
     outs = []
     for flag in ("0", "1"):
         path = os.path.join(tempfile.mkdtemp(), "y.pt")
-        env = dict(os.environ, MAUA_X6_PERSIST=flag)
+        env = dict(os.environ, MAUA_PLAN="x6_persist=" + flag)
         r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-1500:]
         outs.append(torch.load(path))
