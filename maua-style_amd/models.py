@@ -98,7 +98,9 @@ def _x3p_gram_enabled(n, c_in, c_out, h, w):
     """Whether the Gram backward rides in conv_x3p's launch (its D . F chunks run between two items, latency-exposed) or in conv_x3w's
     (MAUA_X3P_GRAM_MIN_MB, default 700): measured in the network, conv_x3p's form wins 7-8 % where the launch's maps - gradient in,
     gradient out, F - are beyond what the 256 MB of Infinity Cache hold (2048 x 2048 images) and loses 2-3 % where they are not (1024)."""
-    mb = n * (c_in + 2 * c_out) * h * w * 4 / 1e6
+    # (the frames the job PLANS per launch count, not this launch's batch: a frame's bits must not depend on how many others share its
+    #  launches - a short last batch, or a frame optimised alone under the same plan, takes the same kernel)
+    mb = hip.lib().maua_get_split_batch_hint() * (c_in + 2 * c_out) * h * w * 4 / 1e6
     return mb >= plan.get_float("x3p_gram_min_mb")
 
 
