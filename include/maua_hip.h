@@ -176,7 +176,7 @@ int maua_conv3x3_x3w_unpool(const float* pooled_x, const unsigned char* codes, i
                             int h, int w, int cout, int pad, void* workspace, size_t workspace_bytes, maua_stream_t stream);
 
 /* The same fp16x3 arithmetic on the third kernel structure (conv_x3q.hip, round 4): K chunks of 32 input channels on
- * v_mfma_f32_16x16x32_f16 (one k-step = one tap x 32 channels), one workgroup of four waves per CU with all nine taps of a
+ * v_mfma_f32_16x16x32_f16 (one k-step = one tap x 32 channels), one workgroup of EIGHT waves (512 threads, two per SIMD) per CU with all nine taps of a
  * chunk resident in LDS.  Same layer arithmetic as maua_conv3x3_x3w - `nn.Conv2d(cin, c, 3)` + `nn.ReLU(inplace=True)`,
  * models.py:129-130, and its backward-data pass - same arguments and flags, same split-K workspace protocol; needs
  * cin % 32 == 0 and planes of at most 2^24 pixels (maua_conv_x3q_supported); bank layout
@@ -199,7 +199,7 @@ int maua_conv3x3_x3q_relu_pool(const float* x, const void* bank, float w_scale, 
                                int n, int cin, int h, int w, int cout, int pad, void* workspace, size_t workspace_bytes,
                                maua_stream_t stream);
 /* ... as the backward-data pass that stages its input straight from the POOLED map's gradient and the pool's decision bytes
- * (maua_conv3x3_x3w_unpool without the Gram term: the deep layers it serves - conv3_4, conv4_4 - carry no style loss on their input).
+ * (maua_conv3x3_x3w_unpool without the Gram term: the layer the host routes here - conv4_4, 512 channels - carries no style loss on its input).
  * Bit-identical to maua_pool2x2_bwd_codes followed by maua_conv3x3_x3q. */
 int maua_conv3x3_x3q_unpool(const float* pooled_x, const unsigned char* codes, int honour_relu_bit, const void* bank, float w_scale,
                             const float* out_relu_mask, float* y, int n, int cin, int h, int w, int cout, int pad, void* workspace,

@@ -112,6 +112,41 @@ def broadcast_network(net, src=0, mid_job=False):
     broadcast_tensors([p.data for p in net.parameters()], src, group=_LONG_GROUP if mid_job else None)
 
 
+class ReplicaWeights:
+    """vid_img rebuilds its loss network per image size from the same weight file; the replicas need ONE broadcast per job, not one per
+    size.  The first call broadcasts rank `src`'s parameters (start-up phase, short-timeout group) and keeps them, conv layer by conv
+    layer; later calls copy the kept tensors into the new network locally - no collective a rank that is a scale ahead or behind could
+    block on.  Only a later network with MORE conv layers than any before it (deeper loss layers at a later size) broadcasts again, and
+    then only on the long-timeout group."""
+
+    def __init__(self):
+        self.kept = []  # [(weight, bias or None)] of the conv layers, in network order
+
+    @staticmethod
+    def _convs(net):
+        import torch.nn as nn
+        return [m for m in net.modules() if isinstance(m, nn.Conv2d)]
+
+    def sync(self, net, src=0):
+        convs = self._convs(net)
+        if not self.kept:
+            broadcast_network(net, src=src)
+            self.kept = [(m.weight.data.clone(), None if m.bias is None else m.bias.data.clone()) for m in convs]
+            return "broadcast"
+        n = min(len(convs), len(self.kept))
+        for m, (w, b) in zip(convs[:n], self.kept[:n]):
+            if m.weight.shape != w.shape:
+                raise RuntimeError("ReplicaWeights: the network changed its layers between image sizes")
+            m.weight.data.copy_(w)
+            if b is not None and m.bias is not None:
+                m.bias.data.copy_(b)
+        if len(convs) > n:  # deeper than anything broadcast so far: the new tail only
+            broadcast_tensors([t for m in convs[n:] for t in ([m.weight.data] + ([] if m.bias is None else [m.bias.data]))], src, group=_LONG_GROUP)
+            self.kept += [(m.weight.data.clone(), None if m.bias is None else m.bias.data.clone()) for m in convs[n:]]
+            return "broadcast of the new tail"
+        return "local copy"
+
+
 def broadcast_style_targets(net, src=0):
     """Style Gram targets captured on rank `src` -> every rank (2.4 MB for the default five layers), so the style
     forward passes run once per job instead of once per rank (and once per frame, as the reference does:

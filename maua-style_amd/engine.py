@@ -147,8 +147,8 @@ class StyleEngine:
         self.pool_codes = {}
         if plan.on("pool_codes"):
             for s in self.steps:
-                if s.kind == "pool" and s.k == 2 and s.stride == 2 and s.mode == "max" and \
-                        hip.pool2x2_codes_supported(*shapes[s.src]):
+                if s.kind == "pool" and s.k == 2 and s.stride == 2 and s.mode == "max" and not s.ceil and \
+                        hip.pool2x2_codes_supported(*shapes[s.src]):  # (floor mode: the kernels' grids and code planes are (h // 2, w // 2))
                     self.pool_codes[id(s)] = torch.empty(shapes[s.dst], dtype=torch.uint8, device=dev)
         # B > 1 (img_vid's windows of frames): every loss module has several terms - one per frame, plus the cross-frame
         # dynamic Gram term of a StyleLoss - each with its own slot behind the per-module ones
@@ -190,8 +190,8 @@ class StyleEngine:
                 users = [t for t in self.steps if t.src == s.dst and t is not s]
                 if len(users) == 1 and users[0].kind == "pool" and id(users[0]) in self.pool_codes and \
                         self._x6_ok(s, s.mod.out_channels) and models_mod.conv3x3_fwd_is_x3w(s.mod, *shapes[s.src][2:]) and \
-                        s.mod.out_channels % 8 == 0 and (plan.on("fuse_pool_split") or hip.conv_x3w_split(
-                            B, shapes[s.src][1], shapes[s.src][2], shapes[s.src][3], s.mod.out_channels, s.pad) == 1):
+                        s.mod.out_channels % 8 == 0 and (plan.on("fuse_pool_split") or models_mod.conv3x3_fwd_family(
+                            s.mod, B, shapes[s.src][2], shapes[s.src][3])[1] == 1):
                     self.fused_pool[id(s)] = users[0]
         self.pooled_by_conv = {id(v) for v in self.fused_pool.values()}
         for s in self.steps:  # (those activations exist as shapes only: 0.5 GB less at 1024x1024)
@@ -908,6 +908,12 @@ class StyleEngine:
         finally:
             models_mod.ROUTE_LOG = None
         return log
+
+    def drop_graphs(self):
+        """Release the captured iteration bundles (graph memory pool, image and L-BFGS history of each): for a caller that is done with
+        this image size and keeps the network."""
+        self.iter_graphs = {}
+        self.graph, self.graph_key = None, None
 
     def saved_bytes(self):
         """Bytes held by activations + gradient buffers for the current shape."""

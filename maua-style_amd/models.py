@@ -176,6 +176,17 @@ def conv3x3_fwd_is_x3w(mod, h, w):
         hip.conv_x3w_supported(mod.in_channels, h, w, mod.padding[0])
 
 
+def conv3x3_fwd_family(mod, n, h, w):
+    """(kernel family, K splits) the forward pass of a 3x3 layer on an n x h x w input takes with a workspace - what conv3x3_mfma /
+    conv3x3_relu_pool will launch, so that the engine's eligibility rules ask about THAT kernel."""
+    cin, cout, pad = mod.in_channels, mod.out_channels, mod.padding[0]
+    if conv3x3_is_x3p(cin, h, w, pad, cout, n):
+        return "conv_x3p", hip.conv_x3p_split(n, cin, h, w, cout, pad)
+    if conv3x3_is_x3q(cin, h, w, pad, 0, cout, n):
+        return "conv_x3q", hip.conv_x3q_split(n, cin, h, w, cout, pad)
+    return "conv_x3w", hip.conv_x3w_split(n, cin, h, w, cout, pad)
+
+
 def conv3x3_relu_pool(x, mod, pooled, codes, workspace=None):
     """conv + bias + ReLU + the 2x2 / 2 max pool behind it without the full-size activation (hip.conv3x3_x3w_relu_pool: one launch, or -
     small grids, with a workspace - a split channel loop whose adding pass pools)."""

@@ -186,13 +186,21 @@ class PixelOptimizer:
         # baked in has moved since (engine buffers: alloc_epoch; targets / weights / coefficients: _graph_key)
         self._bundle_key, bundle = None, None
         if self.engine is not None and self.kind == "lbfgs" and grad_hook is None and plan.on("graph_bundles"):
-            self._bundle_key = ("lbfgs", tuple(self.x.shape), self.independent, self.batch_hint, int(args.lbfgs_num_correction),
-                                float(args.lbfgs_tolerance_change), float(args.lbfgs_tolerance_grad))
+            self._bundle_key = ("lbfgs", tuple(self.x.shape), str(self.x.device), str(self.x.dtype), self.independent, self.batch_hint,
+                                int(args.lbfgs_num_correction), float(args.lbfgs_tolerance_change), float(args.lbfgs_tolerance_grad))
             self.engine._prepare(self.x)  # (allocates for this shape if the engine last served another one: a new epoch)
             bundle = self.engine.iter_graphs.get(self._bundle_key)
             if bundle is not None and (bundle["epoch"] != self.engine.alloc_epoch or bundle["graph_key"] != self.engine._graph_key()):
                 bundle = None
                 del self.engine.iter_graphs[self._bundle_key]
+            # (a bundle's image and L-BFGS states are ITS buffers: an optimiser that is still alive on it keeps it - a second one with
+            #  the same key works on fresh buffers and captures its own graph instead of aliasing the first one's state)
+            owner = bundle.get("owner") if bundle is not None else None
+            if owner is not None and owner() is not None and owner() is not self:
+                bundle = None
+            elif bundle is not None:
+                import weakref
+                bundle["owner"] = weakref.ref(self)
         if bundle is not None:
             bundle["x"].copy_(self.x)
             self.x = bundle["x"]
@@ -294,8 +302,9 @@ class PixelOptimizer:
             self._lbfgs_move(self.engine.gbuf[0], self.engine.total)
         self._graph = graph
         if self._keep_bundle:
+            import weakref
             self.engine.iter_graphs[self._bundle_key] = {"graph": graph, "x": self.x, "states": self.states, "epoch": self.engine.alloc_epoch,
-                                                         "graph_key": self.engine._graph_key()}
+                                                         "graph_key": self.engine._graph_key(), "owner": weakref.ref(self)}
         return slots, total
 
     def step(self):

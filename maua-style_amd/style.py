@@ -362,6 +362,7 @@ def vid_img(args):
     # footprint with its length (the reference holds one frame at a time); a miss decodes the PNG again.
     budget = int(plan.get_float("frame_cache_mb") * (1 << 20))
     written, content_cache = _ByteBudget(budget), _ByteBudget(budget)
+    replica = dist.ReplicaWeights()
     for size_n, (current_size, num_iters) in enumerate(zip(args.image_sizes, args.num_iters)):
         print("\nCurrent size {}px".format(current_size))
         os.makedirs(output_dir + "/" + str(current_size), exist_ok=True)
@@ -372,8 +373,9 @@ def vid_img(args):
 
         optim.set_model_args(args, current_size)
         net, losses = models.load_model(args)
-        # (first scale: start-up, short timeout; later scales: a rank that skipped finished frames waits here for hours)
-        dist.broadcast_network(net, src=0, mid_job=size_n > 0)
+        # (one broadcast per job: the first scale's, in the start-up phase; later scales copy the kept replica weights locally, so no
+        #  rank waits in a collective for a rank that is hours behind)
+        replica.sync(net, src=0)
         batch = frames_per_batch(current_size, args)
 
         for pass_n in range(passes):

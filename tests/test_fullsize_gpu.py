@@ -478,6 +478,43 @@ def test_config3_adam_2048_evaluation_and_descent(weight_files):
     assert math.isfinite(after) and after < before, (before, after)
 
 
+def test_config4_one_ranks_share_of_eight_frames_of_512(weight_files, request):
+    """BASELINE config 4 as ONE rank of the 8-GPU job sees it: 64 synthetic 512 x 512 frames, contiguous blocks of eight per rank
+    (dist.shard_range; /root/reference/style.py:192-233's frame loop, sharded), rank 3's block optimised in batches under the job's plan of
+    planned_frames(512) = 16 frames per launch (a rank with eight frames runs one short batch of eight under that plan).  Finite,
+    descending frame by frame, repeatable bit for bit, and - same plan, same routes - each frame identical to that frame optimised
+    alone."""
+    import dist
+    import models
+    import optim
+    import style as style_mod
+    import hip
+    request.addfinalizer(lambda: hip.set_split_batch_hint(1))
+    S, frames_total, world, rank, N = 512, 64, 8, 3, 12
+    lo, hi = dist.shard_range(frames_total, rank, world)
+    assert (lo, hi) == (24, 32) and [dist.shard_range(frames_total, r, world) for r in range(world)] == [(8 * r, 8 * r + 8) for r in range(world)]
+    plan_b = style_mod.planned_frames(S)
+    frames = synth.frames(frames_total, S)[lo:hi].cuda()
+    style = synth.images(S)[1]
+    args = product_args(weight_files, S=S, N=N)
+    optim.set_model_args(args, S)
+    net, losses = models.load_model(args)
+    out = optim.optimize_frames(frames, [style], frames.clone(), N, args, net, losses, planned_frames=plan_b)
+    again = optim.optimize_frames(frames, [style], frames.clone(), N, args, net, losses, planned_frames=plan_b)
+    torch.cuda.synchronize()
+    assert out.shape == (hi - lo, 3, S, S) and torch.isfinite(out).all() and torch.equal(out, again)
+    eng = optim._engine_of(net)
+    eng.independent, eng.batch_hint = True, plan_b
+    _, before, _ = eng.feval(frames.clone())
+    before = before.clone()
+    _, after, _ = eng.feval(out.clone())
+    torch.cuda.synchronize()
+    assert bool((after < before).all()), (before.tolist(), after.tolist())
+    for k in (0, hi - lo - 1):
+        single = optim.optimize_frames(frames[k:k + 1], [style], frames[k:k + 1].clone(), N, args, net, losses, planned_frames=plan_b)
+        assert torch.equal(single[0], out[k]), (k, rel_l2(single[0].cpu(), out[k].cpu()))
+
+
 # ---------------------------------------------------------------------------------------------------------
 # BASELINE config 4 at its real size: 16 frames of 512x512 per launch (what one rank of the 64-frame job evaluates at once)
 # ---------------------------------------------------------------------------------------------------------

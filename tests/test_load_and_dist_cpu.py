@@ -91,6 +91,24 @@ def _worker(rank, world, port, tmp):
     merged = dist.gather_frames(local, n_frames)
     assert sorted(merged) == list(range(n_frames)) and float(merged[4][0]) == 4.0
     assert dist.max_over_ranks(float(rank)) == float(world - 1)
+    # vid_img's per-size networks: ONE broadcast per job (dist.ReplicaWeights), later sizes copy the kept weights locally
+    def fresh(n_layers, layers):
+        c = models.VGG(models.build_sequential(models.channel_list["VGG-19"][:n_layers], "max"))
+        if rank == 0:
+            c.load_state_dict({k: v for k, v in sd.items() if k in c.state_dict()}, strict=False)
+        else:
+            for p_ in c.parameters():
+                p_.data.fill_(float("nan"))
+        a2 = argparse.Namespace(**{**vars(args), "content_layers": layers, "style_layers": layers})
+        return models.assemble(c.features, models.vgg19_dict, a2)[0]
+    rep = dist.ReplicaWeights()
+    want3 = [sd[f"features.{i}.{n}"] for i in (0, 2) for n in ("weight", "bias")]
+    net1 = fresh(3, "relu1_2")
+    assert rep.sync(net1) == "broadcast" and all(torch.equal(a, b) for a, b in zip(net1.parameters(), want3))
+    net2 = fresh(3, "relu1_1")                                   # a shallower network at the next size: no collective at all
+    assert rep.sync(net2) == "local copy" and all(torch.equal(a, b) for a, b in zip(net2.parameters(), want3[:2]))
+    net3 = fresh(5, "relu2_1")                                   # a deeper one: only its new tail travels
+    assert rep.sync(net3) == "broadcast of the new tail" and all(torch.equal(a, b) for a, b in zip(net3.parameters(), want))
     dist.barrier()
     open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
 
