@@ -6,6 +6,7 @@ tensors; every call is enqueued on torch's current stream.
 """
 import ctypes
 import os
+import sys
 
 import torch
 
@@ -146,6 +147,9 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = L
+        here = os.path.dirname(os.path.abspath(__file__))
+        if here not in sys.path:  # (tools that load this module by path: the planner configuration lives beside it)
+            sys.path.insert(0, here)
         import plan
         plan.forward_to_library(L)  # the library's share of the planner configuration (it never reads the environment)
         plan.warn_ignored()         # MAUA_* variables nothing reads any more: said once, loudly
@@ -154,6 +158,9 @@ def lib():
 
 def apply_plan():
     """Hand the planner configuration's library fields to the library again (after a programmatic change of plan.OVERRIDES)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    if here not in sys.path:
+        sys.path.insert(0, here)
     import plan
     plan.forward_to_library(lib())
 

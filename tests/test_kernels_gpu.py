@@ -1187,3 +1187,21 @@ def test_dmat_pack_batch_equals_the_per_layer_launches(hip):
         assert torch.equal(b0[0], b1) and torch.equal(i0, i1)
     with pytest.raises(hip.HipError):
         hip.DmatPackBatch(items + items[:1]).run()
+
+
+def test_soak_no_silent_differences_at_the_1e_6_level():
+    """The fault the first 128 x 128 Gram form had (one accumulator register of one wave short of a k-step's products in lanes 48-63,
+    7e-5 per workgroup launch with two of its workgroups per CU: tools/mfma_probe/gram128_zero_lanes.hip reproduces it in seconds,
+    profiles/probes_r05.md section 4 lists what was ruled out) would pass every single-launch test.  tools/soak_kernels.py launches every
+    matrix kernel family that runs two MFMA waves per SIMD - conv_x3w, conv_x3q, conv_x3p, conv_x3w's fused Gram form, the Gram forward
+    kernels (two-role 128 x 128 and 64 x 64) and the Gram backward on conv1x1_x3 - 400 times each on fixed inputs and compares every
+    result with the first on the device: ~1e6 - 3e6 workgroup launches per family, a rate of 1e-5 would show dozens of times.
+    (Reference arithmetic of the families: /root/reference/models.py:129-130 convolutions, /root/reference/loss.py:91 Gram.)"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "soak_kernels.py"), "400"], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and "differing launches in all: 0" in r.stdout, (r.stdout[-2000:], r.stderr[-1500:])
+    for flag in ("gram_t128=0", "gram_t128=2"):
+        env = dict(os.environ, MAUA_PLAN=flag)
+        r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "soak_kernels.py"), "200"], env=env, capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0 and "differing launches in all: 0" in r.stdout, (flag, r.stdout[-2000:], r.stderr[-1500:])

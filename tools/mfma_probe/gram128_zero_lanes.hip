@@ -1,0 +1,325 @@
+// Reproducer for the "lanes 48-63 of one accumulator register come out zero" fault of the first 128 x 128 Gram form (profiles/probes_r04.md
+// section 2b): the kernel as it was in commit 194471a - four waves per workgroup, each both staging its 32 rows and
+// multiplying a 64 x 64 sub-block on v_mfma_f32_32x32x16_f16, planes single-buffered, two barriers per stage - launched so that TWO
+// workgroups share a CU (launch bounds (256, 2), 74 KB of LDS each).  Every launch is compared with the first one, bit for bit; a
+// differing slab element is reported with the wave, accumulator, register and lane that produced it.  Variants by -D:
+//   -DWG_PER_CU=1      launch bounds (256, 1) + 96 KB of LDS: one workgroup per CU (never wrong in round 4)
+//   -DNOP_AFTER_CHAIN  s_nop 15 x 4 behind every chain of three dependent MFMAs
+//   -DZERO_BY_C        the accumulators are not zeroed by vector moves: the first MFMA of a stage takes a zero C operand
+//   -DDRAIN_AT_EXIT    s_waitcnt vmcnt(0) + s_nop behind the slab stores, before the wave ends
+//   -DNO_SUBDIAG_SKIP  diagonal sub-blocks compute their (1, 0) block too (no branch over MFMAs inside the k-step)
+//   -DNOP_BEFORE_FOLD  128 cycles of s_nop in front of the fold of the accumulators into the masters
+//   -DNOP_LAST         ... only behind the last chain of a k-step
+//   -DNOP_BEFORE_BARRIER  128 cycles of s_nop between a stage's last MFMA and the barrier that frees the planes
+// hipcc --offload-arch=gfx950 -O3 -o gram128_zero_lanes gram128_zero_lanes.hip ; ./gram128_zero_lanes [C] [HW] [launches]
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+#ifndef WG_PER_CU
+#define WG_PER_CU 2
+#endif
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 g16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 g16x2 __attribute__((ext_vector_type(2)));
+typedef float g32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int gu32x2 __attribute__((ext_vector_type(2)));
+constexpr int GT = 64, GK = 64;
+constexpr int GXROW = 144;
+constexpr int GX128_PLANE = 128 * GXROW;
+constexpr int GX128_LDS = WG_PER_CU == 1 ? 96 * 1024 : 4 * GX128_PLANE + 64;
+
+__device__ __forceinline__ unsigned gx_cvt_pk(float a, float b) {
+    const g32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, g16x2));
+}
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ void gram_x3_partial128_body(const float* __restrict__ f, const float* __restrict__ mean, float* __restrict__ partial,
+                                                        int C, int64_t HW, int ksplit, int64_t chunk, const int pair_index, const int ks) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f32[];
+    unsigned char* smem = reinterpret_cast<unsigned char*>(smem_f32);
+    // (the wave number as a scalar: `skip` / `sub_diag` below branch on scc, no EXEC masks around the MFMAs)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i32 = lane & 31, half = lane >> 5;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int ntile128 = (C + 127) / 128, ntile64 = (C + GT - 1) / GT;
+    int pair = pair_index, Ti = 0;
+    while (pair >= ntile128 - Ti) {
+        pair -= ntile128 - Ti;
+        ++Ti;
+    }
+    const int Tj = Ti + pair;
+    const bool diag = Ti == Tj;
+    const int nplanes = diag ? 2 : 4;
+    float* inv_lds = reinterpret_cast<float*>(smem + nplanes * GX128_PLANE);
+    const int64_t p_begin = (int64_t)ks * chunk;
+    const int64_t p_end = min(HW, p_begin + chunk);
+
+    // staging units of this wave (in each tile): rows wave * 32 + lane / 8 + 8 r (r < 4), pixels pxh * 32 + (lane % 8) * 4 .. + 3, pxh = 0, 1
+    const int srow = wave * 32 + (lane >> 3), spx = (lane & 7) * 4;
+    f32x4 ra[2][4], rb[2][4];  // one stage in flight: [pixel half][r] of tile i / tile j
+    // Loads through a buffer descriptor over the whole map (32-bit offsets: the host side sends maps of 2^29 values and more to the 64 x 64
+    // kernel): rows beyond C are beyond its range and come back as zeros; pixels beyond the slice are zeroed in the (wave-uniform) tail path.
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(f), 0, (unsigned)((int64_t)C * HW * 4), 0x00020000);
+    // (a unit's offset = one per-thread register + scalars, added per load: eight loop-carried offset registers are eight the wave does not have)
+    const unsigned vbase = ((unsigned)srow * (unsigned)HW + (unsigned)spx) * 4u;
+    auto load_unit = [&](f32x4 (&r4)[4], int tile, int64_t p0) {
+        unsigned vb = vbase;
+        asm volatile("" : "+v"(vb));
+        const unsigned sb = ((unsigned)(tile * 128) * (unsigned)HW + (unsigned)p0) * 4u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            r4[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(frs, vb + (sb + (unsigned)(8 * r) * (unsigned)HW * 4u), 0, 0));
+        if (p0 + 32 > p_end) {  // wave-uniform: the slice's last, partial stage
+            const int left = (int)(p_end - p0) - spx;  // cells of this thread's four that exist (<= 0: none)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k >= left) r4[r][k] = 0.f;
+        }
+    };
+    const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(mean ? mean : f), 0, mean ? (unsigned)C * 4u : 0u, 0x00020000);
+    auto load_stage = [&](int64_t p0) {
+        load_unit(ra[0], Ti, p0);
+        load_unit(ra[1], Ti, p0 + 32);
+        if (!diag) {
+            load_unit(rb[0], Tj, p0);
+            load_unit(rb[1], Tj, p0 + 32);
+        }
+    };
+    // split the wave's 32 rows x 64 pixels of one tile (one scale from their maximum) and write them into the planes
+    auto store_tile = [&](f32x4 (&r4)[2][4], int tile_slot, int64_t p0) {
+        if (mean) {  // covariance form: centre the cells that exist (padding cells stay zero; rows beyond C read a mean of 0)
+            unsigned vm = (unsigned)srow * 4u;
+            asm volatile("" : "+v"(vm));
+            const unsigned sm = (unsigned)((tile_slot == 0 ? Ti : Tj) * 128) * 4u;
+            const bool tail = p0 + GK > p_end;  // wave-uniform
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // (re-read per stage: the wave has no eight registers for the values)
+                const float mr = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mrs, vm + (sm + 32u * r), 0, 0));
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (tail) {
+                        const int left = (int)(p_end - p0) - 32 * h - spx;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (k < left) r4[h][r][k] -= mr;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) r4[h][r][k] -= mr;
+                    }
+                }
+            }
+        }
+        float m = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                m = fmaxf(m, fmaxf(fmaxf(fabsf(r4[h][r][0]), fabsf(r4[h][r][1])), fmaxf(fabsf(r4[h][r][2]), fabsf(r4[h][r][3]))));
+        m = wave_max_nonneg(m);
+        int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu) - 127;
+        e = m > 0.f ? max(e, -100) : 11;
+        const float sx = __builtin_bit_cast(float, (unsigned)(127 + 11 - e) << 23);
+        if (lane == 0) inv_lds[tile_slot * 4 + wave] = __builtin_bit_cast(float, (unsigned)(127 + e - 11) << 23);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v0 = r4[h][r][0] * sx, v1 = r4[h][r][1] * sx, v2 = r4[h][r][2] * sx, v3 = r4[h][r][3] * sx;
+                const unsigned h0 = gx_cvt_pk(v0, v1), h1 = gx_cvt_pk(v2, v3);
+                const g16x2 hh0 = __builtin_bit_cast(g16x2, h0), hh1 = __builtin_bit_cast(g16x2, h1);
+                const unsigned l0 = gx_cvt_pk(v0 - (float)hh0[0], v1 - (float)hh0[1]), l1 = gx_cvt_pk(v2 - (float)hh1[0], v3 - (float)hh1[1]);
+                unsigned char* dst = smem + (tile_slot * 2) * GX128_PLANE + (srow + 8 * r) * GXROW + (32 * h + spx) * 2;
+                *reinterpret_cast<gu32x2*>(dst) = gu32x2{h0, h1};
+                *reinterpret_cast<gu32x2*>(dst + GX128_PLANE) = gu32x2{l0, l1};
+            }
+    };
+    auto store_stage = [&](int64_t p0) {
+        store_tile(ra, 0, p0);
+        if (!diag) store_tile(rb, 1, p0);
+    };
+
+    f32x16 master[2][2], acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) master[a][b][r] = acc[a][b][r] = 0.f;
+    const bool skip = diag && wi == 1 && wj == 0;   // wave-uniform: the mirrored 64 x 64 sub-block of a diagonal pair
+    const bool sub_diag = diag && wi == wj;         // a diagonal 64 x 64 sub-block: its (1, 0) block is the transpose of (0, 1)
+    const int bslot = diag ? 0 : 1;
+    const int a_off = (wi * 64 + i32) * GXROW + half * 16;
+    const int b_off = (bslot * 2) * GX128_PLANE + (wj * 64 + i32) * GXROW + half * 16;
+
+    const int64_t nstages = p_begin < p_end ? (p_end - p_begin + GK - 1) / GK : 0;
+    if (nstages > 0) {
+        load_stage(p_begin);
+        store_stage(p_begin);
+        if (nstages > 1) load_stage(p_begin + GK);
+        __syncthreads();
+        for (int64_t st = 0; st < nstages; ++st) {
+            float s_row[2], s_col[2];
+            if (!skip) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    s_row[a] = inv_lds[2 * wi + a];
+                    s_col[a] = inv_lds[bslot * 4 + 2 * wj + a];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    g16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        ah[a] = *reinterpret_cast<const g16x8*>(smem + a_off + a * 32 * GXROW + q * 32);
+                        al[a] = *reinterpret_cast<const g16x8*>(smem + GX128_PLANE + a_off + a * 32 * GXROW + q * 32);
+                        bh[a] = *reinterpret_cast<const g16x8*>(smem + b_off + a * 32 * GXROW + q * 32);
+                        bl[a] = *reinterpret_cast<const g16x8*>(smem + GX128_PLANE + b_off + a * 32 * GXROW + q * 32);
+                    }
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+#ifndef NO_SUBDIAG_SKIP
+                            if (sub_diag && a == 1 && b == 0) continue;  // wave-uniform
+#endif
+#ifdef ZERO_BY_C
+                            {
+                                const f32x16 zero_c = {};
+                                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], q == 0 ? zero_c : acc[a][b], 0, 0, 0);
+                            }
+#else
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
+#endif
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+#ifdef NOP_AFTER_CHAIN
+                            asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+                        }
+#ifdef NOP_LAST
+                    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+                    __builtin_amdgcn_sched_barrier(0);  // (one k-step's fragments at a time: hoisting the next steps' reads costs registers the wave does not have)
+                }
+            }
+#ifdef NOP_BEFORE_BARRIER
+            asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+            __syncthreads();  // every wave is done with the planes (and has its scales in registers)
+            if (st + 1 < nstages) {
+                store_stage(p_begin + (st + 1) * GK);
+                if (st + 2 < nstages) load_stage(p_begin + (st + 2) * GK);
+            }
+#ifdef NOP_BEFORE_FOLD
+            asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+            if (!skip) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const float sc = s_row[a] * s_col[b];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            master[a][b][r] = fmaf(acc[a][b][r], sc, master[a][b][r]);
+#ifndef ZERO_BY_C
+                            acc[a][b][r] = 0.f;
+#endif
+                        }
+                    }
+            }
+            __syncthreads();  // the planes of stage st + 1 are complete
+        }
+    }
+    // the wave's 64 x 64 sub-block is the slab of the 64-channel tile pair (2 Ti + wi, 2 Tj + wj)
+    const int ti64 = 2 * Ti + wi, tj64 = 2 * Tj + wj;
+    if (ti64 > tj64 || tj64 >= ntile64) return;
+    const int p64 = ti64 * ntile64 - ti64 * (ti64 - 1) / 2 + (tj64 - ti64);
+    // (the lane number read afresh: carried from the top of the kernel it is two registers spilled to scratch)
+    const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    float* out = partial + ((int64_t)p64 * ksplit + ks) * (GT * GT) + (ln >> 5) * 4 * GT + (ln & 31);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[(a * 32 + (r & 3) + 8 * (r >> 2)) * GT + b * 32] = master[a][b][r];
+#ifdef DRAIN_AT_EXIT
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+}
+
+__global__ void __launch_bounds__(256, WG_PER_CU)
+gram128_kernel(const float* __restrict__ f, float* __restrict__ partial, int C, int64_t HW, int ksplit, int64_t chunk) {
+    gram_x3_partial128_body(f, nullptr, partial, C, HW, ksplit, chunk, blockIdx.x, blockIdx.y);
+}
+
+int main(int argc, char** argv) {
+    const int C = argc > 1 ? atoi(argv[1]) : 256;
+    const int64_t HW = argc > 2 ? atoll(argv[2]) : 65536;
+    const int launches = argc > 3 ? atoi(argv[3]) : 300;
+    const int ntile128 = (C + 127) / 128, ntile64 = (C + 63) / 64;
+    const int pairs128 = ntile128 * (ntile128 + 1) / 2, pairs64 = ntile64 * (ntile64 + 1) / 2;
+    int ksplit = 512 / pairs128;
+    if (ksplit < 1) ksplit = 1;
+    int64_t chunk = ((HW + ksplit - 1) / ksplit + GK - 1) / GK * GK;
+    ksplit = (int)((HW + chunk - 1) / chunk);
+    std::vector<float> h((size_t)C * HW);
+    uint32_t s = 12345u;
+    for (auto& v : h) {
+        s = s * 1664525u + 1013904223u;
+        v = (s >> 31) ? 0.f : (float)((s >> 8) & 0xffff) / 65536.f;   // post-ReLU-like: half zeros
+    }
+    float *f, *slab, *ref;
+    const size_t slab_n = (size_t)pairs64 * ksplit * GT * GT;
+    CK(hipMalloc(&f, h.size() * 4));
+    CK(hipMalloc(&slab, slab_n * 4));
+    CK(hipMalloc(&ref, slab_n * 4));
+    CK(hipMemcpy(f, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gram128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GX128_LDS));
+    std::vector<float> a(slab_n), b(slab_n);
+    long bad_launches = 0, bad_values = 0;
+    for (int it = 0; it <= launches; ++it) {
+        CK(hipMemset(slab, 0xff, slab_n * 4));  // NaN: an element nobody wrote shows
+        hipLaunchKernelGGL(gram128_kernel, dim3(pairs128, ksplit), dim3(256), GX128_LDS, 0, f, slab, C, HW, ksplit, chunk);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(it == 0 ? a.data() : b.data(), slab, slab_n * 4, hipMemcpyDeviceToHost));
+        if (it == 0) continue;
+        long bad = 0;
+        for (size_t i = 0; i < slab_n; ++i)
+            if (memcmp(&a[i], &b[i], 4) != 0) {
+                if (bad < 4 && bad_launches < 6) {
+                    const size_t e = i % (GT * GT), sl = i / (GT * GT);
+                    const int row = (int)(e / GT), col = (int)(e % GT);
+                    // row = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = b * 32 + (lane & 31)
+                    const int aa = row / 32, rr = row % 32, half = (rr >> 2) & 1, r = (rr & 3) + 4 * (rr >> 3), lane = half * 32 + (col % 32);
+                    int p64 = (int)(sl / ksplit), ti = 0;
+                    while (p64 >= ntile64 - ti) { p64 -= ntile64 - ti; ++ti; }
+                    const int tj = ti + p64;
+                    printf("  launch %d slab %zu (64-tile pair %d,%d: 128-pair %d,%d wave (%d,%d)%s, slice %d): row %d col %d = acc[%d][%d] register %d lane %d: first %g now %g (x %.3f)\n", it, sl,
+                           ti, tj, ti / 2, tj / 2, ti % 2, tj % 2, ti / 2 == tj / 2 ? (ti % 2 == tj % 2 ? " diagonal pair, diagonal sub-block" : " diagonal pair") : "", (int)(sl % ksplit),
+                           row, col, aa, col / 32, r, lane, a[i], b[i], b[i] / a[i]);
+                }
+                ++bad;
+            }
+        if (bad) {
+            ++bad_launches;
+            bad_values += bad;
+        }
+    }
+    printf("C %d HW %lld ksplit %d, %d workgroup(s) per CU: %ld of %d launches differ from the first (%ld values)\n", C, (long long)HW, ksplit, WG_PER_CU, bad_launches, launches, bad_values);
+    return bad_launches ? 2 : 0;
+}
