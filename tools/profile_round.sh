@@ -1,6 +1,6 @@
 set -x
 # (the *_clock.py tools below load diagnostic builds from tools/_build/: run tools/build_stamp_libs.sh in the container first, after any change to csrc/)
-R=$PWD; O=$R/gpurun_out/${ROUND_DIR:-r4fin}; mkdir -p $O
+R=$PWD; O=$R/gpurun_out/${ROUND_DIR:-r5fin}; mkdir -p $O
 python bench.py --steps 200 > $O/bench_graph.json 2> $O/bench_graph.err
 python bench.py --steps 100 --no_hip_graph --no_cpu_baseline --no_extra_sizes > $O/bench_eager.json 2>/dev/null
 cd /tmp; export TMPDIR=/tmp
@@ -22,6 +22,16 @@ rm -rf $O/pmc_a $O/pmc_b $O/pmc_c $O/pmc_d
 for S in 256 512 724 1024 1448 2048; do python bench.py --size $S --steps 100 --no_cpu_baseline --no_extra_sizes 2>/dev/null >> $O/sizes_lbfgs.jsonl; done
 for S in 1024 1448 2048; do python bench.py --size $S --optimizer adam --steps 100 --no_cpu_baseline --no_extra_sizes 2>/dev/null >> $O/sizes_adam.jsonl; done
 python tools/run_configs.py --configs 2,3,4,5,6 --out $O/configs.json > $O/configs.log 2>&1
+# per-dispatch durations of one iteration as the product runs it (graph replay): the per-launch tables (eager events overstate host-bound launches)
+MIN_US=0 GRAPH=--hip_graph BENCH_ARGS="--no_accuracy_probe" bash tools/trace_ab.sh gpurun_out/${ROUND_DIR:-r5fin}/tr1024 MAUA_HIP_GRAPH "1" > $O/trace_graph_1024.txt 2>&1
+MIN_US=0 GRAPH=--hip_graph BENCH_ARGS="--no_accuracy_probe --size 512" bash tools/trace_ab.sh gpurun_out/${ROUND_DIR:-r5fin}/tr512 MAUA_HIP_GRAPH "1" > $O/trace_graph_512.txt 2>&1
+python tools/check_x3p.py 1024 5 10 > $O/check_x3p.txt 2>&1
+python tools/x3p_clock.py 64 64 1024 plain > $O/clock_x3p_conv1_2.txt 2>&1
+python tools/x3p_clock.py 64 64 1024 masked >> $O/clock_x3p_conv1_2.txt 2>&1
+python tools/x3p_clock.py 256 256 256 plain >> $O/clock_x3p_conv1_2.txt 2>&1
+python tools/soak_kernels.py 3000 > $O/soak.txt 2>&1
+(tools/mfma_probe/stage_bw 64 1024; tools/mfma_probe/stage_bw 128 512) > $O/stage_bw.txt 2>&1
+(tools/mfma_probe/gram128_zero_lanes_n0 512 16384 1500; tools/mfma_probe/gram128_zero_lanes_base 512 16384 1500; tools/mfma_probe/gram128_zero_lanes_one 512 16384 1500; tools/mfma_probe/mfma_src_war) > $O/gram128_zero_lanes.txt 2>&1
 python tools/x3w_clock.py 512 512 128 > $O/clock_conv4_2.txt 2>&1
 python tools/x3w_clock.py 64 64 1024 > $O/clock_conv1_2.txt 2>&1
 python tools/bench_x3w.py 1024 5 10 > $O/x3_vs_x3w.txt 2>&1

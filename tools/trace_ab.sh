@@ -9,7 +9,7 @@ for v in $VALS; do
 done
 cd $R
 python - "$O" $VALS <<'PY'
-import csv, glob, statistics, sys
+import csv, glob, os, statistics, sys
 out = {}
 for v in sys.argv[2:]:
     f = glob.glob(f"{sys.argv[1]}/t_{v}/**/*kernel_trace.csv", recursive=True)[0]
@@ -25,7 +25,7 @@ if len({len(out[v]) for v in vals}) == 1:
     tot = [0.0] * len(vals)
     for j in range(len(out[vals[0]])):
         ds = [out[v][j][2] for v in vals]
-        if max(ds) < 30:
+        if max(ds) < float(os.environ.get('MIN_US', 30)):  # (MIN_US=0: every launch)
             continue
         for k, d in enumerate(ds):
             tot[k] += d
