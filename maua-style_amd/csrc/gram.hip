@@ -600,10 +600,29 @@ __device__ __forceinline__ void gram_x3_partial128_body(const float* __restrict_
             for (int r = 0; r < 16; ++r) out[(a * 32 + (r & 3) + 8 * (r >> 2)) * GT + b * 32] = master[a][b][r];
 }
 
+// Workgroup -> (tile pair, slice) of a layer that multiplies in 128 x 128 blocks.  The pairs of ONE slice read the same 128-channel tiles
+// of that slice (C = 512: ten pairs over four tiles - every tile four times); dealt out pair-fastest, consecutive workgroups land on
+// eight different XCDs and every one of those reads comes from memory (L2 hit rate 0.11, 436 MB of tiles read for 243 MB of maps per
+// 1024 x 1024 iteration: profiles/pmc_r04_traffic.json).  So: XCD x (workgroups x, x + 8, ... of the layer's range, which starts at a
+// multiple of 8) owns the slices [x spx, (x + 1) spx) and walks them pair by pair - the pairs of a slice run on the CUs of one L2 at about
+// the same time.  `local` = the workgroup's number inside the layer's padded range of 8 spx npairs; false: nothing to do.  Same slabs,
+// same sums: only the placement changes.
+__device__ __forceinline__ bool gram128_item(int local, int npairs, int ksplit, int* pair, int* ks) {
+    const int spx = (ksplit + 7) >> 3;
+    const int j = local >> 3;
+    const int slice = (local & 7) * spx + j / npairs;
+    *pair = j % npairs;
+    *ks = slice;
+    return j < spx * npairs && slice < ksplit;
+}
+__host__ __device__ inline int gram128_grid(int npairs, int ksplit) { return 8 * ((ksplit + 7) / 8) * npairs; }
+
 __global__ void __launch_bounds__(512, 1)
 gram_x3_partial128_kernel(const float* __restrict__ f, const float* __restrict__ mean, float* __restrict__ partial, int C,
-                          int64_t HW, int ksplit, int64_t chunk) {
-    gram_x3_partial128_body(f, mean, partial, C, HW, ksplit, chunk, blockIdx.x, blockIdx.y);
+                          int64_t HW, int ksplit, int64_t chunk, int npairs) {
+    int pair, ks;
+    if (!gram128_item((int)blockIdx.x, npairs, ksplit, &pair, &ks)) return;
+    gram_x3_partial128_body(f, mean, partial, C, HW, ksplit, chunk, pair, ks);
 }
 
 __global__ void __launch_bounds__(256, 2)
@@ -636,9 +655,9 @@ __global__ void __launch_bounds__(256, 2) gram_x3_partial_batch_kernel(GramParti
 __global__ void __launch_bounds__(512, 1) gram_x3_partial128_batch_kernel(GramPartialBatch b) {
     int z = 0;
     while (z + 1 < b.count && (int)blockIdx.x >= b.first[z + 1]) ++z;
-    const int local = blockIdx.x - b.first[z];
-    const int ks = local / b.npairs[z];
-    gram_x3_partial128_body(b.f[z], b.mean[z], b.partial[z], b.C[z], b.HW[z], b.ksplit[z], b.chunk[z], local - ks * b.npairs[z], ks);
+    int pair, ks;
+    if (!gram128_item((int)blockIdx.x - b.first[z], b.npairs[z], b.ksplit[z], &pair, &ks)) return;  // (b.first: multiples of 8)
+    gram_x3_partial128_body(b.f[z], b.mean[z], b.partial[z], b.C[z], b.HW[z], b.ksplit[z], b.chunk[z], pair, ks);
 }
 
 // sum of slab values base[k * stride_elems] for k = 0, kstride, 2 kstride, ... < ksplit in index order (fp64): eight loads in flight per
@@ -967,10 +986,11 @@ static void gram_plan(int c, int64_t hw, int* npairs, int* ksplit, int64_t* chun
     const int64_t stages = (hw + GK - 1) / GK;
     int64_t want = (768 + wgs - 1) / wgs;
     if (gram_tile128(c, hw)) {
-        // one workgroup per CU: one to two rounds of them, 16 stages each where the map has that many (fewer, longer slices = fewer slabs for the
+        // one workgroup per CU, and the pairs of a slice on the CUs of ONE XCD (gram128_item): spx = 32 / pairs slices per XCD fill its 32 CUs
+        // once; one such round (8 spx slices) or two, whichever is nearer to slices of 16 stages (fewer, longer slices = fewer slabs for the
         // finishing kernels: 512 workgroups per layer at 1024 x 1024 cost them 35 us instead of 23, and the partial launch 120 instead of 112)
-        const int64_t lo = (256 + wgs - 1) / wgs, hi = (512 + wgs - 1) / wgs;
-        want = stages / 16 < lo ? lo : stages / 16 > hi ? hi : stages / 16;
+        const int64_t spx = wgs >= 32 ? 1 : 32 / wgs;
+        want = stages / 16 >= 12 * spx ? 16 * spx : 8 * spx;
     }
     if (want > stages) want = stages;
     if (want < 1) want = 1;
@@ -1034,8 +1054,8 @@ static int gram_partial_impl(const float* f, float* row_mean_out, int c, int64_t
         gram_plan(c, hw, &npairs, &ksplit, &chunk, &wgs);
         static unsigned long long attr128 = 0;
         (void)opt_in_dynamic_lds(reinterpret_cast<const void*>(gram_x3_partial128_kernel), GX128_LDS, &attr128);
-        hipLaunchKernelGGL(gram_x3_partial128_kernel, dim3(wgs, ksplit), dim3(512), GX128_LDS, s, f, center ? row_mean_out : nullptr, (float*)workspace,
-                           c, hw, ksplit, chunk);
+        hipLaunchKernelGGL(gram_x3_partial128_kernel, dim3(gram128_grid(wgs, ksplit)), dim3(512), GX128_LDS, s, f, center ? row_mean_out : nullptr,
+                           (float*)workspace, c, hw, ksplit, chunk, wgs);
     } else if (use_x3) {
         const int nplanes = c <= GT ? 2 : 4;
         const size_t lds = 2 * ((size_t)nplanes * GXPLANE + 64);
@@ -1205,7 +1225,7 @@ int maua_gram_partial_batch(int count, const float* const* fs, float* const* mea
             b.ksplit[nb] = ksplit;
             b.npairs[nb] = wgs;
             b.nplanes[nb] = group == 0 ? 2 : 4;
-            b.first[nb + 1] = b.first[nb] + wgs * ksplit;
+            b.first[nb + 1] = b.first[nb] + (group == 2 ? gram128_grid(wgs, ksplit) : wgs * ksplit);
             ++nb;
             if (ksplit > 2 * GF_FOLD) {
                 fold.partial[nfold] = (float*)workspaces[i];
