@@ -374,6 +374,14 @@ int maua_loss_ledger_sum_f64(double* ledger, int frames, int slots, float* losse
 
 /* ---- small vector helpers used by the host engine -------------------------------------------------- */
 int maua_fill(float* x, int64_t count, float value, maua_stream_t stream);
+/* out[n][c][r qy + ry][r qx + rx] (=, or += with `accumulate`) in[n][(ry r + rx) c_out + c][qy][qx] for the h x w pixels of `out`; pixels whose
+ * site (qy, qx) lies beyond qh x qw get 0.  The tail of a strided layer's backward-data pass computed as a stride-1 convolution over the
+ * output sites: the backward pass of `nn.Conv2d(3, 96, (11, 11), (4, 4))` (NIN's conv1, /root/reference/models.py:84) is a 3x3 convolution
+ * 96 -> 48 over the 254 x 254 gradient (taps = the 11 x 11 filter in steps of 4) followed by this (models.conv_strided_bwd_as_3x3). */
+/* The inverse regrouping: out[n][(ry r + rx) c_in + c][qy][qx] = in[n][c][r qy + ry][r qx + rx], 0 for pixels beyond h x w - the head of the
+ * same layer's FORWARD pass as a 3x3 stride-1 convolution 48 -> 96 over 256 x 256 sites (models.conv_strided_fwd_as_3x3, conv_x3w.hip). */
+int maua_space_to_depth(const float* in, float* out, int n, int c_in, int r, int h, int w, int qh, int qw, maua_stream_t stream);
+int maua_depth_to_space(const float* in, float* out, int n, int c_out, int r, int qh, int qw, int h, int w, int accumulate, maua_stream_t stream);
 int maua_axpy(float* y, const float* x, float alpha, int64_t count, maua_stream_t stream); /* y += alpha x */
 /* out[0] = sum_i in[i] over `count` device floats, fixed order (sums the per-module loss slots, optim.py:207-211). */
 int maua_sum_small(const float* in, int count, float* out, maua_stream_t stream);

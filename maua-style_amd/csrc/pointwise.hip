@@ -469,6 +469,33 @@ static inline int ew_grid(int64_t n) {
 
 using namespace maua;
 
+// Depth to space: in[n][(ry r + rx) c_out + c][qy][qx] -> out[n][c][r qy + ry][r qx + rx] for the H x W pixels that exist (sites beyond the
+// input's extent: zero).  The tail of the strided layers' backward pass as a stride-1 convolution over the output sites (maua_depth_to_space).
+__global__ void __launch_bounds__(256)
+depth_to_space_kernel(const float* __restrict__ in, float* __restrict__ out, int c_out, int r, int QH, int QW, int H, int W, int accumulate) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, nc = blockIdx.z;
+    if (x >= W) return;
+    const int n = nc / c_out, c = nc - n * c_out;
+    const int qy = y / r, qx = x / r, ry = y - qy * r, rx = x - qx * r;
+    float v = 0.f;
+    if (qy < QH && qx < QW) v = in[(((int64_t)n * r * r + ry * r + rx) * c_out + c) * ((int64_t)QH * QW) + (int64_t)qy * QW + qx];
+    float* o = out + ((int64_t)nc * H + y) * W + x;
+    *o = accumulate ? *o + v : v;
+}
+
+// Space to depth: out[n][(ry r + rx) c_in + c][qy][qx] = in[n][c][r qy + ry][r qx + rx] (0 beyond the h x w pixels): the head of a strided
+// layer's forward pass as a stride-1 convolution over sites (maua_space_to_depth).
+__global__ void __launch_bounds__(256)
+space_to_depth_kernel(const float* __restrict__ in, float* __restrict__ out, int c_in, int r, int QH, int QW, int H, int W) {
+    const int qx = blockIdx.x * 256 + threadIdx.x, qy = blockIdx.y, z = blockIdx.z;  // z = (n, ry, rx, c)
+    if (qx >= QW) return;
+    const int c = z % c_in, ph = (z / c_in) % (r * r), n = z / (c_in * r * r);
+    const int y = r * qy + ph / r, x = r * qx + ph % r;
+    float v = 0.f;
+    if (y < H && x < W) v = in[(((int64_t)n * c_in + c) * H + y) * W + x];
+    out[((int64_t)z * QH + qy) * QW + qx] = v;
+}
+
 extern "C" {
 
 int maua_abi_version(void) { return 2; }
@@ -663,6 +690,20 @@ int maua_loss_ledger_sum_f64(double* ledger, int frames, int slots, float* losse
     hipLaunchKernelGGL(loss_ledger_sum_kernel, dim3(frames), dim3(256), 0, (hipStream_t)stream, ledger, slots, losses, totals,
                        losses_f64);
     return check_launch("loss_ledger_sum_kernel");
+}
+
+int maua_depth_to_space(const float* in, float* out, int n, int c_out, int r, int qh, int qw, int h, int w, int accumulate, maua_stream_t stream) {
+    MAUA_REQUIRE(in && out && n > 0 && c_out > 0 && r > 0 && r <= 16 && qh > 0 && qw > 0 && h > 0 && w > 0 && (int64_t)n * c_out <= 65535 && h <= 65535,
+                 MAUA_E_INVAL, "depth_to_space: bad args");
+    hipLaunchKernelGGL(depth_to_space_kernel, dim3((w + 255) / 256, h, n * c_out), dim3(256), 0, (hipStream_t)stream, in, out, c_out, r, qh, qw, h, w, accumulate);
+    return check_launch("depth_to_space_kernel");
+}
+
+int maua_space_to_depth(const float* in, float* out, int n, int c_in, int r, int h, int w, int qh, int qw, maua_stream_t stream) {
+    MAUA_REQUIRE(in && out && n > 0 && c_in > 0 && r > 0 && r <= 16 && qh > 0 && qw > 0 && h > 0 && w > 0 && (int64_t)n * c_in * r * r <= 65535 && qh <= 65535,
+                 MAUA_E_INVAL, "space_to_depth: bad args");
+    hipLaunchKernelGGL(space_to_depth_kernel, dim3((qw + 255) / 256, qh, n * c_in * r * r), dim3(256), 0, (hipStream_t)stream, in, out, c_in, r, qh, qw, h, w);
+    return check_launch("space_to_depth_kernel");
 }
 
 int maua_fill(float* x, int64_t count, float value, maua_stream_t stream) {

@@ -288,6 +288,20 @@ class StyleEngine:
                              hip.conv_x3q_workspace_bytes(n, cout, oh, ow, cin, 2 - s.pad),
                              hip.conv_x3p_workspace_bytes(n, cin, h, w, cout, s.pad),
                              hip.conv_x3p_workspace_bytes(n, cout, oh, ow, cin, 2 - s.pad))
+        # strided layers whose backward pass runs as a 3x3 convolution over the output sites (models.conv_strided_bwd_as_3x3): the sites' buffer
+        self.strided_sites, self.strided_fwd_sites = {}, {}
+        for s in self.steps:
+            if s.kind == "conv" and s.stride > 1 and self.x6_fwd and models_mod.conv_strided_fwd_is_3x3(s.mod, *shapes[s.src][2:]):
+                n, cin, h, w = shapes[s.src]
+                qh, qw = shapes[s.dst][2] + 2, shapes[s.dst][3] + 2
+                self.strided_fwd_sites[id(s)] = torch.empty(n, s.stride * s.stride * cin, qh, qw, device=dev)
+                ws = max(ws, hip.conv_x3w_workspace_bytes(n, s.stride * s.stride * cin, qh, qw, s.mod.out_channels, 0))
+        for s in self.steps:
+            if s.kind == "conv" and s.stride > 1 and self.x6_bwd and models_mod.conv_strided_bwd_is_3x3(s.mod, *shapes[s.dst][2:]):
+                n, cin, _, _ = shapes[s.src]
+                _, cout, oh, ow = shapes[s.dst]
+                self.strided_sites[id(s)] = torch.empty(n, s.stride * s.stride * cin, oh + 2, ow + 2, device=dev)
+                ws = max(ws, hip.conv_x3w_workspace_bytes(n, cout, oh, ow, s.stride * s.stride * cin, 2))
         self.ws = torch.empty(ws, dtype=torch.uint8, device=dev)
         self.x_static = torch.empty(self.shape, device=dev)
         if plan.get("debug_poison") == "1":  # tests: every buffer starts as NaN, so a read-before-write shows up
@@ -478,6 +492,9 @@ class StyleEngine:
                 elif self.x6_fwd and models_mod.conv5x5_is_mfma(s.mod, False):
                     self._timed("conv_5x5_fwd", fl, nb, lambda: models_mod.conv5x5_mfma(
                         a[s.src], s.mod, False, out=a[s.dst], relu=s.relu, workspace=self.ws))
+                elif id(s) in self.strided_fwd_sites:
+                    self._timed("conv_other_fwd", fl, nb, lambda: models_mod.conv_strided_fwd_as_3x3(
+                        a[s.src], s.mod, a[s.dst], s.relu, self.strided_fwd_sites[id(s)], workspace=self.ws))
                 else:
                     wf, _ = s.mod.banks()
                     models_mod._route("conv2d_fwd", a[s.src], s.mod.out_channels, s.pad, False, "direct / fp32 MFMA", relu=s.relu)
@@ -778,6 +795,9 @@ class StyleEngine:
                 elif self.x6_bwd and models_mod.conv5x5_is_mfma(s.mod, True):
                     self._timed("conv_5x5_bwd", fl, nb, lambda: models_mod.conv5x5_mfma(
                         g[s.dst], s.mod, True, out=g[s.src], out_relu_mask=im, workspace=self.ws))
+                elif id(s) in self.strided_sites and im is None:
+                    self._timed("conv_other_bwd", fl, nb, lambda: models_mod.conv_strided_bwd_as_3x3(
+                        g[s.dst], s.mod, g[s.src], workspace=self.ws, sites=self.strided_sites[id(s)]))
                 else:
                     _, wb = s.mod.banks()
                     models_mod._route("conv3x3_few_out" if s.k == 3 and s.stride == 1 and s.mod.in_channels <= 4 and s.mod.out_channels >= 16 else "conv2d_bwd_data",
@@ -833,6 +853,8 @@ class StyleEngine:
                     models_mod.conv1x1_mfma(a[s.src], s.mod, False, out=a[s.dst], relu=s.relu, workspace=self.ws)
                 elif self.x6_fwd and models_mod.conv5x5_is_mfma(s.mod, False):
                     models_mod.conv5x5_mfma(a[s.src], s.mod, False, out=a[s.dst], relu=s.relu, workspace=self.ws)
+                elif id(s) in self.strided_fwd_sites:
+                    models_mod.conv_strided_fwd_as_3x3(a[s.src], s.mod, a[s.dst], s.relu, self.strided_fwd_sites[id(s)], workspace=self.ws)
                 else:
                     wf, _ = s.mod.banks()
                     hip.conv2d_fwd(a[s.src], wf, s.mod.bias_device(), s.k, s.stride, s.pad, s.relu, out=a[s.dst],

@@ -69,6 +69,8 @@ SIGNATURES = {
     "maua_gram_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i64, c_i, c_p, c_sz, c_p]),
     "maua_tv_fwd_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_p, c_sz, c_p]),
     "maua_fill": (c_i, [c_p, c_i64, c_f, c_p]),
+    "maua_depth_to_space": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "maua_space_to_depth": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "maua_axpy": (c_i, [c_p, c_p, c_f, c_i64, c_p]),
     "maua_sum_small": (c_i, [c_p, c_i, c_p, c_p]),
     "maua_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_f, c_f, c_f, c_f, c_p]),
@@ -886,6 +888,24 @@ def adam_step(x, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, ep
 # ------------------------------------------------------------------------------------------
 # image-space steps between two optimisation runs (csrc/image.hip)
 # ------------------------------------------------------------------------------------------
+def space_to_depth(x, r, out):
+    """out[n][(ry r + rx) C + c][qy][qx] = x[n][c][r qy + ry][r qx + rx] (0 beyond x), C = x.shape[1]."""
+    n, c, h, w = x.shape
+    assert out.shape[0] == n and out.shape[1] == r * r * c
+    _check(lib().maua_space_to_depth(_ptr(_f32(x, "x")), _ptr(out), n, c, r, h, w, out.shape[2], out.shape[3], _stream()), "maua_space_to_depth")
+    return out
+
+
+def depth_to_space(x, r, out, accumulate=False):
+    """out[n][c][r qy + ry][r qx + rx] (+)= x[n][(ry r + rx) C + c][qy][qx], C = out.shape[1]; pixels beyond the sites of x: 0."""
+    n, cc, qh, qw = x.shape
+    c_out = out.shape[1]
+    assert cc == r * r * c_out and out.shape[0] == n
+    _check(lib().maua_depth_to_space(_ptr(_f32(x, "x")), _ptr(out), n, c_out, r, qh, qw, out.shape[2], out.shape[3], int(accumulate), _stream()),
+           "maua_depth_to_space")
+    return out
+
+
 def set_split_batch_hint(frames):
     """Frames per launch the job plans with (split-K policy of the convolutions); returns the previous value."""
     prev = lib().maua_get_split_batch_hint()

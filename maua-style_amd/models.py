@@ -255,6 +255,55 @@ def conv3x3_bwd_from_pooled(gy_pooled, codes, honour_relu_bit, mod, out, out_rel
                                   out_relu_mask=out_relu_mask, dmat_bank=dmat_bank, dmat_inv_scale=dmat_inv_scale, workspace=workspace)
 
 
+def conv_strided_bwd_is_3x3(mod, h_out, w_out):
+    """Whether the backward-data pass of a strided layer runs as a stride-1 3x3 convolution over the output sites + depth to space (planner
+    field strided_bwd_3x3): kernel k <= 3 stride, no padding, stride^2 x in_channels <= 64 produced channels, out_channels a multiple of 16
+    (conv_x3w's chunks) - NIN's conv1, `nn.Conv2d(3, 96, (11, 11), (4, 4))` (reference models.py:84): 4.5 GFLOP that the direct kernel takes
+    140 us for at 1024 x 1024."""
+    k, stride, pad = mod.kernel_size[0], mod.stride[0], mod.padding[0]
+    return plan.on("strided_bwd_3x3") and _x6_mode()[1] and _x3_enabled() and _x3w_enabled() and stride > 1 and pad == 0 and k <= 3 * stride and \
+        stride * stride * mod.in_channels <= 64 and mod.out_channels % 16 == 0 and (h_out + 2) * (w_out + 2) >= _x3w_min_pixels() and \
+        hip.conv_x3w_supported(mod.out_channels, h_out, w_out, 2)
+
+
+def conv_strided_fwd_is_3x3(mod, h, w):
+    """Whether the FORWARD pass of a strided layer runs as space to depth + a stride-1 3x3 convolution over sites (planner field
+    strided_fwd_3x3): kernel k <= 3 stride, no padding, stride^2 x in_channels consumed channels a multiple of 16 (conv_x3w's chunks), more
+    than 32 produced channels, and a plane conv_x3w takes.  fp16x3 products (22-bit operands, per-chunk scale): measured 1.5e-7 from fp64 on
+    image-range input, the direct fp32 kernel's own distance (tests/test_strided_as_3x3_gpu.py)."""
+    k, stride, pad = mod.kernel_size[0], mod.stride[0], mod.padding[0]
+    if not (plan.on("strided_fwd_3x3") and _x6_mode()[0] and _x3_enabled() and _x3w_enabled() and stride > 1 and pad == 0 and k <= 3 * stride and
+            (stride * stride * mod.in_channels) % 16 == 0 and mod.out_channels > 32 and h >= k and w >= k):
+        return False
+    qh, qw = (h - k) // stride + 3, (w - k) // stride + 3
+    return qh * qw >= _x3w_min_pixels() and bool(hip.conv_x3w_supported(stride * stride * mod.in_channels, qh, qw, 0))
+
+
+def conv_strided_fwd_as_3x3(x, mod, out, relu, sites, workspace=None):
+    """y[co][Y][X] = sum x[c][s Y + ky][s X + kx] w[co][c][ky][kx] with ky = ry + s my: x regrouped as s^2 c channels over sites
+    (hip.space_to_depth into `sites`, (n, s^2 c, OH + 2, OW + 2): the sites the OH x OW windows reach; pixels beyond the image read 0 and
+    meet zero taps), then a 3x3 stride-1 unpadded convolution with F[co][(ry s + rx) c_in + c][my][mx] = w[co][c][ry + s my][rx + s mx]
+    (conv_x3w.hip, fp16x3)."""
+    s_ = mod.stride[0]
+    hip.space_to_depth(x, s_, sites)
+    bank, wsc = mod.bank_strided_fwd()
+    _route("conv_x3w", sites, mod.out_channels, 0, False, "64co x 8x32px", 1, strided_as_3x3=True, relu=relu)
+    return hip.conv3x3_x3w(sites, bank, wsc, mod.bias_device(), mod.out_channels, 0, relu, out=out, workspace=workspace)
+
+
+def conv_strided_bwd_as_3x3(gy, mod, out, workspace=None, sites=None):
+    """Backward-data of a stride-s, kernel-k (k <= 3 s), unpadded layer.  gx[i] = sum over windows Y and taps t with s Y + t = i of gy[Y] w[t]:
+    for i = s q + r that is t = r + s m, Y = q - m, m = 0, 1, 2 - a 3-tap sum over the output SITES q per dimension, i.e. a stride-1 3x3
+    convolution with padding 2 over gy whose s^2 x in_channels output channels are the s x s pixels of a site (filters = the k x k filter in
+    steps of s, zero where r + s m >= k), then depth to space.  The convolution is conv_x3w's (fp16x3, like every other backward pass);
+    `out` = the (n, in_channels, H, W) gradient, written whole (pixels no window covers: 0)."""
+    s_, c_img = mod.stride[0], mod.in_channels
+    bank, wsc = mod.bank_strided_bwd()
+    sites = hip.conv3x3_x3w(gy, bank, wsc, None, s_ * s_ * c_img, 2, False, out=sites, workspace=workspace)  # (`sites`: the caller's (n, s^2 c, OH + 2, OW + 2) buffer)
+    _route("conv_x3w", gy, s_ * s_ * c_img, 2, True, "64co x 8x32px", 1, strided_as_3x3=True)
+    return hip.depth_to_space(sites, s_, out)
+
+
 def conv1x1_is_mfma(mod, backward):
     """Whether a layer's pass runs on the fp16x3 1x1 kernel (conv1x1_x3.hip): 1x1, stride 1, no padding (NIN's cccp layers,
     reference models.py:84-110), the split-precision path enabled for that pass and fp16x3 selected."""
@@ -374,6 +423,40 @@ class Conv2d(nn.Conv2d):
             self._banks3q = hip.conv_pack_filters_x3q(self.weight.detach().contiguous())
             self._bank3q_key = key
         return self._banks3q
+
+    def bank_strided_fwd(self):
+        """(bank, filter scale) of conv_strided_fwd_as_3x3 (conv_x3w's forward bank): F[co][(ry s + rx) c_in + c][my][mx] =
+        w[co][c][ry + s my][rx + s mx], 0 beyond the k x k filter."""
+        key = (self.weight.data_ptr(), self.weight._version, self.weight.device)
+        if getattr(self, "_banksf_key", None) != key:
+            w = self.weight.detach()
+            co, ci, k, _ = w.shape
+            s_ = self.stride[0]
+            wp = torch.zeros(co, ci, 3 * s_, 3 * s_, device=w.device, dtype=w.dtype)
+            wp[:, :, :k, :k] = w
+            f = wp.view(co, ci, 3, s_, 3, s_).permute(0, 3, 5, 1, 2, 4).reshape(co, s_ * s_ * ci, 3, 3).contiguous()
+            bank, _, wsc = hip.conv_pack_filters_x3w(f)
+            self._banksf = (bank, wsc)
+            self._banksf_key = key
+        return self._banksf
+
+    def bank_strided_bwd(self):
+        """(bank, filter scale) of conv_strided_bwd_as_3x3: the k x k filter regrouped as 3x3 taps over output sites,
+        F[(ry s + rx) c_in + c][co][ty][tx] = w[co][c][ry + s (2 - ty)][rx + s (2 - tx)] (0 beyond the filter), as conv_x3w's FORWARD bank
+        of a layer that consumes out_channels and produces s^2 c_in channels with padding 2."""
+        key = (self.weight.data_ptr(), self.weight._version, self.weight.device)
+        if getattr(self, "_banksb_key", None) != key:
+            w = self.weight.detach()
+            co, ci, k, _ = w.shape
+            s_ = self.stride[0]
+            wp = torch.zeros(co, ci, 3 * s_, 3 * s_, device=w.device, dtype=w.dtype)
+            wp[:, :, :k, :k] = w
+            # wp[co][c][ry + s m_y][rx + s m_x] -> [ry][rx][c][co][m_y][m_x], taps t = 2 - m
+            f = wp.view(co, ci, 3, s_, 3, s_).permute(3, 5, 1, 0, 2, 4).flip(4, 5).reshape(s_ * s_ * ci, co, 3, 3).contiguous()
+            bank, _, wsc = hip.conv_pack_filters_x3w(f)
+            self._banksb = (bank, wsc)
+            self._banksb_key = key
+        return self._banksb
 
     def banks_kxk(self):
         """fp16x2 pre-split, pre-scaled banks (forward, backward-data, filter scale) of the k x k fp16x3 kernel."""
