@@ -45,7 +45,7 @@ __global__ void row_mean_finish_kernel(const double* __restrict__ partial, float
     mean[c] = (float)(acc / (double)HW);
 }
 
-// ... of several layers in one launch each (grid z = layer; rows past a layer's C leave at once)
+// ... of several layers in one launch each
 constexpr int RM_MAX = 8;
 struct RowMeanBatch {
     const float* f[RM_MAX];
@@ -53,18 +53,30 @@ struct RowMeanBatch {
     float* mean[RM_MAX];
     int64_t HW[RM_MAX];
     int C[RM_MAX];
+    int first[RM_MAX + 1];  // rows of the layers in front
 };
 __global__ void __launch_bounds__(256) row_mean_partial_batch_kernel(RowMeanBatch b) {
     __shared__ double scratch[16];
-    const int z = blockIdx.z;
-    if ((int)blockIdx.x >= b.C[z]) return;  // (whole workgroup)
+    // grid x = the rows of every layer, one after the other (b.first: prefix sums of C), y = split.  Same elements per (split, thread) and
+    // the same order of additions as row_mean_partial_kernel (bit-identical means); the loads of eight additions are issued together.
+    int z = 0;
+    while ((int)blockIdx.x >= b.first[z + 1]) ++z;
     const int64_t HW = b.HW[z];
-    const float* row = b.f[z] + (int64_t)blockIdx.x * HW;
+    const int c = blockIdx.x - b.first[z];
+    const float* row = b.f[z] + (int64_t)c * HW;
     const int64_t per = (HW + RM_SPLIT - 1) / RM_SPLIT, lo = blockIdx.y * per, hi = min(HW, lo + per);
     double acc = 0.0;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) acc += (double)row[i];
+    int64_t i = lo + threadIdx.x;
+    for (; i + 7 * 256 < hi; i += 8 * 256) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = row[i + k * 256];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += (double)v[k];
+    }
+    for (; i < hi; i += 256) acc += (double)row[i];
     acc = block_sum(acc, scratch);
-    if (threadIdx.x == 0) b.partial[z][(int64_t)blockIdx.x * RM_SPLIT + blockIdx.y] = acc;
+    if (threadIdx.x == 0) b.partial[z][(int64_t)c * RM_SPLIT + blockIdx.y] = acc;
 }
 __global__ void row_mean_finish_batch_kernel(RowMeanBatch b) {
     const int z = blockIdx.y;
@@ -1177,11 +1189,12 @@ int maua_gram_partial_batch(int count, const float* const* fs, float* const* mea
             rm.mean[nrm] = const_cast<float*>(means[i]);
             rm.HW[nrm] = hws[i];
             rm.C[nrm] = cs[i];
+            rm.first[nrm + 1] = rm.first[nrm] + cs[i];
             maxc = cs[i] > maxc ? cs[i] : maxc;
             ++nrm;
         }
         if (nrm) {
-            hipLaunchKernelGGL(row_mean_partial_batch_kernel, dim3(maxc, RM_SPLIT, nrm), dim3(256), 0, s, rm);
+            hipLaunchKernelGGL(row_mean_partial_batch_kernel, dim3(rm.first[nrm], RM_SPLIT), dim3(256), 0, s, rm);
             int rc = check_launch("row_mean_partial_batch_kernel");
             if (rc) return rc;
             hipLaunchKernelGGL(row_mean_finish_batch_kernel, dim3((maxc + 255) / 256, nrm), dim3(256), 0, s, rm);
