@@ -358,7 +358,7 @@ int maua_gram_partial_batch(int count, const float* const* fs, float* const* mea
                             void* const* workspaces, const size_t* workspace_bytes, const int* slab_counts, maua_stream_t stream);
 /* `means` of maua_gram_partial_batch (nullable; entries nullable): a non-null entry makes the layer a covariance-form layer (loss.py:87-89) -
  * the call first computes the row means of all such layers into those arrays (two launches for all of them), then centres their products.
- * maua_gram_row_means: the same means on their own (maua_gram_partial(center = 1) = this + the partial kernel).  workspace: c * 16 doubles
+ * maua_gram_row_means: the same means on their own (maua_gram_partial(center = 1) = this + the partial kernel).  workspace: c * 64 doubles
  * (the start of the layer's maua_gram_workspace_bytes buffer will do: the slabs overwrite it later). */
 int maua_gram_row_means(const float* f, float* row_mean_out, int c, int64_t hw, void* workspace, size_t workspace_bytes, maua_stream_t stream);
 int maua_gram_finish_mse_batch(int count, const void* const* workspaces, float* const* grams, const float* const* targets,

@@ -24,24 +24,41 @@ constexpr int GRS = GK + 4;  // LDS row stride (floats): 16-byte aligned rows, 4
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
-// Row means in two fixed-order stages: grid (C, RM_SPLIT) partial sums in fp64, then one small kernel adds each row's
-// partials in index order (one workgroup per row could not fill the chip: 96 rows of 64516 values took 64 us).
-constexpr int RM_SPLIT = 16;
+// Row means in two fixed-order stages: grid (C, splits) partial sums in fp64, then one small kernel adds each row's partials in index
+// order.  A workgroup takes ~16K values of a row (rm_split: 64516 values -> 4 workgroups, 16129 and fewer -> 1): thread t adds the
+// values t, t + 256, ... of its part in order, sixteen loads in flight - with 4K values per workgroup (round 4) the launch was bound by
+// workgroup turnover (35840 workgroups: 37 us for NIN's six layers, 74 MB).
+constexpr int RM_SPLIT = 64;  // most splits of a row (the partial sums' row length)
+static __host__ __device__ inline int rm_split(int64_t HW) {
+    const int64_t k = (HW + 16383) / 16384;
+    return k < 1 ? 1 : k > RM_SPLIT ? RM_SPLIT : (int)k;
+}
+__device__ __forceinline__ double rm_part_sum(const float* __restrict__ row, int64_t HW, int split, int part, double* scratch) {
+    const int64_t per = (HW + split - 1) / split, lo = part * per, hi = min(HW, lo + per);
+    double acc = 0.0;
+    int64_t i = lo + threadIdx.x;
+    for (; i + 15 * 256 < hi; i += 16 * 256) {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = row[i + k * 256];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += (double)v[k];
+    }
+    for (; i < hi; i += 256) acc += (double)row[i];
+    return block_sum(acc, scratch);
+}
 __global__ void __launch_bounds__(256)
 row_mean_partial_kernel(const float* __restrict__ f, double* __restrict__ partial, int64_t HW) {
     __shared__ double scratch[16];
-    const float* row = f + (int64_t)blockIdx.x * HW;
-    const int64_t per = (HW + RM_SPLIT - 1) / RM_SPLIT, lo = blockIdx.y * per, hi = min(HW, lo + per);
-    double acc = 0.0;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) acc += (double)row[i];
-    acc = block_sum(acc, scratch);
+    const double acc = rm_part_sum(f + (int64_t)blockIdx.x * HW, HW, gridDim.y, blockIdx.y, scratch);
     if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * RM_SPLIT + blockIdx.y] = acc;
 }
 __global__ void row_mean_finish_kernel(const double* __restrict__ partial, float* __restrict__ mean, int C, int64_t HW) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double acc = 0.0;
-    for (int k = 0; k < RM_SPLIT; ++k) acc += partial[(int64_t)c * RM_SPLIT + k];
+    const int split = rm_split(HW);
+    for (int k = 0; k < split; ++k) acc += partial[(int64_t)c * RM_SPLIT + k];
     mean[c] = (float)(acc / (double)HW);
 }
 
@@ -53,37 +70,26 @@ struct RowMeanBatch {
     float* mean[RM_MAX];
     int64_t HW[RM_MAX];
     int C[RM_MAX];
-    int first[RM_MAX + 1];  // rows of the layers in front
+    int first[RM_MAX + 1];  // (row, part) items of the layers in front
 };
 __global__ void __launch_bounds__(256) row_mean_partial_batch_kernel(RowMeanBatch b) {
     __shared__ double scratch[16];
-    // grid x = the rows of every layer, one after the other (b.first: prefix sums of C), y = split.  Same elements per (split, thread) and
-    // the same order of additions as row_mean_partial_kernel (bit-identical means); the loads of eight additions are issued together.
+    // grid x = the (row, part) items of every layer, one layer after the other (b.first: prefix sums of C x splits); the arithmetic of
+    // row_mean_partial_kernel (bit-identical means)
     int z = 0;
     while ((int)blockIdx.x >= b.first[z + 1]) ++z;
     const int64_t HW = b.HW[z];
-    const int c = blockIdx.x - b.first[z];
-    const float* row = b.f[z] + (int64_t)c * HW;
-    const int64_t per = (HW + RM_SPLIT - 1) / RM_SPLIT, lo = blockIdx.y * per, hi = min(HW, lo + per);
-    double acc = 0.0;
-    int64_t i = lo + threadIdx.x;
-    for (; i + 7 * 256 < hi; i += 8 * 256) {
-        float v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = row[i + k * 256];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc += (double)v[k];
-    }
-    for (; i < hi; i += 256) acc += (double)row[i];
-    acc = block_sum(acc, scratch);
-    if (threadIdx.x == 0) b.partial[z][(int64_t)c * RM_SPLIT + blockIdx.y] = acc;
+    const int split = rm_split(HW), item = blockIdx.x - b.first[z], c = item / split, part = item - c * split;
+    const double acc = rm_part_sum(b.f[z] + (int64_t)c * HW, HW, split, part, scratch);
+    if (threadIdx.x == 0) b.partial[z][(int64_t)c * RM_SPLIT + part] = acc;
 }
 __global__ void row_mean_finish_batch_kernel(RowMeanBatch b) {
     const int z = blockIdx.y;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= b.C[z]) return;
     double acc = 0.0;
-    for (int k = 0; k < RM_SPLIT; ++k) acc += b.partial[z][(int64_t)c * RM_SPLIT + k];
+    const int split = rm_split(b.HW[z]);
+    for (int k = 0; k < split; ++k) acc += b.partial[z][(int64_t)c * RM_SPLIT + k];
     b.mean[z][c] = (float)(acc / (double)b.HW[z]);
 }
 
@@ -1052,7 +1058,7 @@ static int gram_partial_impl(const float* f, float* row_mean_out, int c, int64_t
     hipStream_t s = (hipStream_t)stream;
     if (center) {
         // the partial sums live at the start of the workspace, which the Gram slabs overwrite afterwards (same stream)
-        hipLaunchKernelGGL(row_mean_partial_kernel, dim3(c, RM_SPLIT), dim3(256), 0, s, f, (double*)workspace, hw);
+        hipLaunchKernelGGL(row_mean_partial_kernel, dim3(c, rm_split(hw)), dim3(256), 0, s, f, (double*)workspace, hw);
         int rc = check_launch("row_mean_partial_kernel");
         if (rc) return rc;
         hipLaunchKernelGGL(row_mean_finish_kernel, dim3((c + 255) / 256), dim3(256), 0, s, (const double*)workspace, row_mean_out,
@@ -1144,7 +1150,7 @@ int maua_gram_row_means(const float* f, float* row_mean_out, int c, int64_t hw, 
     MAUA_REQUIRE(workspace_bytes >= (size_t)c * RM_SPLIT * sizeof(double), MAUA_E_WORKSPACE, "gram_row_means: workspace %zu < %zu", workspace_bytes,
                  (size_t)c * RM_SPLIT * sizeof(double));
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(row_mean_partial_kernel, dim3(c, RM_SPLIT), dim3(256), 0, s, f, (double*)workspace, hw);
+    hipLaunchKernelGGL(row_mean_partial_kernel, dim3(c, rm_split(hw)), dim3(256), 0, s, f, (double*)workspace, hw);
     int rc = check_launch("row_mean_partial_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(row_mean_finish_kernel, dim3((c + 255) / 256), dim3(256), 0, s, (const double*)workspace, row_mean_out, c, hw);
@@ -1189,12 +1195,12 @@ int maua_gram_partial_batch(int count, const float* const* fs, float* const* mea
             rm.mean[nrm] = const_cast<float*>(means[i]);
             rm.HW[nrm] = hws[i];
             rm.C[nrm] = cs[i];
-            rm.first[nrm + 1] = rm.first[nrm] + cs[i];
+            rm.first[nrm + 1] = rm.first[nrm] + cs[i] * rm_split(hws[i]);
             maxc = cs[i] > maxc ? cs[i] : maxc;
             ++nrm;
         }
         if (nrm) {
-            hipLaunchKernelGGL(row_mean_partial_batch_kernel, dim3(rm.first[nrm], RM_SPLIT), dim3(256), 0, s, rm);
+            hipLaunchKernelGGL(row_mean_partial_batch_kernel, dim3(rm.first[nrm]), dim3(256), 0, s, rm);
             int rc = check_launch("row_mean_partial_batch_kernel");
             if (rc) return rc;
             hipLaunchKernelGGL(row_mean_finish_batch_kernel, dim3((maxc + 255) / 256, nrm), dim3(256), 0, s, rm);
