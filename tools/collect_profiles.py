@@ -37,8 +37,10 @@ for a, b in (("bench_graph.json", f"bench_r{rr}_final_1024_lbfgs.json"), ("bench
         f.write(json.dumps(last_json(os.path.join(src, a))) + "\n")
 for a, b in (("sizes_lbfgs.jsonl", f"bench_r{rr}_sizes_lbfgs.jsonl"), ("sizes_adam.jsonl", f"bench_r{rr}_sizes_adam.jsonl"),
              ("configs.json", f"configs_r{rr}_final.json"), ("pmc_traffic.json", f"pmc_r{rr}_traffic.json"),
-             ("pmc_traffic_nin.json", f"pmc_r{rr}_traffic_nin.json"), ("trace_graph_1024.txt", f"probe_r{rr}_launch_table_1024_graph.txt"),
-             ("trace_graph_512.txt", f"probe_r{rr}_launch_table_512_graph.txt"), ("check_x3p.txt", f"probe_r{rr}_x3p_vs_x3q_x3w.txt"),
+             ("pmc_traffic_nin.json", f"pmc_r{rr}_traffic_nin.json"), ("launches_graph_1024.txt", f"probe_r{rr}_launch_table_1024_graph.txt"),
+             ("launches_graph_512.txt", f"probe_r{rr}_launch_table_512_graph.txt"), ("launches_graph_256.txt", f"probe_r{rr}_launch_table_256_graph.txt"),
+             ("launches_graph_nin.txt", f"probe_r{rr}_launch_table_nin_graph.txt"), ("graph_host_cost.txt", f"probe_r{rr}_graph_host_cost.txt"),
+             ("check_x3p.txt", f"probe_r{rr}_x3p_vs_x3q_x3w.txt"),
              ("clock_x3p_conv1_2.txt", f"probe_r{rr}_clock_x3p_conv1_2.txt"), ("soak.txt", f"probe_r{rr}_soak.txt"),
              ("stage_bw.txt", f"probe_r{rr}_stage_bw.txt"), ("gram128_zero_lanes.txt", f"probe_r{rr}_gram128_zero_lanes.txt")):
     if os.path.exists(os.path.join(src, a)):

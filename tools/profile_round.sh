@@ -22,9 +22,11 @@ rm -rf $O/pmc_a $O/pmc_b $O/pmc_c $O/pmc_d
 for S in 256 512 724 1024 1448 2048; do python bench.py --size $S --steps 100 --no_cpu_baseline --no_extra_sizes 2>/dev/null >> $O/sizes_lbfgs.jsonl; done
 for S in 1024 1448 2048; do python bench.py --size $S --optimizer adam --steps 100 --no_cpu_baseline --no_extra_sizes 2>/dev/null >> $O/sizes_adam.jsonl; done
 python tools/run_configs.py --configs 2,3,4,5,6 --out $O/configs.json > $O/configs.log 2>&1
-# per-dispatch durations of one iteration as the product runs it (graph replay): the per-launch tables (eager events overstate host-bound launches)
-MIN_US=0 GRAPH=--hip_graph BENCH_ARGS="--no_accuracy_probe" bash tools/trace_ab.sh gpurun_out/${ROUND_DIR:-r5fin}/tr1024 MAUA_HIP_GRAPH "1" > $O/trace_graph_1024.txt 2>&1
-MIN_US=0 GRAPH=--hip_graph BENCH_ARGS="--no_accuracy_probe --size 512" bash tools/trace_ab.sh gpurun_out/${ROUND_DIR:-r5fin}/tr512 MAUA_HIP_GRAPH "1" > $O/trace_graph_512.txt 2>&1
+# per-dispatch durations (and idle gaps) of one steady-state iteration as the product runs it - replayed from the hipGraph, history full:
+# the per-launch tables (eager events overstate host-bound launches)
+for S in 1024 512 256; do bash tools/trace_gaps.sh gpurun_out/${ROUND_DIR:-r5fin}/tg$S --size $S --steps 130 > $O/launches_graph_$S.txt 2>&1; done
+bash tools/trace_gaps.sh gpurun_out/${ROUND_DIR:-r5fin}/tgnin --model nin --steps 130 > $O/launches_graph_nin.txt 2>&1
+python tools/graph_host_cost.py 256 512 1024 2>/dev/null | grep size > $O/graph_host_cost.txt
 python tools/check_x3p.py 1024 5 10 > $O/check_x3p.txt 2>&1
 python tools/x3p_clock.py 64 64 1024 plain > $O/clock_x3p_conv1_2.txt 2>&1
 python tools/x3p_clock.py 64 64 1024 masked >> $O/clock_x3p_conv1_2.txt 2>&1
