@@ -795,6 +795,8 @@ class StyleEngine:
                 elif self.x6_bwd and models_mod.conv5x5_is_mfma(s.mod, True):
                     self._timed("conv_5x5_bwd", fl, nb, lambda: models_mod.conv5x5_mfma(
                         g[s.dst], s.mod, True, out=g[s.src], out_relu_mask=im, workspace=self.ws))
+                elif im is None and models_mod.conv_few_is_mfma(s.mod, *g[s.dst].shape[0:1], *g[s.dst].shape[2:]):
+                    self._timed("conv_other_bwd", fl, nb, lambda: models_mod.conv_few_mfma(g[s.dst], s.mod, g[s.src]))
                 elif id(s) in self.strided_sites and im is None:
                     self._timed("conv_other_bwd", fl, nb, lambda: models_mod.conv_strided_bwd_as_3x3(
                         g[s.dst], s.mod, g[s.src], workspace=self.ws, sites=self.strided_sites[id(s)]))

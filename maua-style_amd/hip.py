@@ -70,6 +70,10 @@ SIGNATURES = {
     "maua_tv_fwd_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_p, c_sz, c_p]),
     "maua_fill": (c_i, [c_p, c_i64, c_f, c_p]),
     "maua_depth_to_space": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "maua_conv_few_mfma_bank_bytes": (c_sz, []),
+    "maua_conv_pack_filters_few_mfma": (c_i, [c_p, c_p, c_i, c_i, c_p]),
+    "maua_conv_few_mfma_supported": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    "maua_conv3x3_few_mfma": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "maua_space_to_depth": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "maua_axpy": (c_i, [c_p, c_p, c_f, c_i64, c_p]),
     "maua_sum_small": (c_i, [c_p, c_i, c_p, c_p]),
@@ -888,6 +892,27 @@ def adam_step(x, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, ep
 # ------------------------------------------------------------------------------------------
 # image-space steps between two optimisation runs (csrc/image.hip)
 # ------------------------------------------------------------------------------------------
+def conv_pack_filters_few_mfma(w):
+    """OIHW weights (64, 1-3, 3, 3) -> the bank of conv3x3_few_mfma (bf16 triples in MFMA lane order)."""
+    cout, cin = w.shape[:2]
+    bank = torch.empty(lib().maua_conv_few_mfma_bank_bytes(), dtype=torch.uint8, device=w.device)
+    _check(lib().maua_conv_pack_filters_few_mfma(_ptr(_f32(w, "w")), bank.data_ptr(), cout, cin, _stream()), "maua_conv_pack_filters_few_mfma")
+    return bank
+
+
+def conv_few_mfma_supported(n, cin, h, w, cout, pad):
+    return bool(lib().maua_conv_few_mfma_supported(int(n), int(cin), int(h), int(w), int(cout), int(pad)))
+
+
+def conv3x3_few_mfma(gy, bank, cin, out=None, rows=8):
+    """Backward-data of the image layer on the matrix cores: gy (n, 64, h, w) -> (n, cin, h, w)."""
+    n, cout, h, w = gy.shape
+    if out is None:
+        out = torch.empty(n, cin, h, w, device=gy.device, dtype=torch.float32)
+    _check(lib().maua_conv3x3_few_mfma(_ptr(_f32(gy, "gy")), bank.data_ptr(), _ptr(out), n, cin, h, w, cout, int(rows), _stream()), "maua_conv3x3_few_mfma")
+    return out
+
+
 def space_to_depth(x, r, out):
     """out[n][(ry r + rx) C + c][qy][qx] = x[n][c][r qy + ry][r qx + rx] (0 beyond x), C = x.shape[1]."""
     n, c, h, w = x.shape
