@@ -67,14 +67,20 @@ struct FewMfmaArgs {
     const unsigned char* bank;
     float* gx;
     int H, W, co;
+    int tiles_x, tiles, per_xcd;  // grid x = 8 per_xcd workgroups: workgroup id takes tile (id % 8) per_xcd + id / 8 - XCD k (ids = k mod 8) walks
+                                  // the k-th contiguous band of the row-major tile list, its CUs side by side (conv_x3w.hip's order; the
+                                  // dispatch order - tile = id - reads the same bytes at half the rate: tools/mfma_probe/stage_bw.hip)
 };
 
-template <int ROWS, int MODE = 0>  // MODE (experiments): 1 = no matrix work, 2 = no loads
+template <int ROWS>
 __global__ void __launch_bounds__(256, 2) conv_few_mfma_kernel(FewMfmaArgs p) {
     extern __shared__ float T[];  // [27][TR x 64]
     constexpr int TR = ROWS + 2, TPL = TR * FM_TC, NBLK = TR * 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 31, kg = lane >> 5;
-    const int x0 = blockIdx.x * FM_OC, y0 = blockIdx.y * ROWS, img = blockIdx.z;
+    const int tile = (int)(blockIdx.x & 7) * p.per_xcd + (int)(blockIdx.x >> 3);
+    if (tile >= p.tiles) return;  // (whole workgroup)
+    const int ty = tile / p.tiles_x;
+    const int x0 = (tile - ty * p.tiles_x) * FM_OC, y0 = ty * ROWS, img = blockIdx.z;
     const int64_t plane = (int64_t)p.H * p.W;
     fm_bf16x8 a[FM_STEPS][3];
 #pragma unroll
@@ -91,13 +97,6 @@ __global__ void __launch_bounds__(256, 2) conv_few_mfma_kernel(FewMfmaArgs p) {
         // (the lane half's eight channels ride in the vector offset, the step's and the register's channel in the scalar offset, which
         // the range check does not see: an out-of-image pixel is out of range whatever the channel)
         const unsigned voff = ok ? (unsigned)(((int64_t)kg * 8 * plane + (int64_t)Y * p.W + X) * 4) : 0x80000000u;
-        if constexpr (MODE == 2) {
-#pragma unroll
-            for (int step = 0; step < FM_STEPS; ++step)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[step][i] = __builtin_bit_cast(float, voff + i);
-            return;
-        }
 #pragma unroll
         for (int step = 0; step < FM_STEPS; ++step)
 #pragma unroll
@@ -111,12 +110,6 @@ __global__ void __launch_bounds__(256, 2) conv_few_mfma_kernel(FewMfmaArgs p) {
         fm_f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        if constexpr (MODE == 1) {
-#pragma unroll
-            for (int step = 0; step < FM_STEPS; ++step)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc[(step * 8 + i) & 15] += v[step][i];
-        } else
 #pragma unroll
         for (int step = 0; step < FM_STEPS; ++step) {
             fm_u32x4 bp[3];
@@ -193,36 +186,28 @@ int maua_conv_few_mfma_supported(int n, int cin, int h, int w, int cout, int pad
            (h + 3) / 4 <= 65535;
 }
 
-int maua_conv3x3_few_mfma(const float* gy, const void* bank, float* gx, int n, int cin, int h, int w, int cout, int rows, maua_stream_t stream) {
+// tile: 0 = the library's choice (4 output rows per workgroup below a million pixels, 8 from there); 1 / 2 / 3 = 4 / 8 / 14 rows x 62 columns
+int maua_conv3x3_few_mfma(const float* gy, const void* bank, float* gx, int n, int cin, int h, int w, int cout, int tile, maua_stream_t stream) {
     MAUA_REQUIRE(gy && bank && gx, MAUA_E_INVAL, "conv3x3_few_mfma: null pointer");
     MAUA_REQUIRE(maua_conv_few_mfma_supported(n, cin, h, w, cout, 1), MAUA_E_UNSUPPORTED, "conv3x3_few_mfma: unsupported geometry");
-    if (rows == 108 || rows == 208) {  // experiments: tile of 8 rows without the matrix work / without the loads
-        const int lds8 = 27 * 10 * FM_TC * 4;
-        FewMfmaArgs q{gy, (const unsigned char*)bank, gx, h, w, cin};
-        static unsigned long long at1 = 0, at2 = 0;
-        const dim3 g8((w + FM_OC - 1) / FM_OC, (h + 7) / 8, n);
-        if (rows == 108) {
-            (void)opt_in_dynamic_lds(reinterpret_cast<const void*>(conv_few_mfma_kernel<8, 1>), lds8, &at1);
-            hipLaunchKernelGGL((conv_few_mfma_kernel<8, 1>), g8, dim3(256), lds8, (hipStream_t)stream, q);
-        } else {
-            (void)opt_in_dynamic_lds(reinterpret_cast<const void*>(conv_few_mfma_kernel<8, 2>), lds8, &at2);
-            hipLaunchKernelGGL((conv_few_mfma_kernel<8, 2>), g8, dim3(256), lds8, (hipStream_t)stream, q);
-        }
-        return check_launch("conv_few_mfma_kernel");
-    }
-    MAUA_REQUIRE(rows == 4 || rows == 8 || rows == 14, MAUA_E_INVAL, "conv3x3_few_mfma: rows per tile 4, 8 or 14");
-    FewMfmaArgs p{gy, (const unsigned char*)bank, gx, h, w, cin};
-    static unsigned long long attr4 = 0, attr8 = 0, attr14 = 0;
+    MAUA_REQUIRE(tile >= 0 && tile <= 3, MAUA_E_INVAL, "conv3x3_few_mfma: tile code 0 - 3");
+    if (tile == 0) tile = (int64_t)h * w < 1000000 ? 1 : 2;
+    FewMfmaArgs p{gy, (const unsigned char*)bank, gx, h, w, cin, 0, 0, 0};
+    static unsigned long long attr[4] = {0, 0, 0, 0};
+    const int rows = tile == 1 ? 4 : tile == 2 ? 8 : 14;
     const int lds = 27 * (rows + 2) * FM_TC * 4;
-    const dim3 grid((w + FM_OC - 1) / FM_OC, (h + rows - 1) / rows, n);
+    p.tiles_x = (w + FM_OC - 1) / FM_OC;
+    p.tiles = p.tiles_x * ((h + rows - 1) / rows);
+    p.per_xcd = (p.tiles + 7) / 8;
+    const dim3 grid((unsigned)(8 * p.per_xcd), 1, (unsigned)n);
     if (rows == 4) {
-        (void)opt_in_dynamic_lds(reinterpret_cast<const void*>(conv_few_mfma_kernel<4>), lds, &attr4);
+        (void)opt_in_dynamic_lds(reinterpret_cast<const void*>(conv_few_mfma_kernel<4>), lds, &attr[1]);
         hipLaunchKernelGGL(conv_few_mfma_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, p);
     } else if (rows == 8) {
-        (void)opt_in_dynamic_lds(reinterpret_cast<const void*>(conv_few_mfma_kernel<8>), lds, &attr8);
+        (void)opt_in_dynamic_lds(reinterpret_cast<const void*>(conv_few_mfma_kernel<8>), lds, &attr[2]);
         hipLaunchKernelGGL(conv_few_mfma_kernel<8>, grid, dim3(256), lds, (hipStream_t)stream, p);
     } else {
-        (void)opt_in_dynamic_lds(reinterpret_cast<const void*>(conv_few_mfma_kernel<14>), lds, &attr14);
+        (void)opt_in_dynamic_lds(reinterpret_cast<const void*>(conv_few_mfma_kernel<14>), lds, &attr[3]);
         hipLaunchKernelGGL(conv_few_mfma_kernel<14>, grid, dim3(256), lds, (hipStream_t)stream, p);
     }
     return check_launch("conv_few_mfma_kernel");

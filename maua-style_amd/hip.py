@@ -904,12 +904,13 @@ def conv_few_mfma_supported(n, cin, h, w, cout, pad):
     return bool(lib().maua_conv_few_mfma_supported(int(n), int(cin), int(h), int(w), int(cout), int(pad)))
 
 
-def conv3x3_few_mfma(gy, bank, cin, out=None, rows=8):
-    """Backward-data of the image layer on the matrix cores: gy (n, 64, h, w) -> (n, cin, h, w)."""
+def conv3x3_few_mfma(gy, bank, cin, out=None, tile=0):
+    """Backward-data of the image layer on the matrix cores: gy (n, 64, h, w) -> (n, cin, h, w).  tile: 0 = the library's choice,
+    1 / 2 / 3 = 4 / 8 / 14 output rows x 62 columns per workgroup."""
     n, cout, h, w = gy.shape
     if out is None:
         out = torch.empty(n, cin, h, w, device=gy.device, dtype=torch.float32)
-    _check(lib().maua_conv3x3_few_mfma(_ptr(_f32(gy, "gy")), bank.data_ptr(), _ptr(out), n, cin, h, w, cout, int(rows), _stream()), "maua_conv3x3_few_mfma")
+    _check(lib().maua_conv3x3_few_mfma(_ptr(_f32(gy, "gy")), bank.data_ptr(), _ptr(out), n, cin, h, w, cout, int(tile), _stream()), "maua_conv3x3_few_mfma")
     return out
 
 

@@ -268,20 +268,17 @@ def conv_strided_bwd_is_3x3(mod, h_out, w_out):
 
 def conv_few_is_mfma(mod, n, h, w):
     """Whether the backward-data pass of the image layer (64 filters over 1-3 channels, 3x3, padding 1) runs on the matrix cores
-    (conv_few_mfma.hip; planner fields few_mfma, few_mfma_max_pixels): per gradient pixel the 27 (tap, channel) sums as one bf16x6
-    product block, then a nine-value gather.  Measured against conv3x3_few_out_kernel (vector ALU): 256 x 256 11.0 vs 16.6 us,
-    512 x 512 25.4 vs 30.6, 1024 x 1024 80 vs 82, 2048 x 2048 317 vs 295 - routed up to 512 x 512 pixels."""
+    (conv_few_mfma.hip; planner field few_mfma): per gradient pixel the 27 (tap, channel) sums as one bf16x6 product block, then a
+    nine-value gather.  Measured against conv3x3_few_out_kernel (vector ALU): 256 x 256 9.6 vs 16.8 us, 512 x 512 20.3 vs 30.9,
+    724 x 724 31.8 vs 48.9, 1024 x 1024 68.1 vs 79.5, 2048 x 2048 289 vs 295."""
     k, stride, pad = mod.kernel_size[0], mod.stride[0], mod.padding[0]
-    return plan.on("few_mfma") and _x6_mode()[1] and k == 3 and stride == 1 and pad == 1 and h * w <= plan.get_int("few_mfma_max_pixels") and \
-        hip.conv_few_mfma_supported(n, mod.in_channels, h, w, mod.out_channels, pad)
+    return plan.on("few_mfma") and _x6_mode()[1] and k == 3 and stride == 1 and pad == 1 and hip.conv_few_mfma_supported(n, mod.in_channels, h, w, mod.out_channels, pad)
 
 
 def conv_few_mfma(gy, mod, out):
-    """gx = conv_backward(gy) of the image layer on conv_few_mfma.hip; tiles of 4 output rows below 384 x 384 pixels, of 8 above."""
-    h, w = gy.shape[2:]
-    rows = 4 if h * w < 384 * 384 else 8
-    _route("conv_few_mfma", gy, mod.in_channels, 1, True, f"{rows} x 62 px, bf16x6")
-    return hip.conv3x3_few_mfma(gy, mod.bank_few_mfma(), mod.in_channels, out=out, rows=rows)
+    """gx = conv_backward(gy) of the image layer on conv_few_mfma.hip (the library picks the tile height)."""
+    _route("conv_few_mfma", gy, mod.in_channels, 1, True, "4 / 8 x 62 px, bf16x6")
+    return hip.conv3x3_few_mfma(gy, mod.bank_few_mfma(), mod.in_channels, out=out)
 
 
 def conv_strided_fwd_is_3x3(mod, h, w):

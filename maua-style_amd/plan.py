@@ -31,7 +31,6 @@ FIELDS = {
     "conv_image": ("1", "host", "the 3-channel image layer's forward pass on conv_img.hip"),
     "x3w_min_pixels": ("4096", "host", "planes smaller than this run conv_x3.hip's 4-row tiles"),
     "few_mfma": ("1", "host", "backward-data of the image layer (64 -> 3 channels) on the matrix cores (conv_few_mfma.hip) instead of conv3x3_few_out's vector-ALU kernel"),
-    "few_mfma_max_pixels": ("262144", "host", "... for planes of at most this many pixels (measured: wins up to 512 x 512, ties at 1024 x 1024, loses at 2048 x 2048)"),
     "strided_fwd_3x3": ("1", "host", "forward pass of a strided, unpadded layer (NIN's stem) as space to depth + a stride-1 3x3 convolution over sites (conv_x3w)"),
     "strided_bwd_3x3": ("1", "host", "backward-data of a strided, unpadded layer (NIN's 11x11 / 4 stem) as a stride-1 3x3 convolution over the output sites + depth to space"),
     # ---- fusions (engine.py)
