@@ -55,9 +55,22 @@ __global__ void __launch_bounds__(256, 4) conv1x1_x3_kernel(ConvArgs p, const fl
     const int j = lane & 31, half = lane >> 5;
     const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
     const int n = blockIdx.z / ksplit, split = blockIdx.z - n * ksplit;
-    const int co0 = blockIdx.y * P1_COT;
     const int64_t HW = (int64_t)p.H * p.W;
-    const int64_t pix0 = (int64_t)blockIdx.x * P1_PX;
+    // Tile order (round 5): with p.tiles_x = items per XCD the (pixel tile, channel tile) items - channel tiles of one pixel tile next to
+    // each other - are dealt so that XCD k (workgroup ids = k mod 8) walks the k-th contiguous band of the list, its CUs side by side: the
+    // channel tiles of a pixel tile share its activations in that XCD's L2, neighbouring CUs read neighbouring row segments of the same
+    // planes at the same time (dispatch order - p.tiles_x = 0: grid (pixel tiles, channel tiles) - reads the same bytes at a lower rate:
+    // tools/mfma_probe/stage_bw.hip, conv_few_mfma.hip).
+    int ptile = blockIdx.x, cot = blockIdx.y;
+    if (p.tiles_x > 0) {
+        const int ncot = (p.Cout + P1_COT - 1) / P1_COT;
+        const int item = (int)(blockIdx.x & 7) * p.tiles_x + (int)(blockIdx.x >> 3);
+        ptile = item / ncot;
+        cot = item - ptile * ncot;
+        if ((int64_t)ptile * P1_PX >= HW) return;  // (whole workgroup)
+    }
+    const int co0 = cot * P1_COT;
+    const int64_t pix0 = (int64_t)ptile * P1_PX;
     const float* __restrict__ xin = p.x + (int64_t)n * p.Cin * HW;
     const float* __restrict__ wgt = p.w;
 
@@ -304,6 +317,12 @@ int conv1x1_x3_launch(const ConvArgs& a, const float* xshift, int n, hipStream_t
     const int ks = a.ws ? p1_choose_split(a, n) : 1;
     p.ksplit = ks;
     dim3 grid((unsigned)((hw + P1_PX - 1) / P1_PX), (unsigned)((a.Cout + P1_COT - 1) / P1_COT), (unsigned)(n * ks));
+    p.tiles_x = 0;
+    if (tuning("p1_order", 1) != 0) {
+        const int64_t items = (int64_t)grid.x * grid.y;
+        p.tiles_x = (int)((items + 7) / 8);
+        grid = dim3((unsigned)(8 * p.tiles_x), 1, (unsigned)(n * ks));
+    }
     const bool acc = ks == 1 && a.accumulate != 0, om = ks == 1 && a.omask != nullptr;
 #define MAUA_P1(ACC_, OM_)                                                                                                   \
     do {                                                                                                                     \

@@ -69,6 +69,7 @@ FIELDS = {
     "gram_bwd_x3": ("1", "lib", "Gram backward in fp16x3 (0: fp32 MFMA)"),
     "gram_t128": ("1", "lib", "128 x 128 two-role Gram blocks: 0 never, 1 whole 64-pixel stages, 2 ragged maps too"),
     "gram_t128_min_hw": ("1024", "lib", "128 x 128 Gram blocks from this many pixels"),
+    "p1_order": ("1", "lib", "conv1x1_x3: (pixel tile, channel tile) items in XCD bands, channel tiles adjacent (0: dispatch order)"),
     "lbfgs_vec": ("1", "lib", "lbfgs: 16-byte loads in the history sweeps"),
     "lbfgs_tri": ("1", "lib", "lbfgs: the triangular form of the coefficient kernel"),
 }
