@@ -256,29 +256,6 @@ pool3s2_max_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x
     }
 }
 
-// 3x3 stride-2 max pooling (NIN's ceil-mode pools, reference models.py:77-80), forward: one thread per window, grid = (ceil(OW / 64), OH,
-// planes) - no index divisions (the generic kernel spends more on its 64-bit divisions than on its nine loads), a window's three rows
-// requested together; window_argmax's scan order and NaN rule (columns / rows beyond the plane - ceil mode - are skipped).
-__global__ void __launch_bounds__(64)
-pool3s2_max_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int OW) {
-    const int ox = blockIdx.x * 64 + threadIdx.x, oy = blockIdx.y;
-    if (ox >= OW) return;
-    const float* p = x + ((int64_t)blockIdx.z * H + 2 * oy) * W + 2 * ox;
-    const int nx = min(3, W - 2 * ox), ny = min(3, H - 2 * oy);
-    float v[3][3];
-#pragma unroll
-    for (int yy = 0; yy < 3; ++yy)
-#pragma unroll
-        for (int xx = 0; xx < 3; ++xx) v[yy][xx] = (yy < ny && xx < nx) ? p[yy * W + xx] : 0.f;
-    float m = v[0][0];
-#pragma unroll
-    for (int yy = 0; yy < 3; ++yy)
-#pragma unroll
-        for (int xx = 0; xx < 3; ++xx)
-            if (yy < ny && xx < nx && (v[yy][xx] > m || v[yy][xx] != v[yy][xx])) m = v[yy][xx];
-    y[((int64_t)blockIdx.z * gridDim.y + oy) * OW + ox] = m;
-}
-
 // 2x2 stride-2 max pooling on even-sized planes (every VGG pool): one thread per window, 8-byte accesses, no divisions.
 // grid = (ceil(OW/256), OH, planes).  Same tie rule as window_argmax: scan order (0,0),(0,1),(1,0),(1,1), first max wins.
 __global__ void __launch_bounds__(256)
@@ -580,10 +557,6 @@ int maua_pool2d_fwd(const float* x, float* y, int n, int c, int h, int w, int k,
     if (mode == 0 && k == 2 && stride == 2 && h % 2 == 0 && w % 2 == 0 && (int64_t)n * c <= 65535 && oh <= 65535) {
         hipLaunchKernelGGL(pool2x2_fwd_kernel, dim3((ow + 255) / 256, oh, n * c), dim3(256), 0, (hipStream_t)stream, x, y, w, ow);
         return check_launch("pool2x2_fwd_kernel");
-    }
-    if (mode == 0 && k == 3 && stride == 2 && (int64_t)n * c <= 65535 && oh <= 65535) {
-        hipLaunchKernelGGL(pool3s2_max_fwd_kernel, dim3((ow + 63) / 64, oh, n * c), dim3(64), 0, (hipStream_t)stream, x, y, h, w, ow);
-        return check_launch("pool3s2_max_fwd_kernel");
     }
     const int64_t total = (int64_t)n * c * oh * ow;
     hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, (int64_t)n * c, h, w,
