@@ -158,7 +158,7 @@ def accuracy_probe():
 
 
 def pmc_traffic(prefix):
-    """HBM-side bytes per launch of the dominant kernel from the committed PMC pass (profiles/pmc_r02_traffic.json, written
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC pass (profiles/pmc_r0N_traffic.json, the newest; written
     by tools/pmc_summary.py from separate `rocprofv3 --pmc` runs of this same command).  Reads: request counters x 64 B,
     doubled as MI355X_MICROARCH.md prescribes for gfx950 (our own calibration, profiles/pmc_r01_calibration.json: x2.0
     for 16 B/lane streams, x1.2-1.6 for 4 B/lane patterns, so this is an upper bound); writes are exact."""
@@ -184,16 +184,18 @@ def pmc_traffic(prefix):
 
 def pmc_traffic_lbfgs():
     """Memory-side bytes of one maua_lbfgs_iterate at full history (its five launches added up) from the committed PMC pass of
-    `bench.py --model nin` (profiles/pmc_r03_traffic_nin.json: tools/profile_round.sh, the last four launches of each kernel)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_r03_traffic_nin.json")
-    if not os.path.exists(path):
+    `bench.py --model nin` (profiles/pmc_r0N_traffic_nin.json, the newest: tools/profile_round.sh, the last four launches of each kernel)."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    path = next((os.path.join(here, f) for f in ("pmc_r05_traffic_nin.json", "pmc_r04_traffic_nin.json", "pmc_r03_traffic_nin.json")
+                 if os.path.exists(os.path.join(here, f))), None)
+    if path is None:
         return None
     with open(path) as f:
         kernels = json.load(f)["kernels"]
     total = sum(2 * e["read_bytes_raw"] + e["write_bytes_raw"] for name, e in kernels.items() if name.startswith(("maua::lbfgs_pair", "maua::lbfgs_finish_dots", "maua::lbfgs_coeffs", "maua::lbfgs_combine")) and "read_bytes_raw" in e)
     if not total:
         return None
-    return {"bytes": round(total), "note": "per update (the five launches), from profiles/pmc_r03_traffic_nin.json (a separate rocprofv3 --pmc pass of "
+    return {"bytes": round(total), "note": f"per update (the five launches), from profiles/{os.path.basename(path)} (a separate rocprofv3 --pmc pass of "
                                            "this command, last four launches of each kernel = full history): 2 x TCC_EA0_RDREQ x 64 B + write requests"}
 
 
