@@ -344,3 +344,21 @@ def test_plan_library_fields_reach_the_library(monkeypatch):
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "maua-style_amd", "csrc")
     for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp")):
         assert "getenv(" not in open(f).read().replace("`getenv`", ""), f
+
+
+def test_integration_md_lists_exactly_the_planner_fields():
+    """INTEGRATION.md's planner table is generated from plan.FIELDS (tools/update_plan_table.py): a field added without re-running the tool,
+    or a default changed, fails here."""
+    import re
+    import plan
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    head = "| field | default | read by | decides |\n|---|---|---|---|\n"
+    body = text[text.index(head) + len(head):]
+    body = body[:body.index("\n\n")]
+    rows = [re.match(r"\| `([a-z0-9_]+)` \| `([^`]*)` \| (host|library) \|", line) for line in body.splitlines()]
+    assert all(rows), [line for line, m in zip(body.splitlines(), rows) if not m]
+    listed = {m.group(1): (m.group(2), m.group(3)) for m in rows}
+    want = {k: (d, "library" if who == "lib" else "host") for k, (d, who, _) in plan.FIELDS.items()}
+    assert listed == want
+    for var in plan.ENV_VARS:
+        assert f"`{var}`" in text, var
