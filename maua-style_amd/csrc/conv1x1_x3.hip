@@ -12,6 +12,7 @@
 // conflict-free for b128.  Without the tap reuse of a 3x3 filter this is a bandwidth / staging-bound kernel (2 MFMA
 // steps per 16 staged values per thread); what it buys is the fp32 matrix cores' 16x lower rate out of the way.
 
+// hipcc-flags: -Xclang -target-feature -Xclang -packed-fp32-ops
 #include "common.hpp"
 
 namespace maua {

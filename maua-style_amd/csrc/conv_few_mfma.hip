@@ -17,6 +17,7 @@
 // T[27][(ROWS + 2) x 64] floats, then every output pixel adds its nine values per channel in tap order.  Gradient pixels outside the image
 // are read as 0 through the buffer descriptor's range check.  Filters: 12 fragments of 16 bytes per lane (bank packed once per weight set),
 // in registers for the wave's life.
+// hipcc-flags: -Xclang -target-feature -Xclang -packed-fp32-ops
 #include <hip/hip_runtime.h>
 
 #include "common.hpp"

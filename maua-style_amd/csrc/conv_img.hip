@@ -12,6 +12,7 @@
 //                image (12 MB at 1024 x 1024: L2-resident, neighbouring lanes read neighbouring pixels) and splits them itself;
 //   bias: the first free pair of the padded K carries it (filter value = bias, pixel value = 1): added exactly by the matrix unit;
 //   a wave walks blocks of 32 pixels of one row in a grid-stride loop; ReLU in registers, 128-byte row segments out.
+// hipcc-flags: -Xclang -target-feature -Xclang -packed-fp32-ops
 #include <hip/hip_runtime.h>
 
 #include "common.hpp"

@@ -7,6 +7,7 @@
 // Workgroup = 64 output channels x (4 rows x 32 columns), wave = one output row, lane = one column; a K = 16 MFMA step takes
 // two taps x 8 channels (lane half h takes tap 2 s + h), the odd last tap runs alone as a K = 8 step.
 // LDS: patch [part][(4 + KS - 1) x (32 + KS - 1) positions][8 ch] + filters [tap][part][co][8 ch].
+// hipcc-flags: -Xclang -target-feature -Xclang -packed-fp32-ops
 #include "common.hpp"
 
 namespace maua {

@@ -11,6 +11,7 @@
 //   * branch-free staging: out-of-image / out-of-range elements load from a clamped address and are zeroed by a
 //     select, so the 12 (+12 mask) + 20 global loads of a chunk issue back to back;
 //   * KC = 8 input channels per chunk for every layer (conv1_1's 3 channels are zero-padded inside LDS only).
+// hipcc-flags: -Xclang -target-feature -Xclang -packed-fp32-ops
 #include <stdlib.h>
 
 #include "common.hpp"

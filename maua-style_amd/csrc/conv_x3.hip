@@ -21,6 +21,7 @@
 // order, deterministic split-K.  The fp32 master accumulator is always present here (it is where the per-chunk scales
 // meet), so one variant serves every channel count (conv1_1's three channels are a single, partly empty chunk).
 
+// hipcc-flags: -Xclang -target-feature -Xclang -packed-fp32-ops
 #include "common.hpp"
 
 namespace maua {

@@ -16,7 +16,7 @@
 //   * the Gram backward of a style loss on the layer's output-side map (conv_x3w.hip's fused form, D . F as one-tap chunks) runs
 //     between an item's last chunk and the next item's first, from registers only.
 // Arithmetic, LDS layout, chunk pipeline and filter banks are conv_x3q.hip's: a one-pass launch gives the same bits.
-// hipcc-flags: -fno-slp-vectorize
+// hipcc-flags: -fno-slp-vectorize -Xclang -target-feature -Xclang -packed-fp32-ops
 #include <stdlib.h>
 
 #include <type_traits>

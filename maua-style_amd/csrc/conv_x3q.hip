@@ -29,7 +29,7 @@
 //
 // LDS (150 KiB): patch [part][octet 4][pos 18 x 34 (+12)][8 ch] = 79,872 B (octet planes 256-byte aligned: the 16x16x32 operand
 // read - lane = (octet, pixel) - is bank-conflict free), filters [tap][part][octet 4][co 64][8 ch] = 73,728 B.
-// hipcc-flags: -fno-slp-vectorize
+// hipcc-flags: -fno-slp-vectorize -Xclang -target-feature -Xclang -packed-fp32-ops
 #include <stdlib.h>
 
 #include <type_traits>

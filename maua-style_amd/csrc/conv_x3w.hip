@@ -21,6 +21,7 @@
 // xh*wh on v_mfma_f32_32x32x16_f16, per-chunk un-scaled fold into fp32 masters.  The scale now covers 16 channels.
 //
 // LDS per workgroup: patch [part][octet][pos 10x34 (+4)][8 ch] = 22,016 B, filters [tap][part][octet][co 64][8 ch] = 36,864 B.
+// hipcc-flags: -Xclang -target-feature -Xclang -packed-fp32-ops
 #include <stdlib.h>
 
 #include "common.hpp"

@@ -17,6 +17,7 @@
 // (no VGPRs); activations are split while they are staged (v_cvt_pk_bf16_f32 + subtract).
 // The ReLU mask of a backward-data pass is NOT applied here while staging; it is applied by the producer of the
 // gradient (`omask` in this kernel's epilogue, the pooling backward, the loss kernels).
+// hipcc-flags: -Xclang -target-feature -Xclang -packed-fp32-ops
 #include <stdlib.h>
 
 #include "common.hpp"

@@ -5,6 +5,7 @@
 // Forward: the (C/64)(C/64+1)/2 upper-triangular 64x64 tiles are split along HW over `ksplit` workgroups each
 // (split-K); every workgroup writes its partial tile to a slab and a second kernel adds the slabs in index order,
 // scales, and mirrors the result - a deterministic reduction without float atomics.
+// hipcc-flags: -Xclang -target-feature -Xclang -packed-fp32-ops
 #include <stdlib.h>
 
 #include "common.hpp"

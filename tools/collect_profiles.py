@@ -42,7 +42,7 @@ for a, b in (("sizes_lbfgs.jsonl", f"bench_r{rr}_sizes_lbfgs.jsonl"), ("sizes_ad
              ("launches_graph_nin.txt", f"probe_r{rr}_launch_table_nin_graph.txt"), ("graph_host_cost.txt", f"probe_r{rr}_graph_host_cost.txt"),
              ("check_x3p.txt", f"probe_r{rr}_x3p_vs_x3q_x3w.txt"),
              ("clock_x3p_conv1_2.txt", f"probe_r{rr}_clock_x3p_conv1_2.txt"), ("soak.txt", f"probe_r{rr}_soak.txt"),
-             ("stage_bw.txt", f"probe_r{rr}_stage_bw.txt"), ("gram128_zero_lanes.txt", f"probe_r{rr}_gram128_zero_lanes.txt")):
+             ("stage_bw.txt", f"probe_r{rr}_stage_bw.txt"), ("gram128_zero_lanes.txt", f"probe_r{rr}_gram128_zero_lanes_matrix.txt")):
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(dst, b))
 if os.path.exists(os.path.join(src, "bench_nin.json")):

@@ -11,6 +11,18 @@
 //   -DNOP_BEFORE_FOLD  128 cycles of s_nop in front of the fold of the accumulators into the masters
 //   -DNOP_LAST         ... only behind the last chain of a k-step
 //   -DNOP_BEFORE_BARRIER  128 cycles of s_nop between a stage's last MFMA and the barrier that frees the planes
+//   -DINTERLEAVE       the twelve MFMAs of a k-step product-major (dependent MFMAs never adjacent in program order; implies the (1, 0) block is computed)
+//   -DREVERSE          (with INTERLEAVE) the four MFMAs of a group in the opposite order
+//   -DAGPR_ACC         (with INTERLEAVE) the MFMAs as inline asm with the accumulators in AccVGPRs
+//   -DSCALAR_FOLD      the fold of the accumulators into the masters as v_fma_f32 (inline asm) instead of the compiler's v_pk_fma_f32
+//   -DPK_ASM_FOLD      the fold as inline-asm v_pk_fma_f32 on register pairs (the instruction the compiler picks, pinned like SCALAR_FOLD's)
+//   -DPK_COPY_FIRST    (with PK_ASM_FOLD) the packed FMA reads copies of the accumulator registers made by v_mov_b32, not the MFMA's own destination registers
+//   -DPK_MUL_ADD       (with PK_ASM_FOLD) v_pk_mul_f32 + v_pk_add_f32 instead of v_pk_fma_f32
+//   -DGAP=n            (with INTERLEAVE) s_sleep n (64 n cycles) between the groups of four MFMAs
+//   -DPARTNER=1|2|3    the CU's SECOND workgroup is not another instance of the kernel but a stand-in that only issues MFMAs (1), only LDS
+//                      reads and writes (2) or only global loads (3) for about as long: workgroups 256-511, 768-1023, ... of a 1-D grid (dealt
+//                      onto the CUs of workgroups 0-255, 512-767, ... as their second workgroup) run the stand-in, the others the kernel;
+//                      4 = control: the same 1-D grid with the kernel in every slot
 // hipcc --offload-arch=gfx950 -O3 -o gram128_zero_lanes gram128_zero_lanes.hip ; ./gram128_zero_lanes [C] [HW] [launches]
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -188,6 +200,37 @@ __device__ __forceinline__ void gram_x3_partial128_body(const float* __restrict_
                         bh[a] = *reinterpret_cast<const g16x8*>(smem + b_off + a * 32 * GXROW + q * 32);
                         bl[a] = *reinterpret_cast<const g16x8*>(smem + GX128_PLANE + b_off + a * 32 * GXROW + q * 32);
                     }
+#ifdef INTERLEAVE
+                    // the same twelve MFMAs product-major: the three dependent MFMAs of a block are never adjacent in program order
+#pragma unroll
+                    for (int prod = 0; prod < 3; ++prod) {
+#ifdef REVERSE  // the group's four MFMAs in the opposite order: block (0, 0) is issued last
+#pragma unroll
+                        for (int a = 1; a >= 0; --a)
+#pragma unroll
+                            for (int b = 1; b >= 0; --b)
+                                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(prod == 0 ? al[a] : ah[a], prod == 1 ? bl[b] : bh[b], acc[a][b], 0, 0, 0);
+#elif defined(AGPR_ACC)  // the accumulators in AccVGPRs (the upper half of the wave's register file) instead of v0 - v63
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int b = 0; b < 2; ++b)
+                                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[a][b]) : "v"(prod == 0 ? al[a] : ah[a]), "v"(prod == 1 ? bl[b] : bh[b]));
+#else
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int b = 0; b < 2; ++b)
+                                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(prod == 0 ? al[a] : ah[a], prod == 1 ? bl[b] : bh[b], acc[a][b], 0, 0, 0);
+#endif
+#ifdef GAP
+                        // GAP x 64 idle cycles (s_sleep) between the groups: a dependent MFMA is then at least that far behind its producer's issue
+                        __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_s_sleep(GAP);  // 64 GAP cycles
+                        __builtin_amdgcn_sched_barrier(0);
+#endif
+                    }
+#else
 #pragma unroll
                     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -209,6 +252,7 @@ __device__ __forceinline__ void gram_x3_partial128_body(const float* __restrict_
                             asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 #endif
                         }
+#endif
 #ifdef NOP_LAST
                     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 #endif
@@ -233,8 +277,31 @@ __device__ __forceinline__ void gram_x3_partial128_body(const float* __restrict_
                     for (int b = 0; b < 2; ++b) {
                         const float sc = s_row[a] * s_col[b];
 #pragma unroll
+#ifdef PK_ASM_FOLD  // the compiler's instruction, written out: v_pk_fma_f32 on register pairs (is it the instruction or the schedule?)
+                        for (int r = 0; r < 16; r += 2) {
+                            g32x2 m2 = {master[a][b][r], master[a][b][r + 1]};
+                            g32x2 a2 = {acc[a][b][r], acc[a][b][r + 1]};
+                            const g32x2 s2 = {sc, sc};
+#ifdef PK_COPY_FIRST  // the packed FMA reads COPIES of the accumulator registers made by two plain v_mov_b32
+                            asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(a2[0]), "=&v"(a2[1]) : "v"(acc[a][b][r]), "v"(acc[a][b][r + 1]));
+#endif
+#ifdef PK_MUL_ADD  // two packed instructions instead of the packed FMA (another rounding, equally repeatable)
+                            asm volatile("v_pk_mul_f32 %1, %1, %2\n\tv_pk_add_f32 %0, %0, %1" : "+v"(m2), "+v"(a2) : "v"(s2));
+#else
+                            asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(m2) : "v"(a2), "v"(s2));
+#endif
+                            master[a][b][r] = m2[0];
+                            master[a][b][r + 1] = m2[1];
+                            acc[a][b][r] = acc[a][b][r + 1] = 0.f;
+                        }
+                        if (false)
+#endif
                         for (int r = 0; r < 16; ++r) {
+#ifdef SCALAR_FOLD  // one v_fma_f32 per element: the compiler's form is v_pk_fma_f32 on register pairs
+                            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(master[a][b][r]) : "v"(acc[a][b][r]), "v"(sc));
+#else
                             master[a][b][r] = fmaf(acc[a][b][r], sc, master[a][b][r]);
+#endif
 #ifndef ZERO_BY_C
                             acc[a][b][r] = 0.f;
 #endif
@@ -262,15 +329,73 @@ __device__ __forceinline__ void gram_x3_partial128_body(const float* __restrict_
 #endif
 }
 
+#ifdef PARTNER
+__device__ unsigned long long g_sink;
+__device__ __noinline__ void partner(const float* __restrict__ f, int iters) {
+    extern __shared__ __attribute__((aligned(16))) float lds_f32[];
+    const int lane = threadIdx.x & 63;
+#if PARTNER == 4
+    (void)lane;
+    (void)iters;
+#elif PARTNER == 1
+    f32x16 c[4] = {};
+    g16x8 a, b;
+    for (int k = 0; k < 8; ++k) a[k] = b[k] = (_Float16)(1 + (lane & 1));
+    for (int i = 0; i < iters; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c[j], 0, 0, 0);
+    if (c[0][0] + c[1][1] + c[2][2] + c[3][3] == 12345.f) g_sink = 1;
+#elif PARTNER == 2
+    f32x4* p = reinterpret_cast<f32x4*>(lds_f32) + threadIdx.x;
+    f32x4 v = {1.f, 2.f, 3.f, 4.f};
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            p[j * 256] = v;
+            v += p[((j + 3) & 7) * 256];
+        }
+    }
+    if (v.x == 12345.f) g_sink = 1;
+#else
+    float acc = 0.f;
+    const float* q = f + threadIdx.x;
+    for (int i = 0; i < iters; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += q[(size_t)((i * 8 + j) & 4095) * 256];
+    if (acc == 12345.f) g_sink = 1;
+#endif
+}
+#endif
+
 __global__ void __launch_bounds__(256, WG_PER_CU)
-gram128_kernel(const float* __restrict__ f, float* __restrict__ partial, int C, int64_t HW, int ksplit, int64_t chunk) {
+gram128_kernel(const float* __restrict__ f, float* __restrict__ partial, int C, int64_t HW, int ksplit, int64_t chunk, int pairs, int partner_iters) {
+#ifdef PARTNER
+    const int g = blockIdx.x >> 8;
+#if PARTNER == 4  // control: the 1-D grid with the kernel in both slots
+    {
+        const int id4 = blockIdx.x;
+        if (id4 >= pairs * ksplit) return;
+        gram_x3_partial128_body(f, nullptr, partial, C, HW, ksplit, chunk, id4 % pairs, id4 / pairs);
+        return;
+    }
+#endif
+    if (g & 1) {
+        partner(f, partner_iters);
+        return;
+    }
+    const int id = (g >> 1) * 256 + (blockIdx.x & 255);
+    if (id >= pairs * ksplit) return;
+    gram_x3_partial128_body(f, nullptr, partial, C, HW, ksplit, chunk, id % pairs, id / pairs);
+#else
     gram_x3_partial128_body(f, nullptr, partial, C, HW, ksplit, chunk, blockIdx.x, blockIdx.y);
+#endif
 }
 
 int main(int argc, char** argv) {
     const int C = argc > 1 ? atoi(argv[1]) : 256;
     const int64_t HW = argc > 2 ? atoll(argv[2]) : 65536;
     const int launches = argc > 3 ? atoi(argv[3]) : 300;
+    const int partner_iters = argc > 4 ? atoi(argv[4]) : 600;
     const int ntile128 = (C + 127) / 128, ntile64 = (C + 63) / 64;
     const int pairs128 = ntile128 * (ntile128 + 1) / 2, pairs64 = ntile64 * (ntile64 + 1) / 2;
     int ksplit = 512 / pairs128;
@@ -294,9 +419,25 @@ int main(int argc, char** argv) {
     long bad_launches = 0, bad_values = 0;
     for (int it = 0; it <= launches; ++it) {
         CK(hipMemset(slab, 0xff, slab_n * 4));  // NaN: an element nobody wrote shows
-        hipLaunchKernelGGL(gram128_kernel, dim3(pairs128, ksplit), dim3(256), GX128_LDS, 0, f, slab, C, HW, ksplit, chunk);
+#ifdef PARTNER
+        hipLaunchKernelGGL(gram128_kernel, dim3(2 * ((pairs128 * ksplit + 255) / 256) * 256), dim3(256), GX128_LDS, 0, f, slab, C, HW, ksplit, chunk, pairs128, partner_iters);
+#else
+        hipLaunchKernelGGL(gram128_kernel, dim3(pairs128, ksplit), dim3(256), GX128_LDS, 0, f, slab, C, HW, ksplit, chunk, pairs128, partner_iters);
+#endif
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(it == 0 ? a.data() : b.data(), slab, slab_n * 4, hipMemcpyDeviceToHost));
+        if (it < 6 && getenv("SUMS")) {  // a fingerprint of the first launches (is launch 0 the odd one? is a variant's result the base result?)
+            const std::vector<float>& v = it == 0 ? a : b;
+            double sum = 0.0;
+            unsigned long long x = 0;
+            for (size_t i = 0; i < slab_n; ++i) {
+                sum += v[i];
+                unsigned u;
+                memcpy(&u, &v[i], 4);
+                x = x * 1099511628211ull + u;
+            }
+            printf("  launch %d: sum %.9g hash %016llx\n", it, sum, x);
+        }
         if (it == 0) continue;
         long bad = 0;
         for (size_t i = 0; i < slab_n; ++i)
@@ -320,6 +461,9 @@ int main(int argc, char** argv) {
             bad_values += bad;
         }
     }
+#ifdef PARTNER
+    printf("second workgroup of a CU = stand-in %d (1 MFMA only, 2 LDS only, 3 global loads only), %d iterations: ", PARTNER, partner_iters);
+#endif
     printf("C %d HW %lld ksplit %d, %d workgroup(s) per CU: %ld of %d launches differ from the first (%ld values)\n", C, (long long)HW, ksplit, WG_PER_CU, bad_launches, launches, bad_values);
     return bad_launches ? 2 : 0;
 }

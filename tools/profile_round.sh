@@ -33,7 +33,8 @@ python tools/x3p_clock.py 64 64 1024 masked >> $O/clock_x3p_conv1_2.txt 2>&1
 python tools/x3p_clock.py 256 256 256 plain >> $O/clock_x3p_conv1_2.txt 2>&1
 python tools/soak_kernels.py 3000 > $O/soak.txt 2>&1
 (tools/mfma_probe/stage_bw 64 1024; tools/mfma_probe/stage_bw 128 512) > $O/stage_bw.txt 2>&1
-(tools/mfma_probe/gram128_zero_lanes_n0 512 16384 1500; tools/mfma_probe/gram128_zero_lanes_base 512 16384 1500; tools/mfma_probe/gram128_zero_lanes_one 512 16384 1500; tools/mfma_probe/mfma_src_war) > $O/gram128_zero_lanes.txt 2>&1
+# the reproducer of round 4's Gram fault in every build of probes_r05.md section 4 (tools/mfma_probe/build_zero_lanes.sh in the container first)
+(cd tools/mfma_probe; for b in n0 p4 p1 p2 p3 il g2 pad g2s pads n0s g2p padp g2pc padpc g2ma padma one g2one; do echo "== $b"; timeout 300 ./gram128_zero_lanes_$b 512 16384 2000 600 | tail -1; done; ./mfma_src_war) > $O/gram128_zero_lanes.txt 2>&1
 python tools/x3w_clock.py 512 512 128 > $O/clock_conv4_2.txt 2>&1
 python tools/x3w_clock.py 64 64 1024 > $O/clock_conv1_2.txt 2>&1
 python tools/bench_x3w.py 1024 5 10 > $O/x3_vs_x3w.txt 2>&1
