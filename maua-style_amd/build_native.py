@@ -21,8 +21,11 @@ def _sources():
 
 
 def _file_flags(src):
-    """Extra compiler flags a source asks for in a `// hipcc-flags: ...` line among its first 60 lines (conv_x3q.hip: no SLP
-    vectorisation - packed fp32 instructions beside MFMAs cost more issue time than the two scalar ones they replace)."""
+    """Extra compiler flags a source asks for in a `// hipcc-flags: ...` line among its first 60 lines.  Every source with an MFMA kernel
+    turns the packed-fp32 target feature off (`-Xclang -target-feature -Xclang -packed-fp32-ops`): a v_pk_fma_f32 / v_pk_mul_f32 /
+    v_pk_add_f32 can lose its low destination register in lanes 48-63 while another wave of the SIMD issues MFMAs (profiles/probes_r05.md
+    section 4: the root cause of round 4's Gram fault), and the scalar forms issue faster beside MFMAs anyway (+0.8 % at 1024 x 1024);
+    tests/test_abi.py checks the built library for kernels with both kinds of instruction."""
     with open(src) as f:
         for _, line in zip(range(60), f):
             if line.startswith("// hipcc-flags:"):
