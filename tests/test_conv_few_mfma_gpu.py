@@ -38,6 +38,8 @@ def test_few_mfma_against_fp64(hip, n, cin, h, w, tile):
     again = torch.empty_like(out)
     hip.conv3x3_few_mfma(gy, bank, cin, out=again, tile=tile)
     assert torch.equal(out, again)
+    if tile:  # the tile height decides which workgroup computes a pixel's 27 sums, not how: same bits as the library's choice
+        assert torch.equal(out, hip.conv3x3_few_mfma(gy, bank, cin, tile=0))
 
 
 def test_few_mfma_wide_dynamic_range_and_zero_gradient(hip):
