@@ -494,14 +494,6 @@ def test_conv3x3_x3_forward_and_backward(hip, cin, cout, H, W, pad):
     torch.cuda.synchronize()
     assert rel_l2(gx2.cpu(), refb + base.double()) <= 2e-6
     assert torch.equal(gx2, gx3)
-    # the order in which the workgroups walk the (pixel tile, channel tile) items (round 5: XCD bands; planner field p1_order) changes no bit
-    L = hip.lib()
-    try:
-        assert L.maua_set_tuning(b"p1_order", 0.0) == 0
-        y_plain = hip.conv1x1_x3(dev(x), dev(w), dev(b), relu=True)
-    finally:
-        L.maua_set_tuning(b"p1_order", 1.0)
-    assert torch.equal(y, y_plain)
 
 
 @pytest.mark.parametrize("cin,cout,H,W", [(512, 512, 16, 16), (256, 256, 33, 40), (512, 64, 8, 8)])
@@ -583,6 +575,14 @@ def test_conv1x1_x3_forward_and_backward(hip, cin, cout, H, W):
     torch.cuda.synchronize()
     assert rel_l2(gx2.cpu(), refb + base.double()) <= 2e-6
     assert torch.equal(gx2, gx3)
+    # the order in which the workgroups walk the (pixel tile, channel tile) items (round 5: XCD bands; planner field p1_order) changes no bit
+    L = hip.lib()
+    try:
+        assert L.maua_set_tuning(b"p1_order", 0.0) == 0
+        y_plain = hip.conv1x1_x3(dev(x), dev(w), dev(b), relu=True)
+    finally:
+        L.maua_set_tuning(b"p1_order", 1.0)
+    assert torch.equal(y, y_plain)
 
 
 @pytest.mark.parametrize("cin,cout,hw", [(128, 128, 4096), (100, 100, 777), (512, 512, 1024)])
