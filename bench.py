@@ -107,15 +107,25 @@ def cpu_baseline(S, optimizer, iters=5, repeats=3, model="vgg19"):
     shape = init.shape
     sweep = {}
     best = (float("inf"), 1)
-    for k in sorted({min(nproc, c) for c in (4, 8, 16, 32, 64, 128, nproc)}):
+    counts, c = [], 1
+    while c < nproc:  # {1, 2, 4, ..., nproc}
+        counts.append(c)
+        c *= 2
+    counts.append(nproc)
+    budget_s = 150.0  # the whole sweep stays bounded: a one-thread evaluation at 1024 x 1024 is ~40 s, which is affordable once
+    t_sweep = time.perf_counter()
+    for k in counts:
         torch.set_num_threads(k)
         t0 = time.perf_counter()
         net.feval(init)
         dt = time.perf_counter() - t0
         sweep[k] = round(dt, 3)
         best = min(best, (dt, k))
-        if dt > 2.0 * best[0]:
-            break  # well past the optimum: larger counts only oversubscribe further
+        if k > best[1] and dt > 2.0 * best[0]:
+            break  # well past the optimum: larger counts only oversubscribe further (the remaining counts are recorded as not run)
+        if time.perf_counter() - t_sweep > budget_s:
+            break
+    not_run = [k for k in counts if k not in sweep]
     torch.set_num_threads(best[1])
 
     def closure(x):
@@ -131,6 +141,7 @@ def cpu_baseline(S, optimizer, iters=5, repeats=3, model="vgg19"):
     dt = statistics.median(times)
     return {"value": round(iters / dt, 5), "unit": "iterations/s", "cores": best[1], "threads_used": best[1], "nproc": nproc,
             "cpu_model": cpu_model, "model": model, "kind": "port", "thread_sweep_s_per_feval": sweep,
+            "thread_counts_not_run": not_run,  # (beyond twice the best time, or the sweep's 150 s budget)
             "sample": f"{iters} L-BFGS iterations of the CPU oracle at {S}x{S} (the benchmarked size, no scaling), median of "
                       f"{repeats} runs: {dt:.2f} s on {best[1]} threads ({nproc} logical CPUs)"}
 
@@ -319,6 +330,17 @@ def finish_exact_split_child(proc):
                     "significand bits, six MFMAs per product block); measured in a fresh child process after the headline"}
 
 
+def lbfgs_still_moving(opt, expect_iters, what):
+    """{n_iter, stopped, history_len} of the optimiser right behind a timed region - and the run FAILS if a stop rule fired inside it:
+    a raised stop flag (g . d > -tolerance, max |g|, ...) makes lbfgs_pair_dots and the kernels behind it return early (lbfgs.hip), which
+    would inflate iterations/s.  The line must prove by itself that every timed iteration did its whole work."""
+    st = opt.state.status()
+    out = {"n_iter": int(st["n_iter"]), "stopped": bool(st["stopped"]), "history_len": int(st["history_len"]), "expected_n_iter": int(expect_iters)}
+    if out["stopped"] or out["n_iter"] != out["expected_n_iter"]:
+        raise RuntimeError(f"bench.py: the L-BFGS optimiser stopped moving inside the timed region of {what}: {out} - the measured rate is not valid")
+    return out
+
+
 def steady_rate(size, steps, optimizer="lbfgs", history=100, warmup=5):
     """iterations/s of one more single-image job at another size on this rank's GPU (the 512x512 figure north_star asks for
     next to the 1024x1024 headline): same construction as the main workload, history prefilled, graph replay."""
@@ -355,6 +377,7 @@ def steady_rate(size, steps, optimizer="lbfgs", history=100, warmup=5):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     _dist.barrier()
+    moving = lbfgs_still_moving(opt, history + warmup + steps, f"the {size}x{size} figure") if optimizer == "lbfgs" else None
     work = algorithmic_work(size, history)
     import dist
     world = dist.group_size()
@@ -362,6 +385,8 @@ def steady_rate(size, steps, optimizer="lbfgs", history=100, warmup=5):
     res = {"image_size": size, "optimizer": optimizer, "steps": steps, "n_gpus": world,
            "iterations_per_s": round(world * steps / dt_all, 2), "ms_per_step": round(dt_all / steps * 1e3, 4),
            "model_tflops": round(world * work["flops"] / (dt_all / steps) / 1e12, 2)}
+    if moving is not None:
+        res["lbfgs"] = moving
     conv = opt.engine is not None and _conv_roofline_of(opt, steps)
     if conv:
         res["conv_roofline_frac"] = conv
@@ -485,6 +510,8 @@ def main():
     torch.cuda.synchronize()
     dist.barrier()
     mine = time.perf_counter() - t0
+    # (every rank checks its own optimiser: a stop flag raised inside the timed region voids the rate)
+    moving = lbfgs_still_moving(opt, prefill + a.warmup + a.steps, "the headline") if a.optimizer == "lbfgs" else None
     elapsed = dist.max_over_ranks(mine)
     per_rank = dist.gather_floats(a.steps / mine)  # iterations/s of every rank (rank order)
     # The same K-step region again, `--repeats` times (each bracketed like the headline one): its spread inside THIS run.
@@ -603,6 +630,7 @@ def main():
                                f"{' history ' + str(a.history) + ' (full)' if prefill else ''}, one image per GPU, "
                                "content 5 / style 100 / tv 1e-3, normalize_gradients, seeded synthetic weights and images",
                    "image_size": S, "optimizer": a.optimizer, "lbfgs_history_len": status.get("history_len"),
+                   "lbfgs": moving,  # {n_iter, stopped, ...} read right behind the timed region (the run fails if a stop rule fired in it)
                    "parallelism": f"frames x{world} (replicas, one broadcast, no per-iteration collective)",
                    "hip_graph": bool(a.hip_graph)},
         "rccl_ranks": dist.group_size(), "dist_backend": dist.backend_name(),

@@ -17,8 +17,10 @@
  *    asynchronously on it, nothing synchronises, so calls can be captured into a hipGraph;
  *  - return value: 0 = ok, <0 = invalid argument / unsupported shape (MAUA_E_*), >0 = hipError_t
  *    of the failed launch; maua_last_error() gives a thread-local message;
- *  - no process-wide mutable state: the message and the split-K batch hint (maua_set_split_batch_hint) are per host thread, so
- *    concurrent jobs on their own threads and streams do not interfere;
+ *  - per host thread: the error message and the split-K batch hint (maua_set_split_batch_hint), so concurrent jobs on their own
+ *    threads and streams do not interfere through them.  PROCESS-WIDE mutable state, exactly two setters: maua_set_tuning (the planner's
+ *    constants, set once when the host side loads the library) and maua_conv_x3p_set_max_groups (tests); neither changes a result bit,
+ *    both are read at launch time - set them before the first launch, not while another thread launches or captures;
  *  - reductions are fixed-order (no float atomics): reruns are bit-identical, like the reference
  *    at a fixed thread count.
  */
@@ -217,7 +219,7 @@ int maua_conv3x3_x3q_unpool(const float* pooled_x, const unsigned char* codes, i
  *   dmat_bank + dmat_inv_scale  the Gram backward D . F of the style loss on out_relu_mask = F goes along (maua_conv3x3_x3w_gram; the
  *                               bank is maua_conv_pack_dmat_x3w's);
  *   pool_codes                  y is the POOLED map and these its decision bytes (maua_conv3x3_x3w_relu_pool; needs relu, no mask).
- * Needs cin % 32 == 0, cout % 64 == 0, cout <= 1024, planes of at most 2^24 pixels and one image's output below 2 GiB
+ * Needs cin % 32 == 0, cout % 64 == 0, cout <= 512 (the bias table in LDS), planes of at most 2^24 pixels and one image's output below 2 GiB
  * (maua_conv_x3p_supported).  workspace as for maua_conv3x3_x3q (maua_conv_x3p_workspace_bytes; maua_conv_x3p_split = the K splits a
  * launch would use, 1 = one pass). */
 int maua_conv_x3p_supported(int cin, int h, int w, int cout, int pad);
@@ -227,7 +229,8 @@ size_t maua_conv_x3p_workspace_bytes(int n, int cin, int h, int w, int cout, int
  * tightly enough) to beat conv_x3w's finer tiles - the host side's routing rule, under the current batch hint; 0 otherwise. */
 int maua_conv_x3p_preferred(int n, int cin, int h, int w, int cout, int pad);
 /* Tests: the workgroups a launch may use (a multiple of 8 from 8 on; anything else restores one per CU = 256), so that small shapes walk
- * several items per workgroup.  Returns the previous value.  Process-wide; results do not depend on it (a tile's arithmetic is the same
+ * several items per workgroup.  Returns the previous OVERRIDE (0 = none: the tuning constant x3p_groups decides), so that passing the
+ * returned value back restores the state exactly.  Process-wide; results do not depend on it (a tile's arithmetic is the same
  * wherever it sits in a workgroup's list). */
 int maua_conv_x3p_set_max_groups(int groups);
 int maua_conv3x3_x3p(const float* x, const unsigned char* in_codes, int honour_relu_bit, const void* bank, float w_scale, const float* bias,

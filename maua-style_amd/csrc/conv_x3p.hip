@@ -706,7 +706,8 @@ __global__ void __launch_bounds__(XP_THREADS, 2) conv_x3p_kernel(ConvArgs p, X3p
     // before the NEXT chunk's tap 0 - this chunk keeps all nine taps in the accumulators (no fold at tap 5) - so the pieces spread over
     // the whole chunk, behind everything the chunk has to wait for: loads and LDS-DMA go out in steps 0-7 and 20-24, stores in steps
     // 8-16 and 25-31, and the waits count the stores issued since (memory operations return in issue order: `vmcnt(n)` = all but the n
-    // youngest are done), so no wait of the chunk's own pipeline waits for a store.
+    // youngest are done), so no wait of the chunk's own pipeline waits for a store.  (Masked form, OM: the pieces' mask loads interleave with
+    // the stores, so `vmcnt(ST1 / ST2)` does wait for the stores issued before the youngest mask loads - conservative, still correct.)
     auto chunk_body = [&](auto epi_tag, const Item& it, int chn, bool later, bool more, const Item& nx, int nch, const PatchSrc& rs) {
         constexpr bool EPI = decltype(epi_tag)::value;
         auto step = [&](int tap, int i, int next_tap, auto fresh, float inv, auto va, auto&& extra) {
@@ -1062,7 +1063,7 @@ size_t maua_conv_x3p_workspace_bytes(int n, int cin, int h, int w, int cout, int
 }
 
 int maua_conv_x3p_set_max_groups(int groups) {
-    const int before = x3p_max_groups();
+    const int before = g_xp_max_groups;  // the raw override (0 = none), so that save / restore is exact
     g_xp_max_groups = groups >= 8 ? groups / 8 * 8 : 0;
     return before;
 }

@@ -113,36 +113,51 @@ def broadcast_network(net, src=0, mid_job=False):
 
 
 class ReplicaWeights:
-    """vid_img rebuilds its loss network per image size from the same weight file; the replicas need ONE broadcast per job, not one per
-    size.  The first call broadcasts rank `src`'s parameters (start-up phase, short-timeout group) and keeps them, conv layer by conv
-    layer; later calls copy the kept tensors into the new network locally - no collective a rank that is a scale ahead or behind could
-    block on.  Only a later network with MORE conv layers than any before it (deeper loss layers at a later size) broadcasts again, and
-    then only on the long-timeout group."""
+    """vid_img rebuilds its loss network per image size; the replicas need ONE broadcast per MODEL and job, not one per size.  The kept
+    weights are keyed by the model (`key`: the caller passes what selects the checkpoint and the architecture - model file, pooling -; a
+    `--scaling_args` table may switch models between sizes, the reference's own config/scaling-img.json goes vgg19 -> prune -> nin).  The
+    first call for a key broadcasts rank `src`'s parameters and keeps them, conv layer by conv layer; later calls with that key copy the
+    kept tensors into the new network locally - no collective a rank that is a scale ahead or behind could block on.  A later network of the
+    same key with MORE conv layers (deeper loss layers at a later size) broadcasts its new tail only; one whose layer shapes do not match
+    the kept ones (the key did not tell two architectures apart) drops the entry and broadcasts whole again.  Every rank takes the same
+    branch: the decision depends on the key and the layer shapes only, which the ranks share.  The very first broadcast of a job runs on
+    the short-timeout start-up group, everything later on the long-timeout one.  Outside a process group `sync` does nothing."""
 
     def __init__(self):
-        self.kept = []  # [(weight, bias or None)] of the conv layers, in network order
+        self.kept = {}  # key -> [(weight, bias or None)] of the conv layers, in network order
+        self.calls = 0
 
     @staticmethod
     def _convs(net):
         import torch.nn as nn
         return [m for m in net.modules() if isinstance(m, nn.Conv2d)]
 
-    def sync(self, net, src=0):
+    @staticmethod
+    def _keep(convs):
+        return [(m.weight.data.clone(), None if m.bias is None else m.bias.data.clone()) for m in convs]
+
+    def sync(self, net, src=0, key=None):
+        if not (td.is_available() and td.is_initialized()):
+            return "single process"
+        first_of_job = self.calls == 0
+        self.calls += 1
+        group = None if first_of_job else _LONG_GROUP
         convs = self._convs(net)
-        if not self.kept:
-            broadcast_network(net, src=src)
-            self.kept = [(m.weight.data.clone(), None if m.bias is None else m.bias.data.clone()) for m in convs]
+        kept = self.kept.get(key)
+        n = 0 if kept is None else min(len(convs), len(kept))
+        if kept is not None and any(m.weight.shape != w.shape or (m.bias is None) != (b is None) for m, (w, b) in zip(convs[:n], kept[:n])):
+            kept = None  # another architecture under the same key: start over for it
+        if kept is None:
+            broadcast_tensors([p.data for p in net.parameters()], src, group=group)
+            self.kept[key] = self._keep(convs)
             return "broadcast"
-        n = min(len(convs), len(self.kept))
-        for m, (w, b) in zip(convs[:n], self.kept[:n]):
-            if m.weight.shape != w.shape:
-                raise RuntimeError("ReplicaWeights: the network changed its layers between image sizes")
+        for m, (w, b) in zip(convs[:n], kept[:n]):
             m.weight.data.copy_(w)
-            if b is not None and m.bias is not None:
+            if b is not None:
                 m.bias.data.copy_(b)
-        if len(convs) > n:  # deeper than anything broadcast so far: the new tail only
-            broadcast_tensors([t for m in convs[n:] for t in ([m.weight.data] + ([] if m.bias is None else [m.bias.data]))], src, group=_LONG_GROUP)
-            self.kept += [(m.weight.data.clone(), None if m.bias is None else m.bias.data.clone()) for m in convs[n:]]
+        if len(convs) > n:  # deeper than anything broadcast so far for this model: the new tail only
+            broadcast_tensors([t for m in convs[n:] for t in ([m.weight.data] + ([] if m.bias is None else [m.bias.data]))], src, group=group)
+            kept += self._keep(convs[n:])
             return "broadcast of the new tail"
         return "local copy"
 

@@ -912,25 +912,29 @@ class StyleEngine:
         self.graph.replay()
         return self.slots, self.total, self.gbuf[0]
 
-    def describe_routes(self, x):
+    def describe_routes(self, x, independent=None, batch_hint=None):
         """Which kernel every convolution launch of one evaluation at `x` takes, as planned and launched (one eager evaluation with
         models.ROUTE_LOG recording): a list of records in launch order - kernel family, pass, channels, plane, tile, K splits, and what
         rides along (mask, pool, unpool, gram).  The conv1_1 backward (64 -> 3: conv3x3_few_out) and NIN's non-3x3 layers are listed by
-        the generic entry points' names.  bench.py prints it as `routes`."""
-        self._prepare(x)
-        names = []
-        idx = 0
-        for s in self.steps:
-            if s.kind == "conv":
-                idx += 1
-                names.append(f"conv#{idx} {s.mod.in_channels}->{s.mod.out_channels} k{s.k}")
+        the generic entry points' names.  bench.py prints it as `routes`.
+        This IS an evaluation: it overwrites the loss slots, gradient buffers and ledger of the engine (call it when the last evaluation's
+        results are no longer needed); `independent` / `batch_hint`: what a frame-batch optimiser would set on the engine (they change K
+        splits and routes), restored afterwards.  Not re-entrant (one module-level log)."""
+        assert models_mod.ROUTE_LOG is None, "describe_routes: a recording is already running"
+        keep = (self.independent, self.batch_hint)
+        if independent is not None:
+            self.independent = bool(independent)
+        if batch_hint is not None:
+            self.batch_hint = int(batch_hint)
         models_mod.ROUTE_LOG = []
         try:
+            self._prepare(x)  # (the plan depends on both settings; the next evaluation re-plans if they were changed here)
             self._run(x)
             torch.cuda.synchronize()
             log = models_mod.ROUTE_LOG
         finally:
             models_mod.ROUTE_LOG = None
+            self.independent, self.batch_hint = keep
         return log
 
     def drop_graphs(self):

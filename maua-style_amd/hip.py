@@ -429,7 +429,8 @@ def conv_x3p_preferred(n, cin, h, w, cout, pad):
 
 
 def conv_x3p_set_max_groups(groups):
-    """Tests: workgroups a conv_x3p launch may use (multiple of 8; 0 restores one per CU); returns the previous value."""
+    """Tests: workgroups a conv_x3p launch may use (multiple of 8; 0 = no override: one per CU / the planner's x3p_groups); returns the
+    previous override (0 = none), so passing it back restores the state exactly."""
     return int(lib().maua_conv_x3p_set_max_groups(int(groups)))
 
 

@@ -88,9 +88,22 @@ ENV_VARS = {
     "MAUA_DIST_JOB_TIMEOUT_S": None,
     "MAUA_HOST_THREADS": None,
 }
+_FIELD_VAR = {field: var for var, field in ENV_VARS.items() if field is not None}
 _TOOL_VARS = {"MAUA_FUZZ_ASSUME_NO_GPU"}  # tools/fuzz_abi_host.py's own switch: not a setting of the product
 
 OVERRIDES = {}  # programmatic overrides (tests: monkeypatch.setitem(plan.OVERRIDES, "fuse_pool", "0")); win over the environment
+
+
+_plan_cache = (None, {})  # (the MAUA_PLAN string it was parsed from, the parsed fields): get() is called several times per launch
+
+
+def _planned():
+    """MAUA_PLAN's fields, parsed once per distinct value of the variable."""
+    global _plan_cache
+    text = os.environ.get("MAUA_PLAN")
+    if _plan_cache[0] != text or text is None:
+        _plan_cache = (text, _parse_plan(text))
+    return _plan_cache[1]
 
 
 def _parse_plan(text):
@@ -116,12 +129,12 @@ def get(name):
     default = FIELDS[name][0]
     if name in OVERRIDES:
         return str(OVERRIDES[name])
-    planned = _parse_plan(os.environ.get("MAUA_PLAN"))
+    planned = _planned()
     if name in planned:
         return planned[name]
-    for var, field in ENV_VARS.items():
-        if field == name and var in os.environ:
-            return os.environ[var]
+    var = _FIELD_VAR.get(name)
+    if var is not None and var in os.environ:
+        return os.environ[var]
     return default
 
 

@@ -373,9 +373,10 @@ def vid_img(args):
 
         optim.set_model_args(args, current_size)
         net, losses = models.load_model(args)
-        # (one broadcast per job: the first scale's, in the start-up phase; later scales copy the kept replica weights locally, so no
-        #  rank waits in a collective for a rank that is hours behind)
-        replica.sync(net, src=0)
+        # (one broadcast per model and job: the first scale's, in the start-up phase; later scales copy the kept replica weights locally,
+        #  so no rank waits in a collective for a rank that is hours behind; a --scaling_args table that changes the model between sizes
+        #  gets one entry per model; nothing happens outside a process group)
+        replica.sync(net, src=0, key=(str(getattr(args, "model_file", None)), str(getattr(args, "pooling", None))))
         batch = frames_per_batch(current_size, args)
 
         for pass_n in range(passes):

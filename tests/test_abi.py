@@ -34,6 +34,37 @@ def test_header_symbols_exported(libpath):
     assert not extra, f"exported but not declared in maua_hip.h: {extra}"
 
 
+def test_header_preamble_names_every_setter_with_its_scope(libpath):
+    """The header's Conventions paragraph says which state is per host thread and which is process-wide: every
+    exported setter (`nm`: a symbol with `_set_` in its name) must be named there, the per-thread one in the per-thread sentence, the
+    process-wide ones in the PROCESS-WIDE sentence - and the sources must agree (thread_local for the former, plain statics for the
+    latter, no other mutable file-scope state outside the diagnostic *_STAMP builds)."""
+    out = subprocess.check_output(["nm", "-D", "--defined-only", libpath], text=True)
+    setters = sorted(set(re.findall(r" T (maua_[a-z0-9_]*set_[a-z0-9_]+)", out)))
+    assert setters == ["maua_conv_x3p_set_max_groups", "maua_set_split_batch_hint", "maua_set_tuning"], setters
+    head = open(HEADER).read().split("#ifndef MAUA_HIP_H")[0]
+    per_thread = head[head.index("per host thread"):head.index("PROCESS-WIDE")]
+    process_wide = head[head.index("PROCESS-WIDE"):head.index("reductions are fixed-order")]
+    assert "maua_set_split_batch_hint" in per_thread and "maua_last_error" in head
+    assert "exactly two setters" in process_wide and "maua_set_tuning" in process_wide and "maua_conv_x3p_set_max_groups" in process_wide
+    assert "no process-wide mutable state" not in head
+    csrc = os.path.join(PKG, "csrc")
+    mutable = {}
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".hpp")):
+            stamp = 0
+            for line in open(os.path.join(csrc, f)):
+                if re.match(r"#if(def)? .*STAMP", line):
+                    stamp += 1
+                elif line.startswith("#endif") and stamp:
+                    stamp -= 1
+                m = re.match(r"static (thread_local )?([^;=()]*?)\b(g_[a-z_0-9]+)\b(\[[^\]]*\])?\s*(=|;)", line)
+                if m and not stamp and "const " not in m.group(2) and "constexpr" not in m.group(2):
+                    mutable[m.group(3)] = bool(m.group(1))
+    assert mutable.get("g_split_batch_hint") is True and mutable.get("g_err") is True      # per host thread
+    assert sorted(k for k, tl in mutable.items() if not tl) == ["g_tuning_set", "g_tuning_values", "g_xp_max_groups"], mutable  # the two documented setters' state
+
+
 def test_binding_table_matches_header(libpath):
     import hip
     assert sorted(hip.SIGNATURES) == declared_symbols()

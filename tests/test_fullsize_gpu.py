@@ -75,7 +75,7 @@ def test_full_size_directional_derivative(setup):
     assert abs(fd[0.25] - slope) <= 5e-3 * abs(slope), (fd, slope)
 
 
-@pytest.mark.parametrize("kernel", ["x3w", "x3", "x6"])
+@pytest.mark.parametrize("kernel", ["x3q", "x3p", "x3w", "x3", "x6"])
 @pytest.mark.parametrize("cin,cout,side", [(64, 64, 1024), (512, 512, 128), (512, 512, 64)])
 def test_full_size_split_conv_is_exactly_homogeneous(cin, cout, side, kernel):
     """Scaling the input by a power of two commutes with the bf16 three-way split, with the fp16 two-way split (its
@@ -87,9 +87,13 @@ def test_full_size_split_conv_is_exactly_homogeneous(cin, cout, side, kernel):
     if kernel == "x6":
         bank_f, bank_b = hip.conv_pack_filters_x6(w)
         conv = lambda t, bank, co: hip.conv3x3_x6(t, bank, None, co, 1, False)
-    elif kernel == "x3w":    # the kernel the benchmark times (conv_x3w.hip)
+    elif kernel == "x3w":    # conv_x3w.hip: the Gram-carrying backward launches and the 64- / 128-channel layers of small images
         bank_f, bank_b, wsc = hip.conv_pack_filters_x3w(w)
         conv = lambda t, bank, co: hip.conv3x3_x3w(t, bank, wsc, None, co, 1, False)
+    elif kernel in ("x3q", "x3p"):    # the kernels that take 21 of the 24 timed launches at 1024 x 1024 (conv_x3q.hip, conv_x3p.hip)
+        bank_f, bank_b, wsc = hip.conv_pack_filters_x3q(w)
+        fn = hip.conv3x3_x3q if kernel == "x3q" else hip.conv3x3_x3p
+        conv = lambda t, bank, co: fn(t, bank, wsc, None, co, 1, False)
     else:
         bank_f, bank_b, wsc = hip.conv_pack_filters_x3(w)
         conv = lambda t, bank, co: hip.conv3x3_x3(t, bank, wsc, None, co, 1, False)
@@ -182,11 +186,12 @@ def _grad_wrt_output(eng, step):
     return hip.pool2x2_bwd_codes(eng.gbuf[pool.dst], eng.pool_codes[id(pool)], torch.empty(g.shape, device="cuda"), True)
 
 
-@pytest.mark.parametrize("kernel", ["x3w", "x3"])
+@pytest.mark.parametrize("kernel", ["x3q", "x3p", "x3w", "x3"])
 @pytest.mark.parametrize("layer", ["conv1_2", "conv2_2", "conv3_2", "conv4_2", "conv5_1"])
 @pytest.mark.parametrize("direction", ["fwd", "bwd"])
 def test_full_size_fp16x3_conv_is_as_close_to_fp64_as_fp32_cpu(setup, layer, direction, kernel):
-    """The split-precision claim at the size that is benchmarked: conv_x3w (the timed kernel) and conv_x3 on the REAL inputs of five layers of the
+    """The split-precision claim at the size that is benchmarked: conv_x3q / conv_x3p (21 of the 24 timed launches at 1024 x 1024),
+    conv_x3w (the three Gram-carrying backward launches) and conv_x3 on the REAL inputs of five layers of the
     1024x1024 network (post-ReLU activations after 1 / 6 / 10 layers with their true dynamic range; for backward-data the
     real incoming gradients), K up to 4608, compared on 64x64 output crops (image corner incl. padding, and interior) with
     F.conv2d in fp64.  Bar: not worse than 1.5x the error of the reference's own arithmetic (fp32 conv on the CPU)."""
@@ -199,8 +204,8 @@ def test_full_size_fp16x3_conv_is_as_close_to_fp64_as_fp32_cpu(setup, layer, dir
     step = next(s for s in eng.steps if s.kind == "conv" and (s.mod.in_channels, s.mod.out_channels) == want[:2]
                 and eng.act[s.src].shape[2] == want[2])
     mod = step.mod
-    bf, bb, wsc = mod.banks3w() if kernel == "x3w" else mod.banks3()
-    conv = hip.conv3x3_x3w if kernel == "x3w" else hip.conv3x3_x3
+    bf, bb, wsc = {"x3w": mod.banks3w, "x3": mod.banks3, "x3q": mod.banks3q, "x3p": mod.banks3q}[kernel]()
+    conv = {"x3w": hip.conv3x3_x3w, "x3": hip.conv3x3_x3, "x3q": hip.conv3x3_x3q, "x3p": hip.conv3x3_x3p}[kernel]
     if direction == "fwd":
         inp = eng.act[step.src].clone()
         got = conv(inp, bf, wsc, mod.bias_device(), mod.out_channels, 1, False)
@@ -221,16 +226,93 @@ def test_full_size_fp16x3_conv_is_as_close_to_fp64_as_fp32_cpu(setup, layer, dir
         assert err <= max(1.5 * floor, 1e-7), (layer, direction, (y0, x0), err, floor)
 
 
+_VGG_CONVS = ["conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3", "conv3_4", "conv4_1", "conv4_2", "conv4_3", "conv4_4",
+              "conv5_1"]
+
+
+def _routes_by_layer(eng, x):
+    """{layer name: (forward record, backward record or None)} of one evaluation: engine.describe_routes lists one record per convolution
+    launch in launch order - the forward pass in network order, the backward pass deepest layer first."""
+    log = eng.describe_routes(x)
+    convs = [s for s in eng.steps if s.kind == "conv"]
+    fwd = [r for r in log if r["pass"] == "fwd"]
+    bwd = [r for r in log if r["pass"] == "bwd"]
+    assert len(fwd) == len(convs) == len(_VGG_CONVS) and len(bwd) == len(convs)
+    return {name: (fwd[i], bwd[len(convs) - 1 - i], convs[i]) for i, name in enumerate(_VGG_CONVS)}
+
+
+@pytest.mark.parametrize("layer,family,pooled", [("conv1_2", "conv_x3p", True), ("conv2_1", "conv_x3p", False), ("conv2_2", "conv_x3p", True),
+                                                 ("conv3_2", "conv_x3p", False), ("conv3_4", "conv_x3p", True), ("conv4_2", "conv_x3q", False),
+                                                 ("conv4_4", "conv_x3q", True), ("conv5_1", "conv_x3q", False)])
+def test_full_size_forward_pass_activations_against_fp64(setup, layer, family, pooled):
+    """The forward twin of the test below: the activations the REAL 1024x1024 forward pass leaves in the engine's buffers - written by
+    the launches the benchmark times: the persistent conv_x3p_kernel on conv1_2 ... conv3_4 (three of them with ReLU + the 2x2 max pool in
+    the epilogue: only the pooled map exists), conv_x3q_kernel from conv4_1 on - against fp64 on crops: relu(conv(a_in)) (and its
+    max_pool2d) recomputed on the CPU from the engine's own input activation (reference models.py:120,129-130).  The route log of the same
+    evaluation says which kernel family the launch under test was.  Bar: 1.5x the error of the fp32 CPU arithmetic on the same data."""
+    import torch.nn.functional as F
+    _, _, _, eng, x = setup
+    rec, _, step = _routes_by_layer(eng, x)[layer]
+    assert rec["kernel"] == family and bool(rec.get("pool")) == pooled and rec["ksplit"] == 1, rec
+    eng.feval(x)
+    torch.cuda.synchronize()
+    mod, a_in = step.mod, eng.act[step.src]
+    assert float(a_in.abs().max()) > 0
+    if pooled:
+        ps = eng.fused_pool[id(step)]
+        assert eng.act[step.dst].is_meta      # the full-size map is a shape only
+        out = eng.act[ps.dst]
+    else:
+        out = eng.act[step.dst]
+    side = a_in.shape[2]
+    size = 64 if side >= 128 else 32
+    for y0, x0 in sorted({(0, 0), (side // 2 - size // 2, min(side // 2 - size // 4, side - size)), (side - size, side - size)}):
+        res = {}
+        for dt in (torch.float64, torch.float32):
+            r = torch.relu(_crop_reference(a_in, mod.weight.detach(), mod.bias.detach(), y0, x0, size, 1, dt))
+            res[dt] = F.max_pool2d(r, 2, 2) if pooled else r
+        if pooled:
+            mine = out[:, :, y0 // 2:(y0 + size) // 2, x0 // 2:(x0 + size) // 2].cpu()
+        else:
+            mine = out[:, :, y0:y0 + size, x0:x0 + size].cpu()
+        floor = rel_l2(res[torch.float32], res[torch.float64])
+        err = rel_l2(mine, res[torch.float64])
+        assert err <= max(1.5 * floor, 1e-7), (layer, (y0, x0), err, floor)
+
+
+def test_full_size_routes_are_the_documented_ones(setup):
+    """What DESIGN.md section 2 says about the 1024 x 1024 iteration: 24 split-precision 3x3 launches - the image layer apart - of which
+    conv_x3p takes the 64- to 256-channel passes and conv_x3q the 512-channel ones; conv_x3w keeps the backward launches that carry a Gram
+    backward along."""
+    _, _, _, eng, x = setup
+    by = _routes_by_layer(eng, x)
+    fam = {k: (f["kernel"], b["kernel"]) for k, (f, b, _) in by.items()}
+    assert fam["conv1_1"][0] == "conv_image"
+    for name in ("conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3", "conv3_4"):
+        assert fam[name][0] == "conv_x3p", (name, fam[name])
+    for name in ("conv4_1", "conv4_2", "conv4_3", "conv4_4", "conv5_1"):
+        assert fam[name][0] == "conv_x3q", (name, fam[name])
+    for name in ("conv5_1", "conv4_4", "conv4_3", "conv4_2", "conv4_1", "conv3_1"):
+        assert fam[name][1] == "conv_x3q", (name, fam[name])
+    for name in ("conv3_4", "conv3_3", "conv2_1"):
+        assert fam[name][1] == "conv_x3p", (name, fam[name])
+    split = sum(1 for f, b, _ in by.values() for r in (f, b) if r["kernel"] in ("conv_x3p", "conv_x3q", "conv_x3w"))
+    assert split == 24
+
+
 @pytest.mark.parametrize("layer", ["conv3_4", "conv4_3", "conv4_4", "conv5_1"])
 def test_full_size_backward_pass_gradients_against_fp64(setup, layer):
     """The gradients the REAL 1024x1024 backward pass leaves in the engine's buffers - written by the launches the benchmark times, with
-    the ReLU mask of the produced gradient applied in the convolution's epilogue (conv_x3w_kernel<false, true, false>) - against fp64 on
+    the ReLU mask of the produced gradient applied in the convolution's epilogue (conv3_4: conv_x3p_kernel<OM, .., UNPOOL>; conv4_3 and
+    conv5_1: conv_x3q_kernel<.., OM>; conv4_4: conv_x3q_kernel<.., OM, .., UNPOOL>; the route log is asserted) - against fp64 on
     64x64 crops: g[input of the layer] = [input > 0] * conv_transpose(g[output of the layer]) (autograd of models.py:129-130 in the
     reference), recomputed on the CPU from the engine's own g[output] and saved activation.  Layers whose input carries no loss term
     (conv4_3's input, relu4_2, is the content layer: its MSE gradient is added on top - checked with it).  Bar: 1.5x the error of the fp32
     CPU arithmetic on the same data."""
     import torch.nn.functional as F
     _, _, _, eng, x = setup
+    rec = _routes_by_layer(eng, x)[layer][1]
+    assert rec["kernel"] == ("conv_x3p" if layer == "conv3_4" else "conv_x3q") and bool(rec.get("unpool")) == (layer in ("conv3_4", "conv4_4")), rec
     eng.feval(x)
     torch.cuda.synchronize()
     want = {"conv3_4": (256, 256, 256, 3), "conv4_3": (512, 512, 128, 1), "conv4_4": (512, 512, 128, 2), "conv5_1": (512, 512, 64, 0)}[layer]

@@ -109,8 +109,38 @@ def _worker(rank, world, port, tmp):
     assert rep.sync(net2) == "local copy" and all(torch.equal(a, b) for a, b in zip(net2.parameters(), want3[:2]))
     net3 = fresh(5, "relu2_1")                                   # a deeper one: only its new tail travels
     assert rep.sync(net3) == "broadcast of the new tail" and all(torch.equal(a, b) for a, b in zip(net3.parameters(), want))
+    # a --scaling_args table that changes the model between sizes (the reference's config/scaling-img.json: vgg19 -> prune -> nin): the
+    # second model is ANOTHER checkpoint of an architecture whose first layers have the same shapes - it must get its own broadcast, not
+    # the first model's kept weights, and coming back to the first model is a local copy again
+    def other(n_layers, layers, scale):
+        c = models.VGG(models.build_sequential(models.channel_list["VGG-19"][:n_layers], "max"))
+        for p_ in c.parameters():
+            p_.data.fill_(scale if rank == 0 else float("nan"))
+        a2 = argparse.Namespace(**{**vars(args), "content_layers": layers, "style_layers": layers})
+        return models.assemble(c.features, models.vgg19_dict, a2)[0]
+    rep = dist.ReplicaWeights()
+    assert rep.sync(fresh(3, "relu1_2"), key=("vgg19.pth", "max")) == "broadcast"
+    net_b = other(3, "relu1_2", 0.25)
+    assert rep.sync(net_b, key=("prune.pth", "max")) == "broadcast" and all(float(p_.min()) == float(p_.max()) == 0.25 for p_ in net_b.parameters())
+    net_a = fresh(3, "relu1_2")
+    assert rep.sync(net_a, key=("vgg19.pth", "max")) == "local copy" and all(torch.equal(a, b) for a, b in zip(net_a.parameters(), want3))
+    # the same key with other layer shapes (a key that did not tell two architectures apart): whole broadcast again, no exception
+    nin_like = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 5), torch.nn.Conv2d(8, 8, 1))
+    for p_ in nin_like.parameters():
+        p_.data.fill_(0.5 if rank == 0 else float("nan"))
+    assert rep.sync(nin_like, key=("vgg19.pth", "max")) == "broadcast" and all(float(p_.min()) == 0.5 for p_ in nin_like.parameters())
     dist.barrier()
     open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+
+
+def test_replica_weights_do_nothing_outside_a_process_group():
+    """vid_img calls ReplicaWeights.sync for every size, single-process runs included: no copy, no exception, whatever the networks are."""
+    import dist
+    rep = dist.ReplicaWeights()
+    a, b = torch.nn.Conv2d(3, 8, 3), torch.nn.Conv2d(3, 16, 5)
+    wa = a.weight.data.clone()
+    assert rep.sync(a, key="m1") == "single process" and rep.sync(b, key="m1") == "single process"
+    assert torch.equal(a.weight.data, wa) and not rep.kept
 
 
 def test_two_rank_gloo_broadcast_and_sharding(tmp_path):

@@ -1,4 +1,4 @@
-"""conv_x3w start stagger sweep (MAUA_X3W_STAGGER is read once per process): one layer, several values, one process each."""
+"""conv_x3w start stagger sweep (planner field x3w_stagger, handed to the library when it is loaded: MAUA_PLAN="x3w_stagger=.."): one layer, several values, one process each."""
 import os, subprocess, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 code = r'''
@@ -24,6 +24,6 @@ for cin, cout, H in ((512, 512, 128), (256, 256, 256), (64, 64, 1024), (128, 128
 print()
 ''' % (REPO, os.path.join(REPO, "maua-style_amd"))
 for st in sys.argv[1:]:
-    env = dict(os.environ, MAUA_X3W_STAGGER=st)
+    env = dict(os.environ, MAUA_PLAN=",".join(p for p in (os.environ.get("MAUA_PLAN", ""), f"x3w_stagger={st}") if p))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     print(f"stagger {st:>3}:", out.stdout.strip(), out.stderr.strip()[-300:] if out.returncode else "")

@@ -1,10 +1,17 @@
 #!/bin/bash
 # Per-dispatch timeline of one 1024 x 1024 L-BFGS iteration (median over the last iterations of the trace) for each value of an
-# environment switch, side by side:   tools/trace_ab.sh OUTDIR VAR "v0 v1"
+# planner field, side by side:   tools/trace_ab.sh OUTDIR FIELD "v0 v1"   (FIELD = a name of plan.FIELDS, e.g. conv_x3p; it is set
+# through MAUA_PLAN="FIELD=value" - any other MAUA_* variable would be ignored by the planner; a full MAUA_* name of an honoured
+# variable, e.g. MAUA_CONV_X3, is exported as it is)
 R=$PWD; O=$R/$1; VAR=$2; VALS=$3; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 for v in $VALS; do
-  export $VAR=$v
+  case $VAR in
+    MAUA_PLAN) export MAUA_PLAN=$v ;;
+    MAUA_CONV_X3|MAUA_CONV_X6|MAUA_HIP_GRAPH|MAUA_DEBUG_POISON|MAUA_HOST_THREADS) export $VAR=$v ;;
+    MAUA_*) echo "trace_ab.sh: $VAR is not an honoured variable; pass the planner field's name instead" >&2; exit 2 ;;
+    *) export MAUA_PLAN="${BASE_PLAN:+$BASE_PLAN,}$VAR=$v" ;;
+  esac
   rocprofv3 --kernel-trace --output-format csv -d $O/t_$v -o p -- python3 $R/bench.py --steps 12 --warmup 2 --no_prefill --no_cpu_baseline --no_extra_sizes --no_exact_split --no_repeats ${GRAPH:---no_hip_graph} $BENCH_ARGS > /dev/null 2>&1
 done
 cd $R
