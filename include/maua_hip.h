@@ -17,8 +17,8 @@
  *    asynchronously on it, nothing synchronises, so calls can be captured into a hipGraph;
  *  - return value: 0 = ok, <0 = invalid argument / unsupported shape (MAUA_E_*), >0 = hipError_t
  *    of the failed launch; maua_last_error() gives a thread-local message;
- *  - per host thread: the error message and the split-K batch hint (maua_set_split_batch_hint), so concurrent jobs on their own
- *    threads and streams do not interfere through them.  PROCESS-WIDE mutable state, exactly two setters: maua_set_tuning (the planner's
+ *  - per host thread: the error message, the split-K batch hint (maua_set_split_batch_hint) and the armed workspace
+ *    (maua_conv_arm_workspace), so concurrent jobs on their own threads and streams do not interfere through them.  PROCESS-WIDE mutable state, exactly two setters: maua_set_tuning (the planner's
  *    constants, set once when the host side loads the library) and maua_conv_x3p_set_max_groups (tests); neither changes a result bit,
  *    both are read at launch time - set them before the first launch, not while another thread launches or captures;
  *  - reductions are fixed-order (no float atomics): reruns are bit-identical, like the reference
@@ -385,13 +385,15 @@ int maua_fill(float* x, int64_t count, float value, maua_stream_t stream);
  * padding=1), /root/reference/models.py:129-130) on the matrix cores (conv_few_mfma.hip, round 5): per gradient pixel the 27 (tap, channel)
  * sums over the 64 channels as one bf16x6 product block, then nine values gathered per output pixel and channel.
  * maua_conv_pack_filters_few_mfma: OIHW weights (64, cin, 3, 3) -> the bank (maua_conv_few_mfma_bank_bytes() bytes; once per weight set).
- * maua_conv3x3_few_mfma: gy (n, 64, h, w) -> gx (n, cin, h, w), written whole; `tile`: 0 = the library's choice, 1 / 2 / 3 = 4 / 8 / 14
+ * maua_conv3x3_few_mfma: gy (n, 64, h, w) -> gx (n, cin, h, w), written whole (`accumulate`: added to what gx holds - the TV loss's
+ * gradient, which the engine computes beside the forward pass since round 6); `tile`: 0 = the library's choice, 1 / 2 / 3 = 4 / 8 / 14
  * output rows x 62 columns per workgroup.
  * maua_conv_few_mfma_supported: geometry check (64 filters, 1-3 channels, padding 1, planes whose 64 gradient maps stay below 2 GiB). */
 size_t maua_conv_few_mfma_bank_bytes(void);
 int maua_conv_pack_filters_few_mfma(const float* w_oihw, void* bank, int cout, int cin, maua_stream_t stream);
 int maua_conv_few_mfma_supported(int n, int cin, int h, int w, int cout, int pad);
-int maua_conv3x3_few_mfma(const float* gy, const void* bank, float* gx, int n, int cin, int h, int w, int cout, int tile, maua_stream_t stream);
+int maua_conv3x3_few_mfma(const float* gy, const void* bank, float* gx, int n, int cin, int h, int w, int cout, int tile, int accumulate,
+                          maua_stream_t stream);
 
 /* The inverse regrouping: out[n][(ry r + rx) c_in + c][qy][qx] = in[n][c][r qy + ry][r qx + rx], 0 for pixels beyond h x w - the head of the
  * same layer's FORWARD pass as a 3x3 stride-1 convolution 48 -> 96 over 256 x 256 sites (models.conv_strided_fwd_as_3x3, conv_x3w.hip). */
@@ -459,6 +461,23 @@ double maua_get_tuning(const char* name, double dflt);
  * workspaces): concurrent jobs with different plans run on a thread each. */
 void maua_set_split_batch_hint(int frames);
 int maua_get_split_batch_hint(void);
+
+/* Split channel loops finished INSIDE the producing launch (round 6).  A launch that splits its channel loop k ways leaves k slabs of partial
+ * sums and - until now always - a second launch adds them (conv_splitk_finish_kernel: bias, ReLU, mask, pool; 7-12 us for kilobytes to
+ * megabytes of work: 19 such launches were 9 % of a 512 x 512 iteration).  With ARRIVAL COUNTERS the producing launch does it itself: the
+ * workgroup that arrives last at its tile adds the other splits' slabs to its own sums - in split order, the additions of the second
+ * launch, bit for bit - and runs the one-pass epilogue; no workgroup waits for another (cdna_hip_programming.md: in-launch split-K
+ * reduction, write-through form).  The reference has no counterpart (one `F.conv2d` per layer, /root/reference/models.py:129-130).
+ *   maua_conv_arm_workspace(workspace, counters, counter_bytes, zero, stream): `counters` = 16 KiB (4096 words, 16-byte aligned) of device
+ *     memory that the library zeroes here (on `stream`; `zero` = 0: the caller vouches that they are zero already - pointing the thread
+ *     back at a workspace it armed before, e.g. while a stream is being captured) and that every in-launch finish leaves zeroed again.  From then on the launches
+ *     of the CALLING HOST THREAD that are handed exactly this `workspace` pointer finish splits of at most `finish_in_launch_max_ks`
+ *     (tuning constant, default 4) slabs in the launch: maua_conv3x3_x3q / _relu_pool / _unpool and maua_conv3x3_x3w / _relu_pool /
+ *     _unpool / _gram.  Any other workspace, larger splits and the other kernel families keep the second launch.  Results are
+ *     bit-identical either way.  The counters belong to the workspace: one stream of launches at a time, like its slabs.  NULL
+ *     workspace or counters: disarm.  Per host thread, like the batch hint.
+ * The *_workspace_bytes functions already return enough for either form. */
+int maua_conv_arm_workspace(void* workspace, void* counters, size_t counter_bytes, int zero, maua_stream_t stream);
 
 /* ---- L-BFGS pixel update: torch.optim.LBFGS as configured at optim.py:180-191 --------------------- */
 /* Device-resident state: `state` is an opaque caller-allocated buffer of maua_lbfgs_state_bytes(count, history)

@@ -123,7 +123,14 @@ struct ConvArgs {
     const unsigned char* in_codes;  // conv_x3w backward, nullable: `x` is the pooled map [Cin][H/2][W/2] of a 2x2 / 2 max pool and these are its
     int in_code_mask;               //   decision bytes; the kernel reads x as the pool's backward pass over them: element (y, x) =
                                     //   pooled[y/2][x/2] if (code & in_code_mask) == 2 (y & 1) + (x & 1) else 0  (mask 7: ReLU bit honoured, 3: not)
+    unsigned* arrive;    // split-K finished INSIDE the launch (conv_x3q / conv_x3w, round 6), nullable: one arrival counter per (image, channel
+                         //   tile, pixel tile), all zero between launches; the workgroup that draws the last ticket of its tile adds the other
+                         //   splits' slabs to its own sums in split order and runs the one-pass epilogue (no conv_splitk_finish launch)
 };
+// conv_api.hip: the arrival counters of the workspace the calling host thread armed (maua_conv_arm_workspace) if `workspace` is that one,
+// else null.  ARRIVE_COUNTERS words; a launch that needs more, or whose workspace is another one, finishes its split in a second launch.
+constexpr int ARRIVE_COUNTERS = 4096;
+unsigned* armed_counters(const void* workspace);
 // conv_api.hip: the library's tuning constants (plan.py lists them; maua_set_tuning sets them, nothing reads the environment)
 double tuning(const char* name, double dflt);
 int split_batch_hint();  // conv_api.hip: frames per launch the caller plans with (split-K cost models), >= 1

@@ -13,6 +13,11 @@ namespace maua {
 // message: two jobs with different plans in one process (one thread each) do not see each other's value.
 static thread_local int g_split_batch_hint = 1;
 int split_batch_hint() { return g_split_batch_hint; }
+// The workspace whose split-K launches may finish inside the launch, and its arrival counters (maua_conv_arm_workspace).  Per host thread:
+// a workspace belongs to one stream of launches at a time anyway (its slabs), and so do its counters.
+static thread_local const void* g_armed_ws = nullptr;
+static thread_local unsigned* g_armed_counters = nullptr;
+unsigned* armed_counters(const void* workspace) { return workspace && workspace == g_armed_ws ? g_armed_counters : nullptr; }
 }  // namespace maua
 
 namespace maua {
@@ -21,7 +26,7 @@ namespace maua {
 // as the caller's default.  Process-wide, read at every use (a few string compares per launch), not thread-safe against concurrent sets.
 static const char* const g_tuning_names[] = {"conv_few_out", "few_out_ks4_below", "x3w_ks", "x3w_stagger", "x3q_ks", "x3q_min_fill", "x3q_min_chunks",
                                              "x3p_ks", "x3p_groups", "x3p_min_fill", "x3p_min_items", "x6_persist", "gram_x3", "gram_bwd_x3",
-                                             "gram_t128", "gram_t128_min_hw", "p1_order", "lbfgs_vec", "lbfgs_tri"};
+                                             "gram_t128", "gram_t128_min_hw", "p1_order", "lbfgs_vec", "lbfgs_tri", "finish_in_launch_max_ks"};
 constexpr int kTunings = sizeof(g_tuning_names) / sizeof(g_tuning_names[0]);
 static double g_tuning_values[kTunings];
 static bool g_tuning_set[kTunings];
@@ -56,6 +61,24 @@ int maua_set_tuning(const char* name, double value) {
     return MAUA_OK;
 }
 double maua_get_tuning(const char* name, double dflt) { return maua::tuning(name, dflt); }
+
+int maua_conv_arm_workspace(void* workspace, void* counters, size_t counter_bytes, int zero, maua_stream_t stream) {
+    if (!workspace || !counters) {  // disarm
+        maua::g_armed_ws = nullptr;
+        maua::g_armed_counters = nullptr;
+        return MAUA_OK;
+    }
+    MAUA_REQUIRE(counter_bytes >= (size_t)maua::ARRIVE_COUNTERS * 4 && ((size_t)counters & 15) == 0, MAUA_E_INVAL,
+                 "conv_arm_workspace: needs %d bytes of 16-byte aligned counters", maua::ARRIVE_COUNTERS * 4);
+    const hipError_t rc = zero ? hipMemsetAsync(counters, 0, (size_t)maua::ARRIVE_COUNTERS * 4, (hipStream_t)stream) : hipSuccess;
+    if (rc != hipSuccess) {
+        set_error("conv_arm_workspace: hipMemsetAsync: %s", hipGetErrorString(rc));
+        return (int)rc;
+    }
+    maua::g_armed_ws = workspace;
+    maua::g_armed_counters = (unsigned*)counters;
+    return MAUA_OK;
+}
 
 void maua_set_split_batch_hint(int frames) { maua::g_split_batch_hint = frames > 0 ? frames : 1; }
 int maua_get_split_batch_hint(void) { return maua::g_split_batch_hint; }

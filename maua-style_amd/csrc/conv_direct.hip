@@ -2,6 +2,14 @@
 // 11x11 stride-4 stem (reference models.py:83).  One thread per output element; a wave covers 64 consecutive
 // pixels of one channel, so the filter taps it needs are wave-uniform.  The forward reads the [tap][ci][co]
 // bank, the backward-data reads the OIHW weights directly.
+//
+// Built WITHOUT packed fp32 instructions since round 6 (they are two plain instructions each: same bits).  No kernel here issues MFMAs, but
+// the split-K finishing kernels run on the main stream right behind their convolution while a frame batch's per-frame Gram kernels (MFMA)
+// may still be running on the side streams, and tools/soak_streams.py showed what round 5 only suspected: a packed-fp32 kernel beside an
+// MFMA kernel of ANOTHER stream can lose results in the upper lanes (profiles/probes_r06.md section 2: conv3x3_few_out beside conv1x1_x3
+// under the MFMA-padding build, 16951 of 17008 runs wrong, lanes 32-63).  conv3x3_few_out's packed FMAs (round 3: 108 -> 54 instructions
+// per channel) go with it: it is the fallback of conv_few_mfma.hip now.
+// hipcc-flags: -Xclang -target-feature -Xclang -packed-fp32-ops
 #include "common.hpp"
 
 namespace maua {

@@ -115,6 +115,15 @@ __global__ void pack_x3q_kernel(const float* __restrict__ w, unsigned short* __r
 
 #define XQ_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+// The kernel's argument segment (ConvArgs is the first parameter): the in-launch finish re-reads its arguments from here behind the K loop
+__device__ __forceinline__ const ConvArgs* xq_kernel_arguments() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (const ConvArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    return nullptr;
+#endif
+}
+
 // One scheduling region of the K loop = 12 MFMAs + what rides along: per MFMA at most one LDS read, one vector-memory
 // instruction and VA vector-ALU instructions, in that order (a lone wave per SIMD hides nothing behind another wave: whatever
 // the compiler clusters in front of the MFMAs is a hole in the matrix pipe).
@@ -180,6 +189,10 @@ __global__ void __launch_bounds__(XQ_THREADS, 2) conv_x3q_kernel(ConvArgs p, flo
     const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (tile >= min(((int)(blockIdx.x & 7) + 1) * per_xcd, tiles_total)) return;  // whole workgroup leaves
     const int x0 = (tile % p.tiles_x) * 32, y0 = (tile / p.tiles_x) * XQ_ROWS;
+    if (tid == 0) {  // for the in-launch finish of a split channel loop (behind the K loop; read there behind several barriers)
+        reinterpret_cast<int*>(Ml)[9] = (n * ntile + cotile) * tiles_total + tile;
+        reinterpret_cast<int*>(Ml)[10] = split;
+    }
 
     // Staging items of this thread: item k = (octet, position) number tid + 512 k.  voff = byte offset of the item's first
     // channel from the chunk's first plane; out-of-image positions and items past the end get an offset beyond the buffer's
@@ -248,6 +261,19 @@ __global__ void __launch_bounds__(XQ_THREADS, 2) conv_x3q_kernel(ConvArgs p, flo
     };
     // channels [c_lo, c_hi) of every item (UNPOOL: the decision bytes come with channel 0)
     auto load_patch_part = [&](const PatchSrc& rs, int c_lo, int c_hi) {
+#ifdef XQ_NO_SPLIT
+        // TIMING-ONLY diagnostic (tools/nosplit_ceiling.sh; wrong numbers): what the K loop would cost if the patch came
+        // as ready fp16 pairs by LDS-DMA - ten 1 KiB buffer-to-LDS loads per wave and chunk (the patch's 78 KiB) instead of forty dword
+        // loads, the maximum, the split and ten ds_write_b128 per thread.
+#if defined(__HIP_DEVICE_COMPILE__)
+        for (int c = c_lo; c < c_hi; ++c)
+            if (c < 5)
+                for (int part = 0; part < 2; ++part)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs.x, (__attribute__((address_space(3))) void*)(Pl + ((wv * 5 + c) * 2 + part) * 992), 16,
+                                                             voff[c < NI ? c : 0], part * 64, 0, 0);
+#endif
+        return;
+#endif
         if constexpr (UNPOOL) {
             if (c_lo == 0) {
 #pragma unroll
@@ -261,6 +287,10 @@ __global__ void __launch_bounds__(XQ_THREADS, 2) conv_x3q_kernel(ConvArgs p, flo
                 rp[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs.x, voff[k], c * st_plane * 4, 0));
     };
     auto publish_max = [&]() {
+#ifdef XQ_NO_SPLIT
+        if (lane == 0) Ml[wave] = 1.f;
+        return;
+#endif
         if constexpr (UNPOOL) {
             // A value counts (for the chunk's scale, and at all) where its byte names a corner that is a patch position - bit 2 of the
             // byte, kept by code_mask = 7, names none.  What another tile's patch holds of this window is that tile's business.
@@ -296,6 +326,9 @@ __global__ void __launch_bounds__(XQ_THREADS, 2) conv_x3q_kernel(ConvArgs p, flo
     // the packed low parts): high parts x sx rounded to nearest, low parts = the (exact) remainders rounded to nearest.  x sx is exact
     // (a power of two), so fma(x, sx, -h) is the remainder without an intermediate product: one mixed-precision FMA per half.
     auto split_item = [&](int k) {
+#ifdef XQ_NO_SPLIT
+        return;
+#endif
         if (k >= NI) return;
 #pragma unroll
         for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(rp[k][c]));  // (pinned between the fences of its step: see the fold)
@@ -317,6 +350,9 @@ __global__ void __launch_bounds__(XQ_THREADS, 2) conv_x3q_kernel(ConvArgs p, flo
         for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(rp[k][c]));
     };
     auto store_patch = [&]() {
+#ifdef XQ_NO_SPLIT
+        return;
+#endif
         if constexpr (UNPOOL) {
 #pragma unroll
             for (int k = 0; k < NI; ++k)
@@ -558,8 +594,82 @@ __global__ void __launch_bounds__(XQ_THREADS, 2) conv_x3q_kernel(ConvArgs p, flo
         d_[4] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_s_memrealtime());
     }
 #endif
+    // Split channel loop finished INSIDE the launch (round 6; p.arrive = one zeroed arrival counter per (image, channel tile, pixel tile)):
+    // every split's workgroup leaves its un-scaled partial sums in its slab - lane-linear, sixteen 16-byte vectors per thread, written
+    // THROUGH (sc1), drained - and draws a ticket (one relaxed agent-scope add per workgroup).  The workgroup that draws the last ticket of
+    // its tile adds the slabs in split order - its own sums from its registers at their place in that order, the others by sc1 loads: the
+    // additions of conv_splitk_finish_kernel, bit for bit - then the bias, and runs the one-pass epilogue below (mask, ReLU, pool,
+    // accumulation); the others leave.  Nothing waits for anything: whatever the order in which the workgroups of a tile run, the last one
+    // to arrive finds every other slab complete (cdna_hip_programming.md, in-launch split-K reduction, sc1 form: the stores are drained in
+    // front of the workgroup's barrier, the ticket add follows the barrier, every load of a slab is an sc1 load).  The last arriver puts
+    // the counter back to zero: the next launch (stream order) finds it so.
+    // (The K loop has no scalar register to spare - one more value alive across it and the allocator spills staging addresses into the
+    //  loop.  So this phase takes nothing across the loop: its tile number and split index were parked in LDS by thread 0 at entry, and
+    //  the kernel arguments it needs are read again from the argument segment through a pointer the compiler cannot see through.)
+    bool final_sums = p.ksplit <= 1;
+    const ConvArgs* kp = xq_kernel_arguments();
+    asm volatile("" : "+s"(kp));
+    if (kp->ksplit > 1 && kp->arrive != nullptr) {
+        const int ksplit = kp->ksplit;
+        const int unit = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(Ml)[9]);
+        const int split = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(Ml)[10]);
+        unsigned* const arrive = kp->arrive + unit;
+        const float* const bias = kp->bias;
+        constexpr unsigned SLAB = XQ_COT * XQ_ROWS * 32 * 4;  // 128 KiB
+        const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(kp->ws) + (int64_t)unit * ksplit * SLAB, 0,
+                                                                            (unsigned)ksplit * SLAB, 0x00020000);
+        const unsigned toff = (unsigned)tid * 16u;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, master[q >> 2][q & 3]), srs, toff, (unsigned)split * SLAB + q * 8192u, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        unsigned* tick = reinterpret_cast<unsigned*>(Ml) + 8;
+        if (tid == 0) *tick = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if ((int)*tick != ksplit - 1) {
+            XQ_EXIT_STAMP();
+            return;
+        }
+        if (tid == 0) __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < ksplit; ++k) {
+            if (k == split) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[i][g] += master[i][g];
+            } else {
+#ifndef XQ_FIN_BATCH
+#define XQ_FIN_BATCH 8
+#endif
+#pragma unroll
+                for (int q0 = 0; q0 < 16; q0 += XQ_FIN_BATCH) {
+                    u32x4 t[XQ_FIN_BATCH];
+#pragma unroll
+                    for (int q = 0; q < XQ_FIN_BATCH; ++q) t[q] = __builtin_amdgcn_raw_buffer_load_b128(srs, toff, (unsigned)k * SLAB + (q0 + q) * 8192u, 16);
+#pragma unroll
+                    for (int q = 0; q < XQ_FIN_BATCH; ++q) acc[(q0 + q) >> 2][(q0 + q) & 3] += __builtin_bit_cast(f32x4, t[q]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + i * 16 + 4 * oct + r;
+                const float b0 = bias != nullptr ? bias[min(co, kp->Cout - 1)] : 0.f;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) master[i][g][r] = acc[i][g][r] + b0;
+            }
+        final_sums = true;
+    }
     // epilogue: lane holds pixel column 16 (g & 1) + px of row y0 + 2 wave + (g >> 1); register r of group i is output channel 16 i + 4 oct + r
-    if constexpr (POOL) if (p.ksplit <= 1) {
+    if constexpr (POOL) if (final_sums) {
         // ReLU + the 2x2 / 2 max pool behind it: a wave's two rows and neighbouring lanes are exactly the windows, so the full-size
         // activation never goes to memory - only the pooled map and one decision byte per window (what pool2x2_fwd_codes_kernel
         // leaves: position of the first maximum in scan order, bit 2 = the maximum is <= 0; bytes laid out [octet of channels][pooled
@@ -607,7 +717,7 @@ __global__ void __launch_bounds__(XQ_THREADS, 2) conv_x3q_kernel(ConvArgs p, flo
         const int oy = y0 + 2 * wave + (g >> 1), ox = x0 + (g & 1) * 16 + px;
         const bool pvalid = oy < p.OH && ox < p.OW;
         const int64_t opix = (int64_t)oy * p.OW + ox;
-        if (p.ksplit > 1) {  // split-K: un-scaled partial sums, finished by conv_splitk_finish_kernel in split order
+        if (!final_sums) {  // split-K: un-scaled partial sums, finished by conv_splitk_finish_kernel in split order
             float* wsp = p.ws + (int64_t)blockIdx.z * p.Cout * out_plane;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -705,6 +815,20 @@ static int xq_launch_one(const ConvArgs& p, dim3 grid, float w_inv, hipStream_t 
     return check_launch("conv_x3q_kernel");
 }
 
+// Bytes of slabs a launch that finishes its split inside the launch needs: one 128 KiB slab per (image, channel tile, pixel tile, split) - whole
+// tiles, so a little more than the [split][Cout][OH][OW] slabs of the two-launch form on ragged planes.
+static size_t x3q_in_launch_bytes(const ConvArgs& a, int n, int ks) {
+    const int64_t tiles = (int64_t)((a.OW + 31) / 32) * ((a.OH + XQ_ROWS - 1) / XQ_ROWS), cot = (a.Cout + XQ_COT - 1) / XQ_COT;
+    return (size_t)n * cot * tiles * ks * (XQ_COT * XQ_ROWS * 32 * 4);
+}
+// Whether a launch split `ks` ways finishes inside the launch: the caller armed this workspace (a.arrive), the split is small enough for
+// one workgroup to add the other slabs (tuning constant finish_in_launch_max_ks, default 4: it reads (ks - 1) x 128 KiB alone), and the
+// tiles have counters.
+static bool x3q_finish_in_launch(const ConvArgs& a, int n, int ks) {
+    const int64_t units = (int64_t)n * ((a.Cout + XQ_COT - 1) / XQ_COT) * ((a.OW + 31) / 32) * ((a.OH + XQ_ROWS - 1) / XQ_ROWS);
+    return ks > 1 && a.arrive != nullptr && ks <= (int)tuning("finish_in_launch_max_ks", 4) && units <= ARRIVE_COUNTERS;
+}
+
 int conv_x3q_launch(const ConvArgs& a, int n, float w_scale, hipStream_t stream) {
     ConvArgs p = a;
 #ifdef XQ_STAMP
@@ -716,17 +840,19 @@ int conv_x3q_launch(const ConvArgs& a, int n, float w_scale, hipStream_t stream)
     p.ksplit = ks;
     const int64_t cot = (a.Cout + XQ_COT - 1) / XQ_COT, per_xcd = (tiles + 7) / 8;
     dim3 grid((unsigned)(per_xcd * 8), (unsigned)cot, (unsigned)(n * ks));
-    const bool acc = ks == 1 && a.accumulate != 0, om = ks == 1 && a.omask != nullptr;
+    const bool whole = ks == 1 || x3q_finish_in_launch(a, n, ks);  // the launch's epilogue holds complete sums (one pass, or the last arriver's)
+    if (!whole) p.arrive = nullptr;
+    const bool acc = whole && a.accumulate != 0, om = whole && a.omask != nullptr;
     const float w_inv = 1.f / w_scale;
     int rc;
-    if (a.pool_codes && ks == 1) rc = xq_launch_one<false, false, true, false>(p, grid, w_inv, stream);
+    if (a.pool_codes && whole) rc = xq_launch_one<false, false, true, false>(p, grid, w_inv, stream);
     else if (a.in_codes && om) rc = xq_launch_one<false, true, false, true>(p, grid, w_inv, stream);
     else if (a.in_codes) rc = xq_launch_one<false, false, false, true>(p, grid, w_inv, stream);
     else if (acc && om) rc = xq_launch_one<true, true, false, false>(p, grid, w_inv, stream);
     else if (acc) rc = xq_launch_one<true, false, false, false>(p, grid, w_inv, stream);
     else if (om) rc = xq_launch_one<false, true, false, false>(p, grid, w_inv, stream);
     else rc = xq_launch_one<false, false, false, false>(p, grid, w_inv, stream);
-    if (rc || ks == 1) return rc;
+    if (rc || whole) return rc;
     // (a split channel loop leaves partial sums: the ReLU + pool of a pooling launch then happen in the pass that adds them)
     return a.pool_codes ? conv_splitk_finish_pool(a, n, ks, stream) : conv_splitk_finish(a, n, ks, stream);
 }
@@ -779,7 +905,10 @@ size_t maua_conv_x3q_workspace_bytes(int n, int cin, int h, int w, int cout, int
     a.OW = w + 2 * pad - 2;
     if (a.OH <= 0 || a.OW <= 0) return 0;
     const int ks = x3q_choose_split(a, n);
-    return ks > 1 ? (size_t)n * ks * cout * a.OH * a.OW * sizeof(float) : 0;
+    if (ks <= 1) return 0;
+    const size_t two_launches = (size_t)n * ks * cout * a.OH * a.OW * sizeof(float);
+    const size_t in_launch = x3q_in_launch_bytes(a, n, ks);  // (whole tiles; a caller that arms its workspace gets this form)
+    return in_launch > two_launches ? in_launch : two_launches;
 }
 
 int maua_conv_x3q_preferred(int n, int cin, int h, int w, int cout, int pad) {
@@ -842,6 +971,7 @@ static int conv3x3_x3q_entry(const float* x, const void* bank, float w_scale, co
         a.in_code_mask = in_code_mask;
     }
     a.ws = (workspace && workspace_bytes >= maua_conv_x3q_workspace_bytes(n, cin, h, w, cout, pad)) ? (float*)workspace : nullptr;
+    a.arrive = a.ws ? armed_counters(workspace) : nullptr;  // (the calling thread armed this workspace: small splits finish inside the launch)
     return conv_x3q_launch(a, n, w_scale, (hipStream_t)stream);
 }
 
@@ -875,6 +1005,7 @@ int maua_conv3x3_x3q_relu_pool(const float* x, const void* bank, float w_scale, 
                  "conv3x3_x3q_relu_pool: needs an output plane of 2 x 2 and more, cin %% 32 == 0, cout %% 8 == 0");
     // without a workspace: one pass over the channels, the epilogue holds complete sums and pools them itself
     a.ws = (workspace && workspace_bytes >= maua_conv_x3q_workspace_bytes(n, cin, h, w, cout, pad)) ? (float*)workspace : nullptr;
+    a.arrive = a.ws ? armed_counters(workspace) : nullptr;  // (the calling thread armed this workspace: small splits finish inside the launch)
     return conv_x3q_launch(a, n, w_scale, (hipStream_t)stream);
 }
 

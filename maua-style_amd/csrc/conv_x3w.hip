@@ -29,6 +29,7 @@
 namespace maua {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -172,9 +173,18 @@ __global__ void __launch_bounds__(1024) pack_dmat_x3w_batch_kernel(DmatPackBatch
 
 // UNPOOL: `x` is the POOLED map of a 2x2 / 2 max pool and `in_codes` its decision bytes; the input the convolution sees is the pool's
 // backward pass over them (pool2x2_bwd_codes_kernel's arithmetic), rebuilt while staging - the full-size gradient never exists.
+// The kernel's argument segment (ConvArgs is the first parameter): the in-launch finish re-reads its arguments from here behind the K loop
+__device__ __forceinline__ const ConvArgs* xw_kernel_arguments() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (const ConvArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    return nullptr;
+#endif
+}
+
 template <bool ACC, bool OM, bool POOL = false, bool UNPOOL = false>
 __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_inv_scale) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[XW_PATCH_BYTES + XW_W_BYTES + 16];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[XW_PATCH_BYTES + XW_W_BYTES + 32];  // (+ four maxima, the in-launch finish's three words)
     unsigned char* Pl = smem;                    // [part][octet][pos][16 B]
     unsigned char* Wl = smem + XW_PATCH_BYTES;   // [tap][part][octet][co][16 B]
     float* Ml = reinterpret_cast<float*>(smem + XW_PATCH_BYTES + XW_W_BYTES);  // per-wave maxima of the chunk being staged
@@ -201,6 +211,10 @@ __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_in
     const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (tile >= min(((int)(blockIdx.x & 7) + 1) * per_xcd, tiles_total)) return;  // whole workgroup leaves
     const int x0 = (tile % p.tiles_x) * 32, y0 = (tile / p.tiles_x) * XW_ROWS;
+    if (tid == 0) {  // for the in-launch finish of a split channel loop (behind the K loop; read there behind several barriers)
+        reinterpret_cast<int*>(Ml)[5] = (n * ntile + cotile) * tiles_total + tile;
+        reinterpret_cast<int*>(Ml)[6] = split;
+    }
 
     // Staging items of this thread: item k = (octet, position) number tid + 256 k.  voff = byte offset of the item's first
     // channel from the chunk's first plane; out-of-image positions and items past the end get an offset beyond the buffer's
@@ -645,8 +659,78 @@ __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_in
         d_[4] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_s_memrealtime());
     }
 #endif
+    // Split channel loop finished INSIDE the launch (round 6; conv_x3q.hip has the description): every split's workgroup leaves its partial
+    // sums in its slab (lane-linear, sixteen 16-byte vectors per thread, written through and drained) and draws a ticket; the last arriver
+    // of a tile adds the slabs in split order - conv_splitk_finish_kernel's additions - then the bias, and runs the one-pass epilogue.
+    // (Nothing of this phase lives across the K loop: tile number and split index wait in LDS, the arguments are read again.)
+    bool final_sums = p.ksplit <= 1;
+    const ConvArgs* kp = xw_kernel_arguments();
+    asm volatile("" : "+s"(kp));
+    if (kp->ksplit > 1 && kp->arrive != nullptr) {
+        const int ksplit = kp->ksplit;
+        const int unit = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(Ml)[5]);
+        const int split = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(Ml)[6]);
+        unsigned* const arrive = kp->arrive + unit;
+        const float* const bias = kp->bias;
+        constexpr unsigned SLAB = XW_COT * XW_ROWS * 32 * 4;  // 64 KiB
+        const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(kp->ws) + (int64_t)unit * ksplit * SLAB, 0,
+                                                                            (unsigned)ksplit * SLAB, 0x00020000);
+        const unsigned toff = (unsigned)tid * 16u;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const f32x16& m = master[q >> 3][(q >> 2) & 1];
+            const f32x4 v = {m[4 * (q & 3)], m[4 * (q & 3) + 1], m[4 * (q & 3) + 2], m[4 * (q & 3) + 3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srs, toff, (unsigned)split * SLAB + q * 4096u, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        unsigned* tick = reinterpret_cast<unsigned*>(Ml) + 4;
+        if (tid == 0) *tick = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if ((int)*tick != ksplit - 1) return;
+        if (tid == 0) __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int row = 0; row < 2; ++row)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][row][r] = 0.f;
+        for (int k = 0; k < ksplit; ++k) {
+            if (k == split) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int row = 0; row < 2; ++row) acc[t][row] += master[t][row];
+            } else {
+#pragma unroll
+                for (int q0 = 0; q0 < 16; q0 += 8) {
+                    u32x4 tq[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) tq[q] = __builtin_amdgcn_raw_buffer_load_b128(srs, toff, (unsigned)k * SLAB + (q0 + q) * 4096u, 16);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const f32x4 v = __builtin_bit_cast(f32x4, tq[q]);
+                        f32x16& a = acc[(q0 + q) >> 3][((q0 + q) >> 2) & 1];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a[4 * ((q0 + q) & 3) + e] += v[e];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float b0 = bias != nullptr ? bias[min(co, kp->Cout - 1)] : 0.f;
+                master[t][0][r] = acc[t][0][r] + b0;
+                master[t][1][r] = acc[t][1][r] + b0;
+            }
+        final_sums = true;
+    }
     // epilogue: lane holds pixel column j of rows y0 + 2 wave + {0, 1}; register r is output channel (r&3)+8*(r>>2)+4*half
-    if constexpr (POOL) {
+    if constexpr (POOL) if (final_sums) {
         // ReLU + the 2x2 / 2 max pool behind it: a wave's two rows and neighbouring lanes are exactly the windows, so the
         // full-size activation never goes to memory - only the pooled map and one decision byte per window (what
         // pool2x2_fwd_codes_kernel leaves: position of the first maximum in scan order, bit 2 = the maximum is <= 0; bytes laid out
@@ -692,7 +776,7 @@ __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_in
         const int oy = y0 + 2 * wave + row;
         const bool pvalid = oy < p.OH && ox < p.OW;
         const int64_t opix = (int64_t)oy * p.OW + ox;
-        if (p.ksplit > 1) {  // split-K: un-scaled partial sums, finished by conv_splitk_finish_kernel in split order
+        if (!final_sums) {  // split-K: un-scaled partial sums, finished by conv_splitk_finish_kernel in split order
             float* wsp = p.ws + (int64_t)blockIdx.z * p.Cout * out_plane;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -776,6 +860,16 @@ static float* g_xw_stamp = nullptr;
 extern "C" void maua_xw_set_stamp_buffer(float* buf) { g_xw_stamp = buf; }
 #endif
 
+// In-launch finish of a split channel loop (conv_x3q.hip): one 64 KiB slab per (image, channel tile, pixel tile, split), whole tiles.
+static size_t x3w_in_launch_bytes(const ConvArgs& a, int n, int ks) {
+    const int64_t tiles = (int64_t)((a.OW + 31) / 32) * ((a.OH + XW_ROWS - 1) / XW_ROWS), cot = (a.Cout + XW_COT - 1) / XW_COT;
+    return (size_t)n * cot * tiles * ks * (XW_COT * XW_ROWS * 32 * 4);
+}
+static bool x3w_finish_in_launch(const ConvArgs& a, int n, int ks) {
+    const int64_t units = (int64_t)n * ((a.Cout + XW_COT - 1) / XW_COT) * ((a.OW + 31) / 32) * ((a.OH + XW_ROWS - 1) / XW_ROWS);
+    return ks > 1 && a.arrive != nullptr && ks <= (int)tuning("finish_in_launch_max_ks", 4) && units <= ARRIVE_COUNTERS;
+}
+
 int conv_x3w_launch(const ConvArgs& a, int n, float w_scale, hipStream_t stream) {
     ConvArgs p = a;
 #ifdef XW_STAMP
@@ -787,12 +881,14 @@ int conv_x3w_launch(const ConvArgs& a, int n, float w_scale, hipStream_t stream)
     p.ksplit = ks;
     const int64_t cot = (a.Cout + XW_COT - 1) / XW_COT, per_xcd = (tiles + 7) / 8;
     dim3 grid((unsigned)(per_xcd * 8), (unsigned)cot, (unsigned)(n * ks));
-    const bool acc = ks == 1 && a.accumulate != 0, om = ks == 1 && a.omask != nullptr;
+    const bool whole = ks == 1 || x3w_finish_in_launch(a, n, ks);  // the launch's epilogue holds complete sums (one pass, or the last arriver's)
+    if (!whole) p.arrive = nullptr;
+    const bool acc = whole && a.accumulate != 0, om = whole && a.omask != nullptr;
     const float w_inv = 1.f / w_scale;
     {
         p.stagger = (int)tuning("x3w_stagger", 7);
     }
-    if (a.pool_codes && ks == 1) hipLaunchKernelGGL((conv_x3w_kernel<false, false, true>), grid, dim3(256), 0, stream, p, w_inv);
+    if (a.pool_codes && whole) hipLaunchKernelGGL((conv_x3w_kernel<false, false, true>), grid, dim3(256), 0, stream, p, w_inv);
     else if (a.in_codes && om) hipLaunchKernelGGL((conv_x3w_kernel<false, true, false, true>), grid, dim3(256), 0, stream, p, w_inv);
     else if (a.in_codes) hipLaunchKernelGGL((conv_x3w_kernel<false, false, false, true>), grid, dim3(256), 0, stream, p, w_inv);
     else if (acc && om) hipLaunchKernelGGL((conv_x3w_kernel<true, true>), grid, dim3(256), 0, stream, p, w_inv);
@@ -800,7 +896,7 @@ int conv_x3w_launch(const ConvArgs& a, int n, float w_scale, hipStream_t stream)
     else if (om) hipLaunchKernelGGL((conv_x3w_kernel<false, true>), grid, dim3(256), 0, stream, p, w_inv);
     else hipLaunchKernelGGL((conv_x3w_kernel<false, false>), grid, dim3(256), 0, stream, p, w_inv);
     int rc = check_launch("conv_x3w_kernel");
-    if (rc || ks == 1) return rc;
+    if (rc || whole) return rc;
     // (a split channel loop leaves partial sums: the ReLU + pool of a pooling launch then happen in the pass that adds them)
     return a.pool_codes ? conv_splitk_finish_pool(a, n, ks, stream) : conv_splitk_finish(a, n, ks, stream);
 }
@@ -886,7 +982,10 @@ size_t maua_conv_x3w_workspace_bytes(int n, int cin, int h, int w, int cout, int
     a.OW = w + 2 * pad - 2;
     if (a.OH <= 0 || a.OW <= 0) return 0;
     const int ks = x3w_choose_split(a, n);
-    return ks > 1 ? (size_t)n * ks * cout * a.OH * a.OW * sizeof(float) : 0;
+    if (ks <= 1) return 0;
+    const size_t two_launches = (size_t)n * ks * cout * a.OH * a.OW * sizeof(float);
+    const size_t in_launch = x3w_in_launch_bytes(a, n, ks);  // (whole tiles; a caller that arms its workspace gets this form)
+    return in_launch > two_launches ? in_launch : two_launches;
 }
 
 static int conv3x3_x3w_entry(const float* x, const void* bank, float w_scale, const float* bias, const float* out_relu_mask, float* y,
@@ -925,6 +1024,7 @@ static int conv3x3_x3w_entry(const float* x, const void* bank, float w_scale, co
         a.in_code_mask = in_code_mask;
     }
     a.ws = (workspace && workspace_bytes >= maua_conv_x3w_workspace_bytes(n, cin, h, w, cout, pad)) ? (float*)workspace : nullptr;
+    a.arrive = a.ws ? armed_counters(workspace) : nullptr;  // (the calling thread armed this workspace: small splits finish inside the launch)
     return conv_x3w_launch(a, n, w_scale, (hipStream_t)stream);
 }
 
@@ -969,6 +1069,7 @@ int maua_conv3x3_x3w_relu_pool(const float* x, const void* bank, float w_scale, 
                  "conv3x3_x3w_relu_pool: needs an output plane of 2 x 2 and more, cin %% 16 == 0, cout %% 8 == 0");
     // without a workspace: one pass over the channels, the epilogue holds complete sums and pools them itself
     a.ws = (workspace && workspace_bytes >= maua_conv_x3w_workspace_bytes(n, cin, h, w, cout, pad)) ? (float*)workspace : nullptr;
+    a.arrive = a.ws ? armed_counters(workspace) : nullptr;  // (the calling thread armed this workspace: small splits finish inside the launch)
     return conv_x3w_launch(a, n, w_scale, (hipStream_t)stream);
 }
 

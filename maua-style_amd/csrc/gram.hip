@@ -685,6 +685,14 @@ __global__ void __launch_bounds__(512, 1) gram_x3_partial128_batch_kernel(GramPa
 __device__ __forceinline__ double slab_sum(const float* __restrict__ base, int ksplit, int kstride) {
     double sd = 0.0;
     int k = 0;
+    // (round 6: thirty-two loads in flight first - the finishing launches were 22-33 us of dependent round trips of eight)
+    for (; k + 31 * kstride < ksplit; k += 32 * kstride) {
+        float v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = base[(int64_t)(k + u * kstride) * (GT * GT)];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) sd += (double)v[u];
+    }
     for (; k + 7 * kstride < ksplit; k += 8 * kstride) {
         float v[8];
 #pragma unroll

@@ -5,6 +5,7 @@ There is NO fallback: if the library cannot be loaded, or a kernel reports an er
 tensors; every call is enqueued on torch's current stream.
 """
 import ctypes
+import threading
 import os
 import sys
 
@@ -73,7 +74,7 @@ SIGNATURES = {
     "maua_conv_few_mfma_bank_bytes": (c_sz, []),
     "maua_conv_pack_filters_few_mfma": (c_i, [c_p, c_p, c_i, c_i, c_p]),
     "maua_conv_few_mfma_supported": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
-    "maua_conv3x3_few_mfma": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "maua_conv3x3_few_mfma": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "maua_space_to_depth": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "maua_axpy": (c_i, [c_p, c_p, c_f, c_i64, c_p]),
     "maua_sum_small": (c_i, [c_p, c_i, c_p, c_p]),
@@ -87,6 +88,7 @@ SIGNATURES = {
     "maua_set_tuning": (c_i, [ctypes.c_char_p, ctypes.c_double]),
     "maua_get_tuning": (ctypes.c_double, [ctypes.c_char_p, ctypes.c_double]),
     "maua_set_split_batch_hint": (None, [c_i]),
+    "maua_conv_arm_workspace": (c_i, [c_p, c_p, c_sz, c_i, c_p]),
     "maua_get_split_batch_hint": (c_i, []),
     "maua_conv_x3w_split": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "maua_conv_x3q_bank_bytes": (c_sz, [c_i, c_i]),
@@ -905,13 +907,14 @@ def conv_few_mfma_supported(n, cin, h, w, cout, pad):
     return bool(lib().maua_conv_few_mfma_supported(int(n), int(cin), int(h), int(w), int(cout), int(pad)))
 
 
-def conv3x3_few_mfma(gy, bank, cin, out=None, tile=0):
-    """Backward-data of the image layer on the matrix cores: gy (n, 64, h, w) -> (n, cin, h, w).  tile: 0 = the library's choice,
-    1 / 2 / 3 = 4 / 8 / 14 output rows x 62 columns per workgroup."""
+def conv3x3_few_mfma(gy, bank, cin, out=None, tile=0, accumulate=False):
+    """Backward-data of the image layer on the matrix cores: gy (n, 64, h, w) -> (n, cin, h, w) (accumulate: added to `out`).  tile: 0 = the
+    library's choice, 1 / 2 / 3 = 4 / 8 / 14 output rows x 62 columns per workgroup."""
     n, cout, h, w = gy.shape
     if out is None:
         out = torch.empty(n, cin, h, w, device=gy.device, dtype=torch.float32)
-    _check(lib().maua_conv3x3_few_mfma(_ptr(_f32(gy, "gy")), bank.data_ptr(), _ptr(out), n, cin, h, w, cout, int(tile), _stream()), "maua_conv3x3_few_mfma")
+    _check(lib().maua_conv3x3_few_mfma(_ptr(_f32(gy, "gy")), bank.data_ptr(), _ptr(out), n, cin, h, w, cout, int(tile), int(bool(accumulate)), _stream()),
+           "maua_conv3x3_few_mfma")
     return out
 
 
@@ -931,6 +934,28 @@ def depth_to_space(x, r, out, accumulate=False):
     _check(lib().maua_depth_to_space(_ptr(_f32(x, "x")), _ptr(out), n, c_out, r, qh, qw, out.shape[2], out.shape[3], int(accumulate), _stream()),
            "maua_depth_to_space")
     return out
+
+
+ARRIVAL_COUNTER_BYTES = 4096 * 4
+_ARMED = threading.local()
+
+
+def conv_arm_workspace(workspace, counters=None, zero=True):
+    """Arm `workspace` (a device tensor handed to the convolution launches of this host thread) for split channel loops that are finished
+    inside the producing launch (maua_conv_arm_workspace): returns the counters tensor (16 KiB, zeroed by the library here and left zeroed
+    by every launch) - keep it alive as long as the workspace is in use.  zero=False: only point this thread back at a workspace it armed
+    before (nothing is enqueued).  workspace None: disarm."""
+    if workspace is None:
+        _check(lib().maua_conv_arm_workspace(None, None, 0, 0, _stream()), "maua_conv_arm_workspace")
+        _ARMED.pair = None
+        return None
+    if counters is None:
+        counters = torch.empty(ARRIVAL_COUNTER_BYTES, dtype=torch.uint8, device=workspace.device)
+        zero = True
+    _check(lib().maua_conv_arm_workspace(workspace.data_ptr(), counters.data_ptr(), counters.numel() * counters.element_size(), int(bool(zero)),
+                                         _stream()), "maua_conv_arm_workspace")
+    _ARMED.pair = (workspace, counters)  # (the library holds raw pointers: both tensors stay alive while this thread is armed with them)
+    return counters
 
 
 def set_split_batch_hint(frames):

@@ -169,3 +169,12 @@ def test_no_packed_fp32_instruction_in_any_kernel_that_issues_mfma(libpath, tmp_
     assert len(mfma) >= 60, len(mfma)  # (the scan sees the kernels)
     both = [k for k, v in stats.items() if v[0] and v[1]]
     assert not both, both[:5]
+    # Round 6 (tools/soak_streams.py, profiles/probes_r06.md section 2): a kernel WITH packed fp32 instructions beside an MFMA kernel of
+    # another stream does lose results.  The kernels that keep them are a closed list - the L-BFGS sweeps, Adam, the bilinear resize: the
+    # update kernels run between an evaluation's last join and the next evaluation's first launch (optim.PixelOptimizer._lbfgs_move,
+    # tests/test_engine_gpu.py::test_packed_fp32_kernels_never_share_the_gpu_with_matrix_kernels), the resize between two scales.
+    packed = sorted(subprocess.run(["c++filt", k], capture_output=True, text=True).stdout.strip().split("(")[0].replace("void ", "")
+                    for k, v in stats.items() if v[0])
+    allowed = ("maua::lbfgs_pair_dots_kernel<", "maua::lbfgs_combine_kernel<", "maua::lbfgs_combine_v4_kernel", "maua::adam_kernel",
+               "maua::resize_bilinear_kernel")
+    assert packed and all(k.startswith(allowed) for k in packed), [k for k in packed if not k.startswith(allowed)]

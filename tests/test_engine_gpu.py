@@ -632,6 +632,79 @@ def test_frame_batch_is_bit_identical_to_frame_by_frame(weight_files, opt, S, ex
     assert not torch.equal(together[0], together[1])
 
 
+@pytest.mark.parametrize("opt", ["lbfgs", "adam"])
+def test_packed_fp32_kernels_never_share_the_gpu_with_matrix_kernels(weight_files, monkeypatch, opt):
+    """Round 6 (tools/soak_streams.py, profiles/probes_r06.md section 2): a kernel with packed fp32 instructions running BESIDE an MFMA
+    kernel of another stream can lose results in its upper lanes.  The library keeps such instructions in the L-BFGS sweeps, Adam and the
+    bilinear resize only (tests/test_abi.py checks the built library); the one place where kernels of different kinds meet on the GPU is
+    a frame batch's side streams.  This records every library call of a B = 3 frame batch (three iterations, eager launches) with the
+    stream it went to, and the engine's fork / join points, and checks the STRUCTURE: between a fork and its join - the only time two
+    streams hold work at once - the launches are either all free of packed fp32 or all free of MFMAs (the per-frame Gram / loss windows
+    hold matrix kernels and no update kernel; the update windows hold `maua_lbfgs_iterate` and nothing else), and outside those windows
+    everything is on one stream.  Frames are independent B = 1 problems (reference style.py:192-290)."""
+    import engine as engine_mod
+    import hip
+    import models
+    import optim
+    B, N, S = 3, 3, 64
+    style = synth.images(S)[1]
+    contents = torch.cat([synth.images(S, seed=50 + k)[0] for k in range(B)])
+    inits = torch.cat([synth.images(S, seed=60 + k)[2] for k in range(B)])
+    args = product_args(weight_files, [], optimizer=opt, S=S, N=N)
+    optim.set_model_args(args, S)
+    net, losses = models.load_model(args)
+    log = []
+
+    class Recorder:
+        def __init__(self, real):
+            self.real = real
+
+        def __getattr__(self, name):
+            fn = getattr(self.real, name)
+            if not name.startswith("maua_"):
+                return fn
+
+            def call(*a):
+                log.append((name, torch.cuda.current_stream().cuda_stream))
+                return fn(*a)
+            return call
+    real_fork, real_join = engine_mod.StyleEngine.fork, engine_mod.StyleEngine.join
+    monkeypatch.setattr(engine_mod.StyleEngine, "fork", lambda self: (log.append(("fork", 0)), real_fork(self))[1])
+    monkeypatch.setattr(engine_mod.StyleEngine, "join", lambda self: (real_join(self), log.append(("join", 0)))[0])
+    monkeypatch.setattr(hip, "_lib", Recorder(hip.lib()))
+    optim.optimize_frames(contents.cuda(), [style], inits.cuda(), N, args, net, losses)
+    torch.cuda.synchronize()
+    packed = {"maua_lbfgs_iterate", "maua_adam_step", "maua_resize_bilinear"}
+    host_only = {"maua_set_split_batch_hint", "maua_get_split_batch_hint", "maua_conv_arm_workspace", "maua_last_error", "maua_lbfgs_status",
+                 "maua_lbfgs_state_bytes", "maua_set_tuning", "maua_get_tuning"}
+    is_matrix = lambda n: n.startswith(("maua_conv", "maua_gram_fwd", "maua_gram_partial", "maua_gram_bwd")) and "workspace_bytes" not in n \
+        and "_supported" not in n and "_preferred" not in n and "_split" not in n and "bank_bytes" not in n and "pack" not in n
+    window, windows, outside_streams = None, [], set()
+    for name, stream in log:
+        if name == "fork":
+            window = [] if window is None else window
+        elif name == "join":
+            assert window is not None
+            windows.append(window)
+            window = None
+        elif name in host_only or name.endswith(("_bytes", "_supported", "_preferred", "_split")):
+            continue
+        elif window is not None:
+            window.append((name, stream))
+        else:
+            outside_streams.add(stream)
+    assert window is None and len(outside_streams) == 1, outside_streams
+    with_packed = [w for w in windows if any(n in packed for n, _ in w)]
+    with_matrix = [w for w in windows if any(is_matrix(n) for n, _ in w)]
+    assert with_matrix and all(len({s_ for _, s_ in w}) > 1 for w in with_matrix)         # the side streams really are in use
+    for w in with_packed:
+        assert all(n in packed for n, _ in w), sorted({n for n, _ in w})                    # an update window holds update kernels only
+    if opt == "lbfgs":
+        assert len(with_packed) == N and all(len(w) == B for w in with_packed)
+    else:
+        assert not with_packed and sum(1 for n, _ in log if n == "maua_adam_step") >= N      # Adam: one launch for the batch, on the main stream
+
+
 @pytest.mark.parametrize("opt,N", [("lbfgs", 5), ("lbfgs", 10), ("adam", 5), ("adam", 10)])
 def test_plain_optimize_and_frame_batch_meet_the_fp64_arbiter_across_routes(weight_files, opt, N):
     """ACROSS kernel routes there is no bit identity to assert: a plain optim.optimize call plans for one image, a frame batch for its
@@ -861,6 +934,49 @@ def test_pool_in_the_convolution_epilogue_changes_no_bit(weight_files, monkeypat
     assert res["0"][2] == 0 and res["1"][2] >= 2, (res["0"][2], res["1"][2])
     assert torch.isfinite(res["1"][1]).all()
     assert torch.equal(res["0"][0], res["1"][0]) and torch.equal(res["0"][1], res["1"][1])
+
+
+@pytest.mark.parametrize("S", [64, 256, 512])
+def test_auxiliary_stream_changes_no_bit(weight_files, monkeypatch, S):
+    """Round 6: TV, the content loss's gradient seed, the packed D banks and the ledger's sum run on an auxiliary stream beside the
+    convolutions (engine._aux_plan): the TV gradient is written FIRST and the image layer's backward pass adds itself to it, the content
+    seed is written when relu4_2 exists and conv4_3's backward pass adds itself and masks the sum.  Same kernels, commuting additions:
+    losses, total and pixel gradient are the same bits as with everything in one queue - eagerly launched and replayed from a captured
+    graph (the auxiliary stream is a branch of the graph), on poisoned buffers; and the plan really moved the launches."""
+    import engine
+    import optim
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setitem(__import__("plan").OVERRIDES, "aux_stream", flag)
+        monkeypatch.setenv("MAUA_DEBUG_POISON", "1")
+        args = product_args(weight_files, S=S)
+        content, style, init = synth.images(S)
+        net, losses = build(args, content, [style], S)
+        eng = engine.StyleEngine(net, losses)
+        x = init.cuda()
+        slots, total, grad = eng.feval(x)
+        torch.cuda.synchronize()
+        eager = (slots.clone().cpu(), total.clone().cpu(), grad.clone().cpu())
+        slots, total, grad = eng.feval(x, capture=True)
+        slots, total, grad = eng.feval(x, capture=True)
+        torch.cuda.synchronize()
+        replay = (slots.clone().cpu(), total.clone().cpu(), grad.clone().cpu())
+        aux, early = eng._aux_plan(x)
+        res[flag] = (eager, replay, aux is not None, early)
+        # six L-BFGS iterations through the captured whole-iteration graph
+        args.hip_graph = True
+        opt = optim.PixelOptimizer(net, losses, init, args)
+        for _ in range(6):
+            opt.step()
+        torch.cuda.synchronize()
+        res[flag] += (opt.x.clone().cpu(),)
+    assert not res["0"][2] and res["1"][2]
+    early = res["1"][3]
+    assert early["tv"] is not None and len(early["content"]) == 1 and len(early["seeded_convs"]) == 1 and early["ledger"]
+    for k in range(3):
+        assert torch.equal(res["0"][0][k], res["1"][0][k]) and torch.equal(res["0"][0][k], res["1"][1][k]) and torch.equal(res["0"][1][k], res["1"][1][k])
+    assert torch.isfinite(res["1"][0][2]).all() and float(res["1"][0][1]) > 0
+    assert torch.equal(res["0"][4], res["1"][4])
 
 
 def test_gram_slabs_from_the_image_layer_change_nothing_but_rounding(weight_files, monkeypatch):
