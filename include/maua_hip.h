@@ -385,15 +385,13 @@ int maua_fill(float* x, int64_t count, float value, maua_stream_t stream);
  * padding=1), /root/reference/models.py:129-130) on the matrix cores (conv_few_mfma.hip, round 5): per gradient pixel the 27 (tap, channel)
  * sums over the 64 channels as one bf16x6 product block, then nine values gathered per output pixel and channel.
  * maua_conv_pack_filters_few_mfma: OIHW weights (64, cin, 3, 3) -> the bank (maua_conv_few_mfma_bank_bytes() bytes; once per weight set).
- * maua_conv3x3_few_mfma: gy (n, 64, h, w) -> gx (n, cin, h, w), written whole (`accumulate`: added to what gx holds - the TV loss's
- * gradient, which the engine computes beside the forward pass since round 6); `tile`: 0 = the library's choice, 1 / 2 / 3 = 4 / 8 / 14
+ * maua_conv3x3_few_mfma: gy (n, 64, h, w) -> gx (n, cin, h, w), written whole; `tile`: 0 = the library's choice, 1 / 2 / 3 = 4 / 8 / 14
  * output rows x 62 columns per workgroup.
  * maua_conv_few_mfma_supported: geometry check (64 filters, 1-3 channels, padding 1, planes whose 64 gradient maps stay below 2 GiB). */
 size_t maua_conv_few_mfma_bank_bytes(void);
 int maua_conv_pack_filters_few_mfma(const float* w_oihw, void* bank, int cout, int cin, maua_stream_t stream);
 int maua_conv_few_mfma_supported(int n, int cin, int h, int w, int cout, int pad);
-int maua_conv3x3_few_mfma(const float* gy, const void* bank, float* gx, int n, int cin, int h, int w, int cout, int tile, int accumulate,
-                          maua_stream_t stream);
+int maua_conv3x3_few_mfma(const float* gy, const void* bank, float* gx, int n, int cin, int h, int w, int cout, int tile, maua_stream_t stream);
 
 /* The inverse regrouping: out[n][(ry r + rx) c_in + c][qy][qx] = in[n][c][r qy + ry][r qx + rx], 0 for pixels beyond h x w - the head of the
  * same layer's FORWARD pass as a 3x3 stride-1 convolution 48 -> 96 over 256 x 256 sites (models.conv_strided_fwd_as_3x3, conv_x3w.hip). */

@@ -68,7 +68,6 @@ struct FewMfmaArgs {
     const unsigned char* bank;
     float* gx;
     int H, W, co;
-    int accumulate;               // gx += (the TV gradient computed beside the forward pass is already there, round 6) instead of gx =
     int tiles_x, tiles, per_xcd;  // grid x = 8 per_xcd workgroups: workgroup id takes tile (id % 8) per_xcd + id / 8 - XCD k (ids = k mod 8) walks
                                   // the k-th contiguous band of the row-major tile list, its CUs side by side (conv_x3w.hip's order; the
                                   // dispatch order - tile = id - reads the same bytes at half the rate: tools/mfma_probe/stage_bw.hip)
@@ -161,8 +160,7 @@ __global__ void __launch_bounds__(256, 2) conv_few_mfma_kernel(FewMfmaArgs p) {
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) s += t0[((ky * 3 + kx) * co + c) * TPL - ky * FM_TC - kx];
-            float* o = p.gx + ((int64_t)img * co + c) * plane + (int64_t)Y * p.W + X;
-            *o = p.accumulate ? *o + s : s;
+            p.gx[((int64_t)img * co + c) * plane + (int64_t)Y * p.W + X] = s;
         }
     }
 }
@@ -190,13 +188,12 @@ int maua_conv_few_mfma_supported(int n, int cin, int h, int w, int cout, int pad
 }
 
 // tile: 0 = the library's choice (4 output rows per workgroup below a million pixels, 8 from there); 1 / 2 / 3 = 4 / 8 / 14 rows x 62 columns
-int maua_conv3x3_few_mfma(const float* gy, const void* bank, float* gx, int n, int cin, int h, int w, int cout, int tile, int accumulate,
-                          maua_stream_t stream) {
+int maua_conv3x3_few_mfma(const float* gy, const void* bank, float* gx, int n, int cin, int h, int w, int cout, int tile, maua_stream_t stream) {
     MAUA_REQUIRE(gy && bank && gx, MAUA_E_INVAL, "conv3x3_few_mfma: null pointer");
     MAUA_REQUIRE(maua_conv_few_mfma_supported(n, cin, h, w, cout, 1), MAUA_E_UNSUPPORTED, "conv3x3_few_mfma: unsupported geometry");
     MAUA_REQUIRE(tile >= 0 && tile <= 3, MAUA_E_INVAL, "conv3x3_few_mfma: tile code 0 - 3");
     if (tile == 0) tile = (int64_t)h * w < 1000000 ? 1 : 2;
-    FewMfmaArgs p{gy, (const unsigned char*)bank, gx, h, w, cin, accumulate ? 1 : 0, 0, 0, 0};
+    FewMfmaArgs p{gy, (const unsigned char*)bank, gx, h, w, cin, 0, 0, 0};
     static unsigned long long attr[4] = {0, 0, 0, 0};
     const int rows = tile == 1 ? 4 : tile == 2 ? 8 : 14;
     const int lds = 27 * (rows + 2) * FM_TC * 4;

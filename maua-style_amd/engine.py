@@ -310,8 +310,8 @@ class StyleEngine:
                 if t is not None and not t.is_meta:
                     t.fill_(float("nan"))
             self.ws[:self.ws.numel() // 4 * 4].view(torch.float32)[:] = float("nan")
-        # split channel loops of the convolutions are finished inside the producing launch (hip.conv_arm_workspace): the arrival counters
-        # belong to this workspace; armed again at every _run (the setting is per host thread and another engine may have armed its own)
+        # planner field finish_in_launch: split channel loops of the convolutions finished inside the producing launch
+        # (hip.conv_arm_workspace; measured neutral, off by default): the arrival counters belong to this workspace
         self.ws_counters = torch.empty(hip.ARRIVAL_COUNTER_BYTES, dtype=torch.uint8, device=dev) if plan.on("finish_in_launch") and ws > 0 else None
         self.ws_armed_epoch = None
         # Independent frames: the per-frame kernels (Gram, losses, Gram backward, optimiser) of different frames share
@@ -337,16 +337,6 @@ class StyleEngine:
             self.side_ws = [torch.empty(small, dtype=torch.uint8, device=dev) for _ in range(ns)]
             self.ev_main = torch.cuda.Event()
             self.ev_side = [torch.cuda.Event() for _ in range(ns)]
-        # Round 6: the small kernels of a single image's evaluation that nothing waits for at once - the TV loss and its gradient, the
-        # content loss and its gradient seed, the packed banks of the D matrices, the sum of the loss ledger - ride on ONE auxiliary stream
-        # beside the convolutions instead of standing in their queue (each is 5-25 us of launch latency for kilobytes to a few MB: 42 us of
-        # a 1.78 ms iteration at 512 x 512, 34 of 0.92 ms at 256 x 256).  Same kernels, same values, same fixed summation orders: bit-identical
-        # results (tests/test_engine_gpu.py::test_auxiliary_stream_changes_no_bit).  None of them has packed fp32 instructions (what may run
-        # beside MFMA kernels of another stream: tests/test_abi.py).  Planner field aux_stream.
-        self.aux, self.aux_ev = None, {}
-        if B == 1 and self.ledger is not None and not self.style_aside and plan.on("aux_stream"):
-            self.aux = torch.cuda.Stream(device=dev)
-            self.aux_ev = {k: torch.cuda.Event() for k in ("start", "content", "gram", "tv", "seed", "pack", "end")}
 
     # -- one evaluation --------------------------------------------------------------------------------
     def _style_terms(self, s, B):
@@ -409,9 +399,9 @@ class StyleEngine:
         return True
 
     def _arm(self):
-        """This host thread's convolution launches on self.ws finish small splits in the launch (maua_conv_arm_workspace).  The counters are
-        zeroed ONCE per workspace (the memset must not be part of a captured iteration: every launch leaves them zeroed); later calls
-        only point the thread-local setting back at this engine's workspace."""
+        """This host thread's convolution launches on self.ws finish small splits in the launch (maua_conv_arm_workspace) when the planner
+        field finish_in_launch is on.  The counters are zeroed ONCE per workspace (the memset must not be part of a captured iteration:
+        every launch leaves them zeroed); later calls only point the thread-local setting back at this engine's workspace."""
         if self.ws_counters is None:
             hip.conv_arm_workspace(None)
             return
@@ -420,47 +410,6 @@ class StyleEngine:
             self.ws_armed_epoch = (self.ws.data_ptr(), self.ws_counters.data_ptr())
         else:
             hip.conv_arm_workspace(self.ws, self.ws_counters, zero=False)
-
-    def _aux_plan(self, x):
-        """(auxiliary stream or None, what runs on it early) for this evaluation - decided from the plan alone, so a captured graph and an
-        eager evaluation take the same launches:
-          tv       the TV step, when the image layer's backward pass runs on conv_few_mfma (it can add itself to a gradient that is there);
-          content  ids of the content steps whose seed is written beside the forward pass: plain (unweighted) losses on an activation whose
-                   only other reader is a 3x3 convolution that runs conv3x3_mfma in the backward pass (it accumulates and masks), with an
-                   active loss deeper in the network (something flows into that convolution);
-          seeded_convs  ids of those convolutions;   ledger  whether every loss record is written before the backward pass starts."""
-        none = (None, {"tv": None, "content": set(), "seeded_convs": set(), "ledger": False})
-        if self.aux is None or self.timer is not None or x.shape[0] != 1 or self.ledger is None:
-            return none
-        a = self.act
-        early = {"tv": None, "content": set(), "seeded_convs": set(), "ledger": False}
-        order = {id(s): k for k, s in enumerate(self.steps)}
-        active = [s for s in self.steps if s.kind in ("style", "content") and self._active(s, a[s.src].shape)]
-        first_conv = next((s for s in self.steps if s.kind == "conv" and s.src == 0), None)
-        tv = next((s for s in self.steps if s.kind == "tv"), None)
-        if tv is not None and first_conv is not None and active and id(first_conv) not in self.fused_unpool and \
-                id(first_conv) not in self.fused_gram and not (self.x6_bwd and self._x6_ok(first_conv, first_conv.mod.in_channels)) and \
-                models_mod.conv_few_is_mfma(first_conv.mod, x.shape[0], *a[first_conv.dst].shape[2:]):
-            early["tv"] = tv
-        for sc in active:
-            if sc.kind != "content" or getattr(sc.mod, "weights", None) is not None or "temporal" in getattr(sc.mod, "name", ""):
-                continue
-            readers = [s for s in self.steps if s is not sc and getattr(s, "src", None) == sc.src and
-                       (s.kind in ("conv", "pool", "relu") or s in active)]
-            if len(readers) != 1 or readers[0].kind != "conv":
-                continue
-            c = readers[0]
-            fg = self.fused_gram.get(id(c))
-            if id(c) in self.fused_unpool or (fg is not None and self._active(fg[0], a[c.src].shape)) or \
-                    not (self.x6_bwd and self._x6_ok(c, c.mod.in_channels)) or c.k != 3 or c.stride != 1:
-                continue
-            if not any(order[id(s2)] > order[id(c)] for s2 in active):
-                continue  # nothing deeper: the convolution's backward pass does not run at all
-            early["content"].add(id(sc))
-            early["seeded_convs"].add(id(c))
-        content_active = [s for s in active if s.kind == "content"]
-        early["ledger"] = (tv is None or early["tv"] is not None) and all(id(s) in early["content"] for s in content_active)
-        return self.aux, early
 
     def fork(self):
         """Side streams wait for everything enqueued on the current stream so far."""
@@ -538,29 +487,8 @@ class StyleEngine:
         forked = False
         batch = []
         emitted = set()  # style steps whose Gram slabs came out of the image layer's launch
-        aux, early = self._aux_plan(x)
-        main = torch.cuda.current_stream()
-        if aux is not None:
-            self.aux_ev["start"].record(main)
-            aux.wait_event(self.aux_ev["start"])
-            if early["tv"] is not None:  # g[image] = the TV gradient now; the image layer's backward pass adds itself to it at the end
-                with torch.cuda.stream(aux):
-                    hip.tv_fwd_bwd_ledger(a[0], g[0], early["tv"].mod.strength, False, self.ledger[0], early["tv"].slot)
-                    self.aux_ev["tv"].record(aux)
         # ---------------- forward
         for s in self.steps:
-            if s.kind == "content" and aux is not None and id(s) in early["content"]:
-                # the content loss and its gradient seed as soon as the activation exists: g[act] = gw 2 / N (F - T), unmasked; the backward
-                # pass of the convolution behind it ADDS itself and applies the ReLU mask to the sum (same bits: the addition commutes)
-                lw, gw = self._coefficients(s)
-                n_el = a[s.src].nelement()
-                self.aux_ev["content"].record(main)
-                aux.wait_event(self.aux_ev["content"])
-                with torch.cuda.stream(aux):
-                    hip.mse_fwd_bwd_ledger(a[s.src], s.mod.target, g[s.src], lw / n_el, gw * 2.0 / n_el, False, self.ledger[0], s.slot,
-                                           mask_grad_by_x=False)
-                    self.aux_ev["seed"].record(aux)
-                continue
             if s.kind == "conv":
                 fl, nb = self._conv_work(s, a[s.src].shape, a[s.dst].shape, False)
                 if id(s) in self.fused_pool:
@@ -732,41 +660,20 @@ class StyleEngine:
                 for d, b, i in packs:
                     hip.conv_pack_dmat_x3w(d, b, i)
                 packs = []
-            pack_ctx = contextlib.nullcontext()
-            if aux is not None and packs:  # (the banks are read by the backward passes of conv3_2 / 2_2 / 1_2: far behind)
-                self.aux_ev["gram"].record(main)
-                aux.wait_event(self.aux_ev["gram"])
-                pack_ctx = torch.cuda.stream(aux)
-            with pack_ctx:
-                for k0 in range(0, len(packs), 4):  # the one-tap banks of the fused layers' D matrices, one launch
-                    grp = packs[k0:k0 + 4]
-                    key = tuple((d.data_ptr(), b.data_ptr(), i.data_ptr()) for d, b, i in grp)
-                    pk = self._gram_batches.get(("pack", k0))
-                    if pk is None or pk[0] != key:
-                        pk = (key, hip.DmatPackBatch(grp))
-                        self._gram_batches[("pack", k0)] = pk
-                    pk[1].run()
-                if aux is not None and packs:
-                    self.aux_ev["pack"].record(aux)
-                    early["packs_pending"] = True
-        if aux is not None and early["ledger"]:
-            # every loss record of this evaluation is written (TV and content on this stream, the style layers' by the finishing launch):
-            # the ledger's sum runs here, beside the backward pass, instead of behind it
-            if not early.get("packs_pending"):
-                self.aux_ev["gram"].record(main)
-                aux.wait_event(self.aux_ev["gram"])
-            with torch.cuda.stream(aux):
-                hip.loss_ledger_sum(self.ledger, self.slots_all, self.total, self.slots_f64)
-        if aux is not None:
-            self.aux_ev["end"].record(aux)
+            for k0 in range(0, len(packs), 4):  # the one-tap banks of the fused layers' D matrices, one launch
+                grp = packs[k0:k0 + 4]
+                key = tuple((d.data_ptr(), b.data_ptr(), i.data_ptr()) for d, b, i in grp)
+                pk = self._gram_batches.get(("pack", k0))
+                if pk is None or pk[0] != key:
+                    pk = (key, hip.DmatPackBatch(grp))
+                    self._gram_batches[("pack", k0)] = pk
+                pk[1].run()
         # ---------------- backward
         # Gradient buffers of fused conv+ReLU activations are kept PRE-MASKED: the last kernel that writes g[k] (the
         # backward of the consumer, or the last loss term attached to k) zeroes it where a[k] <= 0, so no backward-data
         # pass has to apply threshold_backward while it stages its input.
         final_writer = {}
         for s in self.steps:  # forward order == reverse of execution order: the first hit per activation wins
-            if aux is not None and id(s) in early["content"]:
-                continue  # (its seed was written first; the convolution behind it writes last)
             if s.kind in ("conv", "pool") or (s.kind in ("style", "content") and self._active(s, a[s.src].shape)):
                 final_writer.setdefault(s.src, s)
         relu_acts = {s.dst for s in self.steps if s.kind == "conv" and s.relu}
@@ -857,8 +764,6 @@ class StyleEngine:
                         self.dmat[id(s)], f, self.mean[id(s)], g[s.src], acc, workspace=self.ws, relu_mask=rm))
                     cur = s.src
             elif s.kind == "content":
-                if aux is not None and id(s) in early["content"]:
-                    continue  # (done beside the forward pass; the convolution's backward pass added itself to the seed)
                 if self._active(s, a[s.src].shape):
                     lw, gw = self._coefficients(s)
                     n = a[s.src].nelement()
@@ -873,9 +778,7 @@ class StyleEngine:
                                         self.slots[s.slot:s.slot + 1], workspace=self.ws, mask_grad_by_x=premask(s))
                     cur = s.src
             elif s.kind == "tv":
-                if aux is not None and early["tv"] is s:
-                    assert cur == 0  # (the image layer's backward pass added itself to the TV gradient)
-                elif self.ledger is not None:
+                if self.ledger is not None:
                     hip.tv_fwd_bwd_ledger(a[0], g[0], s.mod.strength, cur == 0, self.ledger[0], s.slot)
                 else:
                     hip.tv_fwd_bwd(a[0], g[0], s.mod.strength, cur == 0, self.slots[s.slot:s.slot + 1], workspace=self.ws)
@@ -888,15 +791,6 @@ class StyleEngine:
                 im = a[s.src] if premask(s) else None
                 fg = self.fused_gram.get(id(s))
                 with_gram = fg is not None and self._active(fg[0], a[s.src].shape) and premask(fg[0])
-                if aux is not None and with_gram and early.get("packs_pending"):
-                    main.wait_event(self.aux_ev["pack"])  # the D banks are packed on the auxiliary stream
-                    early["packs_pending"] = False
-                seeded = aux is not None and id(s) in early["seeded_convs"]  # g[s.src] holds the content loss's seed: add to it
-                if seeded:
-                    main.wait_event(self.aux_ev["seed"])
-                tv_first = aux is not None and early["tv"] is not None and s.src == 0  # g[image] holds the TV gradient: add to it
-                if tv_first:
-                    main.wait_event(self.aux_ev["tv"])
                 up = self.fused_unpool.get(id(s))
                 if up is not None:  # from the pooled map's gradient and the pool's decisions (the pool step below was skipped)
                     c, n = a[s.src].shape[1], a[s.src][0].nelement()
@@ -912,8 +806,7 @@ class StyleEngine:
                     fused_done.add(id(fg[0]))
                 elif self.x6_bwd and self._x6_ok(s, s.mod.in_channels):
                     self._timed("conv3x3_split_bwd", fl, nb, lambda: models_mod.conv3x3_mfma(
-                        g[s.dst], s.mod, True, out=g[s.src], out_relu_mask=im, accumulate=seeded, workspace=self.ws,
-                        pool_group=id(s) in self.pool_groups))
+                        g[s.dst], s.mod, True, out=g[s.src], out_relu_mask=im, workspace=self.ws, pool_group=id(s) in self.pool_groups))
                 elif self.x6_bwd and models_mod.conv1x1_is_mfma(s.mod, True):
                     self._timed("conv_1x1_bwd", fl, nb, lambda: models_mod.conv1x1_mfma(
                         g[s.dst], s.mod, True, out=g[s.src], out_relu_mask=im, workspace=self.ws))
@@ -921,7 +814,7 @@ class StyleEngine:
                     self._timed("conv_5x5_bwd", fl, nb, lambda: models_mod.conv5x5_mfma(
                         g[s.dst], s.mod, True, out=g[s.src], out_relu_mask=im, workspace=self.ws))
                 elif im is None and models_mod.conv_few_is_mfma(s.mod, *g[s.dst].shape[0:1], *g[s.dst].shape[2:]):
-                    self._timed("conv_other_bwd", fl, nb, lambda: models_mod.conv_few_mfma(g[s.dst], s.mod, g[s.src], accumulate=tv_first))
+                    self._timed("conv_other_bwd", fl, nb, lambda: models_mod.conv_few_mfma(g[s.dst], s.mod, g[s.src]))
                 elif id(s) in self.strided_sites and im is None:
                     self._timed("conv_other_bwd", fl, nb, lambda: models_mod.conv_strided_bwd_as_3x3(
                         g[s.dst], s.mod, g[s.src], workspace=self.ws, sites=self.strided_sites[id(s)]))
@@ -947,10 +840,6 @@ class StyleEngine:
                 cur = s.src
         if cur != 0:
             hip.fill_(g[0], 0.0)
-        if aux is not None:
-            main.wait_event(self.aux_ev["end"])  # everything the auxiliary stream did belongs to this evaluation
-            if early["ledger"]:
-                return
         if self.ledger is not None:  # (B == 1 or independent frames: no per-module terms to fold afterwards)
             hip.loss_ledger_sum(self.ledger, self.slots_all, self.total, self.slots_f64)
             return

@@ -74,7 +74,7 @@ SIGNATURES = {
     "maua_conv_few_mfma_bank_bytes": (c_sz, []),
     "maua_conv_pack_filters_few_mfma": (c_i, [c_p, c_p, c_i, c_i, c_p]),
     "maua_conv_few_mfma_supported": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
-    "maua_conv3x3_few_mfma": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "maua_conv3x3_few_mfma": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "maua_space_to_depth": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "maua_axpy": (c_i, [c_p, c_p, c_f, c_i64, c_p]),
     "maua_sum_small": (c_i, [c_p, c_i, c_p, c_p]),
@@ -907,14 +907,13 @@ def conv_few_mfma_supported(n, cin, h, w, cout, pad):
     return bool(lib().maua_conv_few_mfma_supported(int(n), int(cin), int(h), int(w), int(cout), int(pad)))
 
 
-def conv3x3_few_mfma(gy, bank, cin, out=None, tile=0, accumulate=False):
-    """Backward-data of the image layer on the matrix cores: gy (n, 64, h, w) -> (n, cin, h, w) (accumulate: added to `out`).  tile: 0 = the
-    library's choice, 1 / 2 / 3 = 4 / 8 / 14 output rows x 62 columns per workgroup."""
+def conv3x3_few_mfma(gy, bank, cin, out=None, tile=0):
+    """Backward-data of the image layer on the matrix cores: gy (n, 64, h, w) -> (n, cin, h, w).  tile: 0 = the library's choice,
+    1 / 2 / 3 = 4 / 8 / 14 output rows x 62 columns per workgroup."""
     n, cout, h, w = gy.shape
     if out is None:
         out = torch.empty(n, cin, h, w, device=gy.device, dtype=torch.float32)
-    _check(lib().maua_conv3x3_few_mfma(_ptr(_f32(gy, "gy")), bank.data_ptr(), _ptr(out), n, cin, h, w, cout, int(tile), int(bool(accumulate)), _stream()),
-           "maua_conv3x3_few_mfma")
+    _check(lib().maua_conv3x3_few_mfma(_ptr(_f32(gy, "gy")), bank.data_ptr(), _ptr(out), n, cin, h, w, cout, int(tile), _stream()), "maua_conv3x3_few_mfma")
     return out
 
 

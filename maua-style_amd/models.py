@@ -275,10 +275,10 @@ def conv_few_is_mfma(mod, n, h, w):
     return plan.on("few_mfma") and _x6_mode()[1] and k == 3 and stride == 1 and pad == 1 and hip.conv_few_mfma_supported(n, mod.in_channels, h, w, mod.out_channels, pad)
 
 
-def conv_few_mfma(gy, mod, out, accumulate=False):
-    """gx (+)= conv_backward(gy) of the image layer on conv_few_mfma.hip (the library picks the tile height)."""
-    _route("conv_few_mfma", gy, mod.in_channels, 1, True, "4 / 8 x 62 px, bf16x6", accumulate=accumulate)
-    return hip.conv3x3_few_mfma(gy, mod.bank_few_mfma(), mod.in_channels, out=out, accumulate=accumulate)
+def conv_few_mfma(gy, mod, out):
+    """gx = conv_backward(gy) of the image layer on conv_few_mfma.hip (the library picks the tile height)."""
+    _route("conv_few_mfma", gy, mod.in_channels, 1, True, "4 / 8 x 62 px, bf16x6")
+    return hip.conv3x3_few_mfma(gy, mod.bank_few_mfma(), mod.in_channels, out=out)
 
 
 def conv_strided_fwd_is_3x3(mod, h, w):

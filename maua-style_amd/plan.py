@@ -44,7 +44,6 @@ FIELDS = {
     "fuse_gram_max_c": ("256", "host", "style layers of at most this many channels have their Gram backward ride in the next convolution's backward launch (0: never)"),
     "image_gram": ("1", "host", "the image layer's launch leaves the Gram slabs of relu1_1"),
     "finish_in_launch": ("0", "host", "1: the engine arms its split-K workspace - small splits are added up by the last workgroup to arrive at a tile, no finishing launch (bit-identical; measured neutral at 512 x 512: the last arriver's serial chain costs what the launch cost, profiles/probes_r06.md section 1)"),
-    "aux_stream": ("1", "host", "single images: TV, content MSE, the D banks and the ledger sum run on an auxiliary stream beside the convolutions (bit-identical)"),
     "dmat_pack_batch": ("1", "host", "one launch packs the D matrices of all fused style layers"),
     "style_stream": ("auto", "host", "Gram / loss chains of a single image on a side stream: 0, 1, or auto (from 1536 x 1536 pixels)"),
     "side_streams": ("4", "host", "side streams for the per-frame kernels of independent frames (0: none)"),

@@ -137,7 +137,7 @@ def test_full_size_lbfgs_descends(setup):
     """torch.optim.LBFGS without a line search (what the reference runs, /root/reference/optim.py:170-199) on this objective is chaotic in
     its first steps: the pair (s, y) of the first tiny move amplifies whatever the gradient's ReLU / max-pool decisions do between two
     nearby images, and the third evaluation lands on a spike whose height varies by two orders of magnitude under a 1e-6 relative change of
-    the start image or any change of a kernel route (measured, tools/_build/dbg4.py in round 5: 5.6e5 ... 5.9e7 from 5.41e5, the
+    the start image or any change of a kernel route (measured, tools/probes_r05/dbg4.py in round 5: 5.6e5 ... 5.9e7 from 5.41e5, the
     reference's own arithmetic included).  The update recovers from every one of them; how many iterations that takes depends on the
     spike.  So: forty iterations (a spike of 6e7 is back under the start value after ~25), a finite loss at every step, descent at the end."""
     import optim

@@ -1213,3 +1213,22 @@ def test_soak_no_silent_differences_at_the_1e_6_level():
         env = dict(os.environ, MAUA_PLAN=flag)
         r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "soak_kernels.py"), "200"], env=env, capture_output=True, text=True, timeout=1200)
         assert r.returncode == 0 and "differing launches in all: 0" in r.stdout, (flag, r.stdout[-2000:], r.stderr[-1500:])
+
+
+def test_stream_soak_of_the_pairings_the_product_runs():
+    """Round 6 (profiles/probes_r06.md section 2): tools/soak_streams.py runs kernels on two streams at once and compares every result of
+    the one with a run made alone.  It found what round 5 suspected: a kernel WITH packed fp32 instructions beside an MFMA kernel of
+    another stream loses results (conv3x3_few_out beside conv1x1_x3 under the MFMA-padding build: 16951 of 17008 runs, lanes 32-63; the
+    L-BFGS sweeps beside the 128 x 128 Gram kernel in the product build: 2-14 of ~2000 runs).  The product never forms such a pair - the
+    kernels that keep packed fp32 (L-BFGS sweeps, Adam, resize) run between an evaluation's last join and the next one's first launch
+    (test_packed_fp32_kernels_never_share_the_gpu_with_matrix_kernels), everything that can stand beside an MFMA kernel is built without
+    them (tests/test_abi.py) - and this soaks the pairs it DOES form, a frame batch's side streams (reference style.py:192-290: frames are
+    independent problems): the per-frame loss / pooling kernels and the split-K finishing kernels beside the per-frame Gram and Gram-backward
+    kernels, and the L-BFGS update of one frame beside another frame's.  ~2.5 s per pairing, every victim result compared bit for bit."""
+    import subprocess
+    import sys
+    pairs = ",".join(f"{v}:{a}" for v in ("pointwise", "splitk_finish") for a in ("gram128", "gram64", "conv1x1")) + ",lbfgs_512:lbfgs,lbfgs_128:lbfgs"
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "soak_streams.py"), "--seconds", "2.5", "--pairs", pairs],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "# total differing runs: 0;" in r.stdout, (r.stdout[-3000:], r.stderr[-1500:])
+    assert r.stdout.count(" runs differ") >= 8 + 4

@@ -250,12 +250,17 @@ def main():
     ap.add_argument("--aggressors", default="")
     ap.add_argument("--out", default="")
     ap.add_argument("--diagnose", type=int, default=0, help="describe the first N differing runs of every pairing (where, by how much)")
+    ap.add_argument("--pairs", default="", help="exact pairings victim:aggressor,victim:aggressor (instead of the product of --victims and --aggressors)")
     a = ap.parse_args()
     g = torch.Generator(device="cuda").manual_seed(17)
     rng = np.random.default_rng(5)
     V, A = build_victims(g), build_aggressors(g)
     vs = [v for v in a.victims.split(",") if v] or list(V)
     ags = [x for x in a.aggressors.split(",") if x] or list(A)
+    pairs = [tuple(p.split(":")) for p in a.pairs.split(",") if p]
+    if pairs:
+        vs = list(dict.fromkeys(v for v, _ in pairs))
+        ags = list(dict.fromkeys(x for _, x in pairs))
     lib = os.environ.get("MAUA_HIP_LIB", "maua-style_amd/libmaua_hip.so")
     print(f"# soak_streams: library {lib}, {a.seconds:.0f} s per pairing", flush=True)
     rows, total_bad = [], 0
@@ -266,6 +271,8 @@ def main():
         rows.append(dict(victim=vn, aggressor=None, runs=n, victim_workgroups=w, differing=b))
         total_bad += b
         for an in ags:
+            if pairs and (vn, an) not in pairs:
+                continue
             n, w, b = soak(vn, V[vn], an, A[an][0], a.seconds, rng, a.diagnose)
             print(f"{vn:14s} x {an:12s} : {b} of {n} runs differ ({w / 1e6:.1f} M victim workgroups)", flush=True)
             rows.append(dict(victim=vn, aggressor=an, runs=n, victim_workgroups=w, differing=b))
