@@ -685,14 +685,6 @@ __global__ void __launch_bounds__(512, 1) gram_x3_partial128_batch_kernel(GramPa
 __device__ __forceinline__ double slab_sum(const float* __restrict__ base, int ksplit, int kstride) {
     double sd = 0.0;
     int k = 0;
-    // (round 6: thirty-two loads in flight first - the finishing launches were 22-33 us of dependent round trips of eight)
-    for (; k + 31 * kstride < ksplit; k += 32 * kstride) {
-        float v[32];
-#pragma unroll
-        for (int u = 0; u < 32; ++u) v[u] = base[(int64_t)(k + u * kstride) * (GT * GT)];
-#pragma unroll
-        for (int u = 0; u < 32; ++u) sd += (double)v[u];
-    }
     for (; k + 7 * kstride < ksplit; k += 8 * kstride) {
         float v[8];
 #pragma unroll
@@ -831,11 +823,7 @@ __global__ void __launch_bounds__(256) gram_finish_mse_batch_kernel(GramFinishBa
     const int e = blockIdx.y * 256 + threadIdx.x;
     const int er = e / GT, ec = e % GT;
     const int src = (ti == tj && er > ec) ? ec * GT + er : e;
-#if defined(GF_X) && GF_X == 3
-    const double sd = (double)base[src];
-#else
     const double sd = slab_sum(base + src, ksplit, kstride);
-#endif
     const float s = (float)(sd * (double)b.scale[z]);
     const int gi = ti * GT + er, gj = tj * GT + ec;
     const float* __restrict__ target = b.target[z];
@@ -848,18 +836,14 @@ __global__ void __launch_bounds__(256) gram_finish_mse_batch_kernel(GramFinishBa
         gram[(int64_t)gi * C + gj] = s;
         dmat[(int64_t)gi * C + gj] = grad_scale * d;
         sq = (double)d * (double)d;
-#if !defined(GF_X) || GF_X != 1
         if (ti != tj) {
             const float dt = s - target[(int64_t)gj * C + gi];
             gram[(int64_t)gj * C + gi] = s;
             dmat[(int64_t)gj * C + gi] = grad_scale * dt;
             sq += (double)dt * (double)dt;
         }
-#endif
     }
-#if !defined(GF_X) || GF_X != 2
     sq = block_sum(sq, scratch);
-#endif
     if (threadIdx.x == 0) {
         double* rec = b.rec[z];
         rec[2 + blockIdx.x * gridDim.y + blockIdx.y] = sq;
