@@ -174,7 +174,7 @@ def pmc_traffic(prefix):
     doubled as MI355X_MICROARCH.md prescribes for gfx950 (our own calibration, profiles/pmc_r01_calibration.json: x2.0
     for 16 B/lane streams, x1.2-1.6 for 4 B/lane patterns, so this is an upper bound); writes are exact."""
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    path = next((os.path.join(here, f) for f in ("pmc_r05_traffic.json", "pmc_r04_traffic.json", "pmc_r03_traffic.json", "pmc_r02_traffic.json")
+    path = next((os.path.join(here, f) for f in ("pmc_r06_traffic.json", "pmc_r05_traffic.json", "pmc_r04_traffic.json", "pmc_r03_traffic.json", "pmc_r02_traffic.json")
                  if os.path.exists(os.path.join(here, f))), None)
     if path is None:
         return None

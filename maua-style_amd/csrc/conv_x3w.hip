@@ -98,7 +98,16 @@ __device__ __forceinline__ void pack_dmat_x3w_body(const float* __restrict__ d, 
     const int tid = threadIdx.x;
     const int64_t total4 = (int64_t)C * C / 4;  // (C % 16 == 0)
     float m = 0.f;
-    for (int64_t e = tid; e < total4; e += 1024) {
+    // (all loads of the maximum in flight together - a 256 x 256 matrix is sixteen per thread: the launch was a chain of sixteen round trips)
+    int64_t e = tid;
+    for (; e + 7 * 1024 < total4; e += 8 * 1024) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<const float4*>(d)[e + u * 1024];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+    }
+    for (; e < total4; e += 1024) {
         const float4 v = reinterpret_cast<const float4*>(d)[e];
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }

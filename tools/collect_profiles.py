@@ -8,8 +8,8 @@ import subprocess
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rr = sys.argv[1] if len(sys.argv) > 1 else "05"
-src = os.path.join(REPO, sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/r5fin")
+rr = sys.argv[1] if len(sys.argv) > 1 else "06"
+src = os.path.join(REPO, sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/r6fin")
 dst = os.path.join(REPO, "profiles")
 
 

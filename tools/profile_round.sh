@@ -1,6 +1,6 @@
 set -x
 # (the *_clock.py tools below load diagnostic builds from tools/_build/: run tools/build_stamp_libs.sh in the container first, after any change to csrc/)
-R=$PWD; O=$R/gpurun_out/${ROUND_DIR:-r5fin}; mkdir -p $O
+R=$PWD; O=$R/gpurun_out/${ROUND_DIR:-r6fin}; mkdir -p $O
 python bench.py --steps 200 > $O/bench_graph.json 2> $O/bench_graph.err
 python bench.py --steps 100 --no_hip_graph --no_cpu_baseline --no_extra_sizes > $O/bench_eager.json 2>/dev/null
 cd /tmp; export TMPDIR=/tmp
@@ -24,8 +24,8 @@ for S in 1024 1448 2048; do python bench.py --size $S --optimizer adam --steps 1
 python tools/run_configs.py --configs 2,3,4,5,6 --out $O/configs.json > $O/configs.log 2>&1
 # per-dispatch durations (and idle gaps) of one steady-state iteration as the product runs it - replayed from the hipGraph, history full:
 # the per-launch tables (eager events overstate host-bound launches)
-for S in 1024 512 256; do bash tools/trace_gaps.sh gpurun_out/${ROUND_DIR:-r5fin}/tg$S --size $S --steps 130 > $O/launches_graph_$S.txt 2>&1; done
-bash tools/trace_gaps.sh gpurun_out/${ROUND_DIR:-r5fin}/tgnin --model nin --steps 130 > $O/launches_graph_nin.txt 2>&1
+for S in 1024 512 256; do bash tools/trace_gaps.sh gpurun_out/${ROUND_DIR:-r6fin}/tg$S --size $S --steps 130 > $O/launches_graph_$S.txt 2>&1; done
+bash tools/trace_gaps.sh gpurun_out/${ROUND_DIR:-r6fin}/tgnin --model nin --steps 130 > $O/launches_graph_nin.txt 2>&1
 python tools/graph_host_cost.py 256 512 1024 2>/dev/null | grep size > $O/graph_host_cost.txt
 python tools/check_x3p.py 1024 5 10 > $O/check_x3p.txt 2>&1
 python tools/x3p_clock.py 64 64 1024 plain > $O/clock_x3p_conv1_2.txt 2>&1
