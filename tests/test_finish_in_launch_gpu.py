@@ -51,7 +51,7 @@ def data(cin, cout, H, W, n, seed=0):
 
 FAMILIES = ["x3q", "x3w"]
 # cin, cout, H, W, n
-SHAPES = [(256, 256, 64, 64, 1), (512, 200, 33, 45, 1), (128, 64, 66, 70, 2), (256, 128, 16, 32, 1)]
+SHAPES = [(256, 256, 64, 64, 1), (512, 200, 33, 45, 1), (128, 64, 66, 70, 2), (256, 128, 16, 32, 1), (512, 512, 32, 32, 1), (256, 192, 90, 91, 1)]
 
 
 def _entry(hip, family):
