@@ -362,3 +362,53 @@ def test_integration_md_lists_exactly_the_planner_fields():
     assert listed == want
     for var in plan.ENV_VARS:
         assert f"`{var}`" in text, var
+
+
+def test_plan_cache_follows_the_environment(monkeypatch):
+    """plan.get() parses MAUA_PLAN once per distinct value of the variable (it is asked several times per launch): a changed,
+    removed or malformed value is seen at the next call, programmatic overrides still win."""
+    import plan
+    monkeypatch.delenv("MAUA_PLAN", raising=False)
+    assert plan.get("x3p_min_items") == plan.FIELDS["x3p_min_items"][0]
+    monkeypatch.setenv("MAUA_PLAN", "x3p_min_items=1024")
+    assert plan.get("x3p_min_items") == "1024" and plan.get("x3p_min_items") == "1024"
+    monkeypatch.setenv("MAUA_PLAN", "x3p_min_items=256;gram_t128=2")
+    assert plan.get("x3p_min_items") == "256" and plan.get("gram_t128") == "2"
+    monkeypatch.setitem(plan.OVERRIDES, "x3p_min_items", "64")
+    assert plan.get("x3p_min_items") == "64"
+    monkeypatch.setenv("MAUA_PLAN", "nonsense")
+    with pytest.raises(ValueError):
+        plan.get("gram_t128")
+    monkeypatch.delenv("MAUA_PLAN")
+    assert plan.get("gram_t128") == plan.FIELDS["gram_t128"][0]
+    # the honoured per-field variables still work, and MAUA_PLAN wins over them
+    monkeypatch.setenv("MAUA_CONV_X3", "0")
+    assert plan.get("conv_x3") == "0"
+    monkeypatch.setenv("MAUA_PLAN", "conv_x3=1")
+    assert plan.get("conv_x3") == "1"
+
+
+def test_bench_line_refuses_a_stopped_optimiser():
+    """bench.lbfgs_still_moving: the timed region's rate is only valid if every iteration did its whole work - a raised stop flag makes the
+    update kernels return early.  The helper reports {n_iter, stopped, history_len} and raises when a stop rule fired
+    or an iteration is missing."""
+    import bench
+
+    class State:
+        def __init__(self, **kw):
+            self.kw = kw
+
+        def status(self):
+            return self.kw
+
+    class Opt:
+        pass
+    opt = Opt()
+    opt.state = State(n_iter=305, history_len=100, stopped=False, gtd=-1.0, t=1.0)
+    assert bench.lbfgs_still_moving(opt, 305, "the test") == {"n_iter": 305, "stopped": False, "history_len": 100, "expected_n_iter": 305}
+    opt.state = State(n_iter=305, history_len=100, stopped=True, gtd=1.0, t=1.0)
+    with pytest.raises(RuntimeError, match="stopped moving"):
+        bench.lbfgs_still_moving(opt, 305, "the test")
+    opt.state = State(n_iter=290, history_len=100, stopped=False, gtd=-1.0, t=1.0)
+    with pytest.raises(RuntimeError):
+        bench.lbfgs_still_moving(opt, 305, "the test")
