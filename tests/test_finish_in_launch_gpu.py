@@ -105,11 +105,12 @@ def test_in_launch_finish_of_the_pooling_and_unpooling_forms(hip, family, ks, ci
     """conv + ReLU + 2x2 max pool (the last arriver pools complete sums in its epilogue; the two-launch form pools in
     conv_splitk_finish_pool_kernel) and the backward pass staged from a pooled gradient, masked and not: armed = unarmed, bit for bit,
     pooled map and decision bytes alike; odd planes (45 x 45: floor-mode pooling) included."""
-    pack, conv, relu_pool, unpool, ws_bytes, split = _entry(hip, family)
-    if cin // (32 if family == "x3q" else 16) < 2 * ks or (family == "x3q" and cout % 8) or cout % 8:
+    pack, _, relu_pool, unpool, ws_bytes, split = _entry(hip, family)
+    if cin // (32 if family == "x3q" else 16) < 2 * ks or cout % 8:
         pytest.skip("not a shape of this form")
     force(hip, **{f"{family}_ks": ks})
-    x, w, b, g = data(cin, cout, H, W, n, seed=3)
+    assert split(n, cin, H, W, cout, 1) == ks
+    x, w, b, _ = data(cin, cout, H, W, n, seed=3)
     bf, bb, wsc = pack(w)
     ws = _poisoned(max(ws_bytes(n, cin, H, W, cout, 1), ws_bytes(n, cout, H, W, cin, 1)))
     PH, PW = H // 2, W // 2
@@ -167,7 +168,7 @@ def test_in_launch_finish_under_a_captured_graph_and_many_replays(hip):
     force(hip, x3q_ks=2, x3w_ks=4)
     x, w, b, _ = data(256, 256, 64, 64, 1, seed=7)
     bq, bbq, wsq = hip.conv_pack_filters_x3q(w)
-    bw, bbw, wsw = hip.conv_pack_filters_x3w(w)
+    bw, _, wsw = hip.conv_pack_filters_x3w(w)
     ws = _poisoned(max(hip.conv_x3q_workspace_bytes(1, 256, 64, 64, 256, 1), hip.conv_x3w_workspace_bytes(1, 256, 64, 64, 256, 1)))
     y1, y2, y3 = (torch.empty(1, 256, 64, 64, device="cuda") for _ in range(3))
 

@@ -61,8 +61,7 @@ def build_victims(g):
     cin = cout = 512
     xs = torch.relu(torch.randn(1, cin, 64, 64, device=dev, generator=g))
     w = torch.randn(cout, cin, 3, 3, device=dev, generator=g) * math.sqrt(2.0 / (9 * cin))
-    fq, bq, wsq = hip.conv_pack_filters_x3q(w)
-    fw, bw, wsw = hip.conv_pack_filters_x3w(w)
+    fq, _, wsq = hip.conv_pack_filters_x3q(w)
     bias = torch.randn(cout, device=dev, generator=g) * 0.1
     ws = torch.empty(max(hip.conv_x3q_workspace_bytes(1, cin, 64, 64, cout, 1), hip.conv_x3w_workspace_bytes(1, cin, 64, 64, cout, 1), 16),
                      dtype=torch.uint8, device=dev)
