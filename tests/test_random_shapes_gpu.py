@@ -269,3 +269,107 @@ def test_random_configurations_against_the_cpu_oracle(weight_files, seed):
         rel = float(diff.norm() / ograd.double().norm())
         windows += 1
     assert rel <= 1e-4, (seed, S, extra, rel, windows, opt.engine is not None)
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_random_lbfgs_problems_against_the_oracle(hip, seed):
+    """The device-resident L-BFGS (lbfgs.hip: coefficient-space two-loop, ring of `history` pairs, the y.s > 1e-10 rule, H_diag, the first
+    step min(1, 1 / |g|_1)) on random vector lengths (ragged: not multiples of the kernels' block sizes), histories 1 ... 60 (wrapping several
+    times within the run) and iteration counts, against the oracle's restatement of torch.optim.LBFGS in fp64 (reference optim.py:180-191)."""
+    from oracle import lbfgs_run
+    r = random.Random(3000 + seed)
+    n = r.choice([r.randint(50, 5000), r.randint(5000, 60000), 3 * r.randint(20, 120) ** 2])
+    history = r.choice([1, 2, 3, 5, 8, 17, 33, 60])
+    iters = r.randint(6, 45)
+    gg = torch.Generator().manual_seed(seed)
+    a = torch.rand(n, generator=gg, dtype=torch.float64) * 3 + 0.5
+    q = 0.1 * n * n
+    sigma = 0.1
+
+    def fg(x):
+        aa = a.to(x.device, x.dtype)
+        rr = torch.roll(x, 1)
+        loss = sigma * ((aa * x * x).sum() + q * (x ** 4).sum() + 0.5 * (x * rr).sum())
+        grad = sigma * (2 * aa * x + 4 * q * x ** 3 + 0.5 * (rr + torch.roll(x, -1)))
+        return float(loss), grad
+    x0 = (torch.randn(n, generator=gg, dtype=torch.float64) * (1.25 / n)).float().double()
+    trace, stats = [], {}
+    ref, _ = lbfgs_run(fg, x0, iters, history=history, trace=trace, stats=stats)
+    x = x0.float().cuda()
+    st = hip.LbfgsState(n, history, x.device)
+    for it in range(iters):
+        st.iterate(x, fg(x)[1].contiguous())
+        if it in (0, 1, 2, 4):
+            torch.cuda.synchronize()
+            assert rel_l2(x.cpu(), trace[it]) <= 2e-4, (n, history, iters, it)
+    torch.cuda.synchronize()
+    s = st.status()
+    assert s["n_iter"] == iters and not s["stopped"] and s["history_len"] <= history and abs(s["history_len"] - stats["history_len"]) <= 2
+    assert float((x.cpu().double() - ref).norm() / x0.norm()) <= 1e-4, (n, history, iters)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_gram_shapes_against_fp64(hip, seed):
+    """GramMatrix forward (`torch.mm(x, x.t())`, reference loss.py:67-91; covariance form :87-89) and its backward D (F - mean) on random
+    channel counts (8 ... 600, ragged against the 64- and 128-channel blocks) and plane sizes (ragged against the 64-pixel stages), with and
+    without centring, masked and accumulating: both against fp64."""
+    r = random.Random(4000 + seed)
+    c = r.choice([8, 24, 64, 96, 128, 200, 256, 384, 512, 600])
+    h, w = r.randint(3, 120), r.randint(3, 120)
+    center = r.random() < 0.4
+    g = torch.Generator().manual_seed(seed)
+    f = torch.relu(torch.randn(1, c, h, w, generator=g)) * float(10.0 ** r.uniform(-2, 2))
+    fd = f.cuda()
+    n = f.numel()
+    gram, mean = hip.gram_fwd(fd, 1.0 / n, center)
+    torch.cuda.synchronize()
+    F2 = f.double().reshape(c, -1)
+    Fc = F2 - F2.mean(dim=1, keepdim=True) if center else F2
+    ref = Fc @ Fc.t() / n
+    assert rel_l2(gram.cpu(), ref) <= 2e-6, (c, h, w, center)
+    assert torch.equal(gram, gram.t())
+    if center:
+        assert rel_l2(mean.cpu(), F2.mean(dim=1)) <= 1e-6
+    d = torch.randn(c, c, generator=g) * 1e-3
+    d = (d + d.t()).cuda()
+    masked, acc = r.random() < 0.5, r.random() < 0.5
+    prev = torch.randn(c, h * w, generator=g).cuda() * float(f.abs().max()) * 1e-3
+    gf = prev.clone()
+    hip.gram_bwd(d, fd, mean if center else None, gf, acc, relu_mask=fd if masked else None)
+    torch.cuda.synchronize()
+    want = d.cpu().double() @ Fc
+    if acc:
+        want = want + prev.cpu().double()
+    if masked:
+        want = want * (F2 > 0)
+    assert rel_l2(gf.cpu(), want) <= 2e-6 or float((gf.cpu().double() - want).abs().max()) <= 1e-6 * float(want.abs().max() or 1.0), (c, h, w, center, masked, acc)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_pool_geometries_against_torch(hip, seed):
+    """`nn.MaxPool2d` / `nn.AvgPool2d` (reference models.py:119-123: 2x2 stride 2; NIN's 3x3 stride 2 ceil mode, :77-80) forward and backward
+    on random planes: values bit for bit against ATen on the CPU (selections and averages of the same fp32 values), gradients routed to
+    ATen's receivers; with the ReLU mask of the pooled map's source folded in."""
+    r = random.Random(6000 + seed)
+    k, stride, ceil = r.choice([(2, 2, False), (2, 2, False), (3, 2, True), (3, 2, False), (2, 2, True), (3, 3, False)])
+    mode = r.choice(["max", "max", "avg"])
+    n, c = r.choice([1, 2]), r.choice([3, 8, 24, 64])
+    h, w = r.randint(k, 90), r.randint(k, 90)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.relu(torch.randn(n, c, h, w, generator=g))
+    x[x > 0] = torch.round(x[x > 0] * 8) / 8 + 0.125     # many exact ties: the first maximum in scan order must win, as in ATen
+    xd = x.cuda()
+    y = hip.pool2d_fwd(xd, k, stride, ceil, mode)
+    xr = x.clone().requires_grad_(True)
+    yr = (F.max_pool2d(xr, k, stride, 0, ceil_mode=ceil) if mode == "max" else F.avg_pool2d(xr, k, stride, 0, ceil_mode=ceil))
+    torch.cuda.synchronize()
+    assert y.shape == yr.shape and torch.equal(y.cpu(), yr.detach()), (k, stride, ceil, mode, n, c, h, w)
+    gy = torch.randn(*yr.shape, generator=g)
+    yr.backward(gy)
+    mask = r.random() < 0.5
+    gx = hip.pool2d_bwd(gy.cuda(), xd, k, stride, ceil, mode, relu_mask_by_x=mask)
+    torch.cuda.synchronize()
+    want = xr.grad * (x > 0) if mask else xr.grad
+    if mode == "max":
+        assert torch.equal(gx.cpu() != 0, want != 0) or k == 3, (k, stride, ceil, mode, h, w)
+    assert rel_l2(gx.cpu(), want.double()) <= 1e-6, (k, stride, ceil, mode, n, c, h, w, mask)
