@@ -373,3 +373,76 @@ def test_random_pool_geometries_against_torch(hip, seed):
     if mode == "max":
         assert torch.equal(gx.cpu() != 0, want != 0) or k == 3, (k, stride, ceil, mode, h, w)
     assert rel_l2(gx.cpu(), want.double()) <= 1e-6, (k, stride, ceil, mode, n, c, h, w, mask)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_1x1_5x5_and_image_layer_shapes_against_fp64(hip, seed):
+    """The other convolution kernels on random geometries against fp64: the fp16x3 1x1 product (NIN's cccp layers and the Gram backward,
+    reference models.py:84-110), the fp16x3 5x5 layer (NIN's conv2, :86), the image layer forward (bf16x6, `nn.Conv2d(3, 64, 3)`, :129) and
+    its backward-data pass on the matrix cores (conv_few_mfma.hip)."""
+    r = random.Random(8000 + seed)
+    kind = ["1x1", "5x5", "image", "few"][seed % 4]
+    g = torch.Generator().manual_seed(seed)
+    n = r.choice([1, 1, 2])
+    h, w = r.randint(6, 130), r.randint(6, 130)
+    if kind == "1x1":
+        cin, cout = r.choice([16, 96, 200, 256, 384, 1024]), r.choice([64, 96, 200, 256, 1024])
+        x = torch.relu(torch.randn(n, cin, h, w, generator=g))
+        wt = torch.randn(cout, cin, generator=g) * math.sqrt(2.0 / cin)
+        b = torch.randn(cout, generator=g) * 0.1
+        relu, masked = r.random() < 0.5, r.random() < 0.4
+        mask = torch.relu(torch.randn(n, cout, h, w, generator=g)) if masked else None
+        y = hip.conv1x1_x3(x.cuda(), wt.cuda(), b.cuda(), relu, out_relu_mask=None if mask is None else mask.cuda())
+        ref = F.conv2d(x.double(), wt.double()[:, :, None, None], b.double())
+        ref = torch.relu(ref) if relu else ref
+        ref = ref * (mask > 0) if masked else ref
+    elif kind == "5x5":
+        cin, cout, pad = r.choice([8, 96, 128]), r.choice([64, 256, 200]), r.choice([2, 2, 0, 1])
+        if h + 2 * pad < 5 or w + 2 * pad < 5:
+            h, w = h + 5, w + 5
+        x = torch.relu(torch.randn(n, cin, h, w, generator=g))
+        wt = torch.randn(cout, cin, 5, 5, generator=g) * math.sqrt(2.0 / (25 * cin))
+        b = torch.randn(cout, generator=g) * 0.1
+        bf, _, wsc = hip.conv_pack_filters_kxk_x3(wt.cuda())
+        y = hip.conv_kxk_x3(x.cuda(), bf, wsc, b.cuda(), cout, 5, pad, True)
+        ref = torch.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=pad))
+    elif kind == "image":
+        cin, cout, pad = r.choice([1, 3, 3]), 64, r.choice([1, 1, 0])
+        x = torch.rand(1, cin, h, w, generator=g) * 255 - 120
+        wt = torch.randn(cout, cin, 3, 3, generator=g) * math.sqrt(2.0 / (9 * cin))
+        b = torch.randn(cout, generator=g) * 0.1
+        bank = hip.conv_pack_filters_image(wt.cuda(), b.cuda())
+        y = hip.conv3x3_image(x.cuda(), bank, cout, pad, True)
+        ref = torch.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=pad))
+    else:
+        cin = r.choice([1, 3, 3])
+        if not hip.conv_few_mfma_supported(n, cin, h, w, 64, 1):
+            pytest.skip("geometry outside conv_few_mfma")
+        wt = torch.randn(64, cin, 3, 3, generator=g) * math.sqrt(2.0 / (9 * cin))
+        gy = torch.randn(n, 64, h, w, generator=g) * (torch.rand(n, 64, h, w, generator=g) > 0.5)
+        bank = hip.conv_pack_filters_few_mfma(wt.cuda())
+        y = hip.conv3x3_few_mfma(gy.cuda(), bank, cin, tile=r.choice([0, 1, 2, 3]))
+        ref = torch.nn.grad.conv2d_input((n, cin, h, w), wt.double(), gy.double(), padding=1)
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape and torch.isfinite(y).all()
+    assert rel_l2(y.cpu(), ref) <= BAR, (kind, n, h, w)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_bilinear_resizes_against_aten(hip, seed):
+    """`F.interpolate(x, ..., mode="bilinear", align_corners=False)` between two scales (reference style.py:38-66) on random sizes, in both
+    calling forms (size / scale_factor): ATen's source-index arithmetic, to 1e-6 of the value range."""
+    r = random.Random(9500 + seed)
+    c, h, w = r.choice([1, 3]), r.randint(8, 300), r.randint(8, 300)
+    x = torch.rand(1, c, h, w, generator=torch.Generator().manual_seed(seed)) * 255 - 120
+    if r.random() < 0.5:
+        size = (r.randint(8, 400), r.randint(8, 400))
+        y = hip.resize_bilinear(x.cuda(), size=size)
+        ref = F.interpolate(x, size=size, mode="bilinear", align_corners=False)
+    else:
+        sf = r.choice([0.5, 2.0, 1.4142135, 0.70710678, 1.3, 3.0])
+        y = hip.resize_bilinear(x.cuda(), scale_factor=sf)
+        ref = F.interpolate(x, scale_factor=sf, mode="bilinear", align_corners=False)
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape
+    assert float((y.cpu() - ref).abs().max()) <= 1e-6 * 255 * 4, (c, h, w)
