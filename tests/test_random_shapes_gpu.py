@@ -446,3 +446,37 @@ def test_random_bilinear_resizes_against_aten(hip, seed):
     torch.cuda.synchronize()
     assert y.shape == ref.shape
     assert float((y.cpu() - ref).abs().max()) <= 1e-6 * 255 * 4, (c, h, w)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_frame_batches_are_bit_identical_to_single_frames(weight_files, seed):
+    """optim.optimize_frames on random batch sizes, image sides (odd ones too) and flags: every frame of the batch carries the bits of the
+    same frame optimised alone under the same plan (the split-K policy follows the PLANNED frames, per-frame kernels share nothing):
+    frames are independent B = 1 problems (reference style.py:192-290)."""
+    import models
+    import optim
+    import synth
+    from conftest import product_args
+    r = random.Random(12000 + seed)
+    B, N, S = r.randint(2, 5), r.randint(2, 6), r.randint(48, 140)
+    opt = r.choice(["lbfgs", "lbfgs", "adam"])
+    extra = []
+    if r.random() < 0.3:
+        extra += ["--pooling", "avg"]
+    if r.random() < 0.3:
+        extra += ["--no_grad_norm"]
+    if r.random() < 0.3:
+        extra += ["--use_covariance"]
+    if r.random() < 0.4:
+        extra += ["--style_layers", r.choice(["relu1_1,relu3_1", "relu2_1,relu4_1,relu5_1", "relu1_2"]), "--content_layers", r.choice(["relu3_2", "relu4_2", "relu2_2"])]
+    style = synth.images(S)[1]
+    contents = torch.cat([synth.images(S, seed=50 + k)[0] for k in range(B)])
+    inits = torch.cat([synth.images(S, seed=60 + k)[2] for k in range(B)])
+    args = product_args(weight_files, extra, optimizer=opt, S=S, N=N)
+    optim.set_model_args(args, S)
+    net, losses = models.load_model(args)
+    together = optim.optimize_frames(contents.cuda(), [style], inits.cuda(), N, args, net, losses).cpu()
+    for k in sorted(r.sample(range(B), 2)):
+        single = optim.optimize_frames(contents[k:k + 1].cuda(), [style], inits[k:k + 1].cuda(), N, args, net, losses, planned_frames=B).cpu()
+        assert torch.equal(together[k], single[0]), (B, N, S, opt, extra, k, rel_l2(together[k], single[0].double()))
+    assert torch.isfinite(together).all() and not torch.equal(together[0], together[1])
