@@ -153,6 +153,20 @@ def test_two_rank_gloo_broadcast_and_sharding(tmp_path):
     assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
 
 
+def test_eight_rank_gloo_broadcast_and_sharding(tmp_path):
+    """The same worker at the world size of the target node (8 ranks, gloo on the CPU: one process per would-be GPU): rank 0's weights and
+    style targets reach all eight, five frames shard as 1 + 1 + 1 + 1 + 1 + 0 + 0 + 0 and gather whole, max-over-ranks, the replica
+    weights' per-model bookkeeping.  No RCCL run with N > 1 has ever been possible here: this is the N = 8 control
+    flow, without the GPU."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(8)]
+
+
 def test_flow_warp_map_matches_reference_fixture(tmp_path):
     """load.flow_warp_map / read_flo / write_flow against the reference's own reader and writer (tests/golden/flow_warp_map.npz,
     tools/make_golden.py::gen_temporal)."""
