@@ -77,6 +77,9 @@ struct X3pArgs {
     int groups;   // workgroups of the launch (a multiple of 8)
     int tiles_y;  // tile rows of one plane
     int d_split, d_tx, d_ty, d_cot, d_n;  // groups / 8 (a workgroup's stride through its XCD's items) as digits of the item index
+    int order;    // 0: item = ((n ncot + cotile) tiles + tile) ksplit + split;  1 (round 6): ((n tiles + tile) ncot + cotile) ksplit + split -
+                  // the channel tiles of ONE pixel tile side by side on the CUs of an XCD, so that they stage the same patch at the same time
+                  // (an XCD's band then holds whole pixel tiles: the input plane leaves memory once instead of once per channel tile)
     float w_inv_scale;
 };
 
@@ -179,10 +182,18 @@ __global__ void __launch_bounds__(XP_THREADS, 2) conv_x3p_kernel(ConvArgs p, X3p
         int t = idx;
         it.split = t % ksplit;
         t /= ksplit;
-        const int tile = t % q.tiles;
-        t /= q.tiles;
-        it.cot = t % q.ncot;
-        it.n = t / q.ncot;
+        int tile;
+        if (q.order) {
+            it.cot = t % q.ncot;
+            t /= q.ncot;
+            tile = t % q.tiles;
+            it.n = t / q.tiles;
+        } else {
+            tile = t % q.tiles;
+            t /= q.tiles;
+            it.cot = t % q.ncot;
+            it.n = t / q.ncot;
+        }
         it.x0 = (tile % p.tiles_x) * 32;
         it.y0 = (tile / p.tiles_x) * XP_ROWS;
         it.n = __builtin_amdgcn_readfirstlane(it.n);
@@ -198,15 +209,22 @@ __global__ void __launch_bounds__(XP_THREADS, 2) conv_x3p_kernel(ConvArgs p, X3p
         it.split += q.d_split;
         c = it.split >= ksplit ? 1 : 0;
         it.split -= c ? ksplit : 0;
+        if (q.order) {  // (digits: split, channel tile, tile column, tile row, image)
+            it.cot += q.d_cot + c;
+            c = it.cot >= q.ncot ? 1 : 0;
+            it.cot -= c ? q.ncot : 0;
+        }
         it.x0 += (q.d_tx + c) * 32;
         c = it.x0 >= tiles_w ? 1 : 0;
         it.x0 -= c ? tiles_w : 0;
         it.y0 += (q.d_ty + c) * XP_ROWS;
         c = it.y0 >= tiles_h ? 1 : 0;
         it.y0 -= c ? tiles_h : 0;
-        it.cot += q.d_cot + c;
-        c = it.cot >= q.ncot ? 1 : 0;
-        it.cot -= c ? q.ncot : 0;
+        if (!q.order) {  // (digits: split, tile column, tile row, channel tile, image)
+            it.cot += q.d_cot + c;
+            c = it.cot >= q.ncot ? 1 : 0;
+            it.cot -= c ? q.ncot : 0;
+        }
         it.n += q.d_n + c;
         chunk_range(it);
         return it;
@@ -1000,16 +1018,25 @@ int conv_x3p_launch(const ConvArgs& a, int n, float w_scale, hipStream_t stream)
     const int max_groups = x3p_max_groups();
     q.groups = (int)(items >= max_groups ? max_groups : (items + 7) / 8 * 8);
     q.tiles_y = q.tiles / p.tiles_x;
+    q.order = tuning("x3p_order", 1) != 0 ? 1 : 0;
     {
         int st = q.groups / 8;
         q.d_split = st % ks;
         st /= ks;
+        if (q.order) {
+            q.d_cot = st % q.ncot;
+            st /= q.ncot;
+        }
         q.d_tx = st % p.tiles_x;
         st /= p.tiles_x;
         q.d_ty = st % q.tiles_y;
         st /= q.tiles_y;
-        q.d_cot = st % q.ncot;
-        q.d_n = st / q.ncot;
+        if (q.order) {
+            q.d_n = st;
+        } else {
+            q.d_cot = st % q.ncot;
+            q.d_n = st / q.ncot;
+        }
     }
     q.w_inv_scale = 1.f / w_scale;
     const bool om = ks == 1 && a.omask != nullptr, gram = a.dbank != nullptr, unpool = a.in_codes != nullptr;
