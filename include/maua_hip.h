@@ -98,7 +98,10 @@ int maua_conv3x3_x6(const float* x, const void* bank, const float* bias, const f
  * 1-3 channels (`nn.Conv2d(3, 64, 3, padding=1)` + `nn.ReLU`, models.py:129-130: conv1_1) with K = the 9 cin (channel, tap) pairs in two
  * K = 16 matrix steps, filters in registers, pixels gathered from the image - bound by writing the activation (conv_img.hip).
  * Bank: maua_conv_image_bank_bytes(cout, cin) bytes, packed from the OIHW weights AND the bias (nullable) once per weight set: the bias
- * rides in the first unused pair of the padded K against a pixel value of 1.  Forward only. */
+ * rides in the first unused pair of the padded K against a pixel value of 1.  Forward only.  maua_conv_image_supported: the geometry check -
+ * the kernel's offsets are 32-bit, its store descriptor spans 64 output planes: planes of fewer than 2^24 pixels (a 4096 x 4096 image is one
+ * pixel past that; callers route such layers to maua_conv3x3_x6, the same products).  maua_conv_image_gram_slabs returns 0 for them. */
+int maua_conv_image_supported(int n, int cin, int h, int w, int cout, int pad);
 size_t maua_conv_image_bank_bytes(int cout, int cin);
 int maua_conv_pack_filters_image(const float* w_oihw, const float* bias, void* bank, int cout, int cin, maua_stream_t stream);
 int maua_conv3x3_image(const float* x, const void* bank, float* y, int n, int cin, int h, int w, int cout, int pad, int relu,

@@ -324,11 +324,18 @@ int maua_conv_pack_filters_image(const float* w_oihw, const float* bias, void* b
     return check_launch("pack_image_kernel");
 }
 
+// What the kernel's 32-bit offsets hold: an image below 2^31 elements, fewer than 2^31 row blocks, and 64 output planes below 2^32 bytes (the
+// store descriptor spans a 64-channel tile: planes of fewer than 2^24 pixels - a 4096 x 4096 image is one pixel too many).
+static bool conv_image_fits(int64_t n, int64_t cin, int64_t h, int64_t w, int64_t pad) {
+    const int64_t oh = h + 2 * pad - 2, ow = w + 2 * pad - 2;
+    return cin * h * w < (1ll << 31) && n * oh * ((ow + 31) / 32) < (1ll << 31) && 64 * oh * ow < (1ll << 30);
+}
+
 static int conv_image_fill(ImgArgs& p, const float* x, const void* bank, float* y, int n, int cin, int h, int w, int cout, int pad, int relu) {
     MAUA_REQUIRE(x && bank && y, MAUA_E_INVAL, "conv3x3_image: null pointer");
     MAUA_REQUIRE(conv_dims_ok(n, cin, h, w, cout, pad) && pad <= 2 && cin <= 3, MAUA_E_INVAL, "conv3x3_image: bad dims (1-3 input channels)");
     MAUA_REQUIRE(h + 2 * pad >= 3 && w + 2 * pad >= 3, MAUA_E_UNSUPPORTED, "conv3x3_image: input smaller than the filter");
-    MAUA_REQUIRE((int64_t)cin * h * w < (1ll << 31), MAUA_E_UNSUPPORTED, "conv3x3_image: image too large");
+    MAUA_REQUIRE(conv_image_fits(n, cin, h, w, pad), MAUA_E_UNSUPPORTED, "conv3x3_image: plane too large (maua_conv_image_supported)");
     p.x = x;
     p.bank = (const unsigned char*)bank;
     p.y = y;
@@ -343,7 +350,6 @@ static int conv_image_fill(ImgArgs& p, const float* x, const void* bank, float* 
     p.relu = relu;
     p.blocks_x = (p.OW + 31) / 32;
     p.blocks = (int64_t)n * p.OH * p.blocks_x;
-    MAUA_REQUIRE(p.blocks < (1ll << 31) && (int64_t)64 * p.OH * p.OW < (1ll << 30), MAUA_E_UNSUPPORTED, "conv3x3_image: plane too large");
     return MAUA_OK;
 }
 // workgroups of four waves, a block per wave at least; at most CI_OCC per CU (what the registers allow)
@@ -361,8 +367,12 @@ int maua_conv3x3_image(const float* x, const void* bank, float* y, int n, int ci
     return check_launch("conv_image_kernel");
 }
 
+int maua_conv_image_supported(int n, int cin, int h, int w, int cout, int pad) {
+    return conv_dims_ok(n, cin, h, w, cout, pad) && pad <= 2 && cin <= 3 && h + 2 * pad >= 3 && w + 2 * pad >= 3 && conv_image_fits(n, cin, h, w, pad);
+}
+
 int maua_conv_image_gram_slabs(int h, int w, int pad) {
-    if (h <= 0 || w <= 0 || pad < 0 || pad > 2 || h + 2 * pad < 3 || w + 2 * pad < 3) return 0;
+    if (h <= 0 || w <= 0 || pad < 0 || pad > 2 || h + 2 * pad < 3 || w + 2 * pad < 3 || !conv_image_fits(1, 3, h, w, pad)) return 0;
     const int64_t oh = h + 2 * pad - 2, ow = w + 2 * pad - 2;
     return (int)conv_image_grid(oh * ((ow + 31) / 32));
 }

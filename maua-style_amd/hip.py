@@ -52,6 +52,7 @@ SIGNATURES = {
     "maua_conv_pack_filters_image": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p]),
     "maua_conv3x3_image": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "maua_conv_image_gram_slabs": (c_i, [c_i, c_i, c_i]),
+    "maua_conv_image_supported": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "maua_conv3x3_image_gram": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "maua_relu_fwd": (c_i, [c_p, c_i64, c_p]),
     "maua_relu_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_p]),
@@ -611,6 +612,11 @@ def conv3x3_image(x, bank, cout, pad, relu, out=None):
     _check(lib().maua_conv3x3_image(_ptr(_f32(x, "x")), bank.data_ptr(), _ptr(out), n, cin, h, w, cout, pad, int(relu), _stream()),
            "maua_conv3x3_image")
     return out
+
+
+def conv_image_supported(n, cin, h, w, cout, pad):
+    """Whether conv3x3_image takes this layer (1-3 channels, planes of fewer than 2^24 pixels: its offsets are 32-bit)."""
+    return bool(lib().maua_conv_image_supported(int(n), int(cin), int(h), int(w), int(cout), int(pad)))
 
 
 def conv_image_gram_slabs(h, w, pad):

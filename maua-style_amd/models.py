@@ -160,7 +160,8 @@ def conv3x3_mfma(x, mod, backward, out=None, out_relu_mask=None, relu=False, acc
         _route("conv_x3", x, cout, p, backward, "64co x 4x32px", mask=out_relu_mask is not None, relu=relu, accumulate=accumulate)
         return hip.conv3x3_x3(x, bb if backward else bf, wsc, bias, cout, p, relu, out=out, out_relu_mask=out_relu_mask,
                               accumulate=accumulate, workspace=workspace)
-    if not backward and consumed <= 3 and out_relu_mask is None and not accumulate and _image_kernel_enabled():
+    if not backward and consumed <= 3 and out_relu_mask is None and not accumulate and _image_kernel_enabled() and \
+            hip.conv_image_supported(n, consumed, h, w, cout, p):  # (planes from 2^24 pixels on - 4096 x 4096 - take the general kernel below)
         # the image layer: the 27 (channel, tap) pairs as K, no LDS - bound by writing the activation (conv_img.hip; same bf16x6 products)
         _route("conv_image", x, cout, p, backward, "27 (channel, tap) pairs as K, bf16x6", relu=relu)
         return hip.conv3x3_image(x, mod.bank_image(), cout, p, relu, out=out)
