@@ -19,15 +19,21 @@ VGG19_CHANNELS = [64, 64, "P", 128, 128, "P", 256, 256, 256, 256, "P",
                   512, 512, 512, 512, "P", 512, 512, 512, 512, "P"]
 
 
-def vgg19_state_dict(bias_scale=0.05, dtype=torch.float32):
+# The other VGG feature stacks of reference models.py:134-137: VGG-16 (also behind the "nyud" / "fcn32s" / "sod" checkpoints, models.py:259-288)
+# and the channel-pruned VGG-16 ("prun", models.py:249-258) whose widths are multiples of nothing.
+VGG16_CHANNELS = [64, 64, "P", 128, 128, "P", 256, 256, 256, "P", 512, 512, 512, "P", 512, 512, 512, "P"]
+VGG16P_CHANNELS = [24, 22, "P", 41, 51, "P", 108, 89, 111, "P", 184, 276, 228, "P", 512, 512, 512, "P"]
+
+
+def vgg19_state_dict(bias_scale=0.05, dtype=torch.float32, channels=None):
     """He-normal conv weights keyed like torchvision-style `features.<idx>.*`.
 
     Seeds: weight of the conv at Sequential index idx uses Generator(1000+idx),
     its bias Generator(2000+idx).  `bias_scale=0` reproduces the zero-bias
-    recipe of SURVEY.md Appendix A.
+    recipe of SURVEY.md Appendix A.  `channels`: another VGG stack (VGG16_CHANNELS, VGG16P_CHANNELS), same recipe.
     """
     sd, idx, cin = {}, 0, 3
-    for c in VGG19_CHANNELS:
+    for c in (VGG19_CHANNELS if channels is None else channels):
         if c == "P":
             idx += 1
             continue

@@ -16,6 +16,24 @@ import torch.nn.functional as F
 # ----------------------------------------------------------------------------------------
 VGG19_CHANNELS = [64, 64, "P", 128, 128, "P", 256, 256, 256, 256, "P",
                   512, 512, 512, 512, "P", 512, 512, 512, 512, "P"]
+VGG16_CHANNELS = [64, 64, "P", 128, 128, "P", 256, 256, 256, "P", 512, 512, 512, "P", 512, 512, 512, "P"]   # models.py:136
+VGG16P_CHANNELS = [24, 22, "P", 41, 51, "P", 108, 89, 111, "P", 184, 276, 228, "P", 512, 512, 512, "P"]    # models.py:135 (channel-pruned)
+
+
+def _vgg_channels(m):
+    """Which VGG feature stack a checkpoint name selects (models.py:248-327: any of the VGG keywords, then in this order "prun" -> VGG-16p,
+    "nyud" / "fcn32s" / "sod" -> VGG-16 (their classifiers differ, and are dropped), "vgg19", "vgg16"; otherwise a ValueError)."""
+    if not any(k in m for k in ("fcn32s", "prun", "sod", "vgg", "nyud")):
+        return None
+    if "prun" in m:
+        return VGG16P_CHANNELS
+    if "nyud" in m or "fcn32s" in m or "sod" in m:
+        return VGG16_CHANNELS
+    if "vgg19" in m:
+        return VGG19_CHANNELS
+    if "vgg16" in m:
+        return VGG16_CHANNELS
+    raise ValueError("VGG architecture not recognized.")  # models.py:327
 
 
 def _vgg_names(channels):
@@ -66,9 +84,10 @@ def _feature_layers(model_file, pooling):
     if pooling not in ("max", "avg"):
         raise ValueError("Unrecognized pooling argseter")  # models.py:124 (sic)
     out, idx = [], 0
-    if "vgg19" in m or m == "vgg19":
+    channels = _vgg_channels(m)
+    if channels is not None:
         cin = 3
-        for c in VGG19_CHANNELS:
+        for c in channels:
             if c == "P":
                 out.append(("pool", 2, 2, False))
                 idx += 1
@@ -77,7 +96,7 @@ def _feature_layers(model_file, pooling):
                 out.append(("relu",))
                 idx += 2
                 cin = c
-        return out, _vgg_names(VGG19_CHANNELS)
+        return out, _vgg_names(channels)
     if "nin" in m:
         for spec in NIN_FEATURES:
             if spec == "P":

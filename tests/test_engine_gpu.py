@@ -959,3 +959,95 @@ def test_gram_slabs_from_the_image_layer_change_nothing_but_rounding(weight_file
     assert torch.allclose(s0, s1, rtol=2e-6, atol=0)
     assert rel_l2(res["1"][2], res["0"][2].double()) <= 2e-6
     assert torch.isfinite(res["1"][2]).all()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The reference's other VGG stacks (models.py:134-137, chosen by the checkpoint's name models.py:248-327): VGG-16 (also "nyud" / "fcn32s" /
+# "sod") and the channel-pruned VGG-16 whose widths - 24, 22, 41, 51, 108, 89, 111, 184, 276, 228 - fit none of the fp16x3 kernels' chunks
+# ---------------------------------------------------------------------------------------------------------
+VGG16_STACKS = {"vgg16": ("vgg16_synth.pth", "VGG16_CHANNELS"), "vgg16prune": ("vgg16-prune_synth.pth", "VGG16P_CHANNELS")}
+VGG16_ALT_FLAGS = ["--use_covariance", "--pooling", "avg", "--content_layers", "relu3_3,relu5_1", "--style_layers", "relu1_2,relu2_2,relu3_1,relu4_3"]
+
+
+@pytest.fixture(scope="module")
+def vgg16_files(weight_files):
+    d = os.path.dirname(weight_files["vgg19"])
+    out = dict(weight_files)
+    for tag, (fname, channels) in VGG16_STACKS.items():
+        out[tag] = os.path.join(d, fname)
+        torch.save(synth.vgg19_state_dict(channels=getattr(synth, channels)), out[tag])
+    return out
+
+
+@pytest.mark.parametrize("tag", list(VGG16_STACKS))
+@pytest.mark.parametrize("name,S,flags", [("S80_default", 80, []), ("S72_covariance_avgpool_layers_alt", 72, VGG16_ALT_FLAGS)])
+def test_engine_on_vgg16_and_pruned_vgg16_matches_reference(vgg16_files, tag, name, S, flags):
+    """One evaluation of the whole loss network on the two other VGG feature stacks against the reference's own numbers (fixtures of
+    tools/make_golden.py::gen_vgg16): every module's loss, the total, the pixel gradient; for the default flags also the fp64 arbiter - as close
+    to it as the reference's fp32 arithmetic is."""
+    import engine
+    g = gold(f"feval_{tag}_{name}")
+    args = product_args(vgg16_files, flags, model=tag, S=S)
+    content, style, init = synth.images(S)
+    net, losses = build(args, content, [style], S)
+    assert [type(m).__name__ for m in net] == list(g["module_types"])
+    if "conv_channels" in g:
+        assert [m.out_channels for m in net if type(m).__name__ == "Conv2d"] == list(g["conv_channels"])
+    eng = engine.StyleEngine(net, losses)
+    slots, total, grad = eng.feval(init.cuda())
+    torch.cuda.synchronize()
+    check_against_golden(g, losses, slots, total, grad)
+    g1 = grad.clone()
+    assert torch.equal(g1, eng.feval(init.cuda())[2])
+    if not flags:
+        g64 = gold(f"feval_{tag}_{name}_f64")
+        ours, theirs = rel_l2(g1.cpu(), g64["grad"]), rel_l2(g["grad"], g64["grad"])
+        assert ours <= 1.5 * theirs, (tag, ours, theirs)
+
+
+@pytest.mark.parametrize("tag", list(VGG16_STACKS))
+@pytest.mark.parametrize("opt", ["lbfgs", "adam"])
+def test_vgg16_and_pruned_vgg16_trajectories_vs_fp64_arbiter(vgg16_files, tag, opt):
+    import optim
+    g = gold(f"traj_{tag}_S64")
+    args = product_args(vgg16_files, model=tag, optimizer=opt, S=64, N=6)
+    content, style, init = synth.images(64)
+    out = optim.optimize(content, [style], init.clone(), 6, args)
+    floor = rel_l2(g[f"{opt}_N6_f32"], g[f"{opt}_N6_f64"])
+    err = rel_l2(out, g[f"{opt}_N6_f64"])
+    assert err <= max(1e-3, 2 * floor), (tag, opt, err, floor)
+
+
+@pytest.mark.parametrize("tag,S", [("vgg16prune", 512), ("vgg16", 512)])
+def test_vgg16_stacks_at_512_determinism_slope_and_routes(vgg16_files, tag, S):
+    """At a size where the wide kernels are routed: deterministic evaluation, the gradient is the slope of the loss, and the route log shows
+    which family took the pruned widths (none of them a multiple of 16) and which the regular ones."""
+    import engine
+    import models
+    import optim
+    args = product_args(vgg16_files, ["--no_grad_norm"], model=tag, S=S)
+    content, style, init = synth.images(S)
+    optim.set_model_args(args, S)
+    net, losses = models.load_model(args)
+    optim.set_content_targets(net, content, args)
+    optim.set_style_targets(net, [style], args)
+    for m in losses:
+        m.mode = "loss"
+    eng = engine.StyleEngine(net, losses)
+    x = init.cuda()
+    s0, t0, g0 = [t.clone() for t in eng.feval(x)]
+    s1, t1, g1 = eng.feval(x)
+    torch.cuda.synchronize()
+    assert torch.equal(g0, g1) and torch.equal(s0, s1)
+    v = g0 / g0.norm()
+    slope = float((g0.double() * v.double()).sum())
+    fd = (float(eng.feval(x + 0.5 * v)[1]) - float(eng.feval(x - 0.5 * v)[1])) / 1.0
+    assert abs(fd - slope) <= 2e-2 * abs(slope), (fd, slope)
+    log = eng.describe_routes(x)
+    convs = [m for m in net if type(m).__name__ == "Conv2d"]
+    assert len(log) == 2 * len(convs)
+    wide = {"conv_x3", "conv_x3w", "conv_x3q", "conv_x3p"}
+    if tag == "vgg16":   # regular widths: every layer behind the image layer on an fp16x3 family
+        assert all(r["kernel"] in wide for r in log if r["consumed"] > 3 and r["produced"] > 3), log
+    else:                # pruned widths: fp16x3 with padded chunks from 16 consumed channels on (conv_x3.hip)
+        assert all(r["kernel"] in wide for r in log if r["consumed"] >= 41 and r["produced"] > 3), log

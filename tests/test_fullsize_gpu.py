@@ -514,8 +514,9 @@ def test_config3_stock_scaling_table_256_to_2048(tmp_path, weight_files):
     with open(os.path.join(PKG, "config", "scaling-img.json")) as f:
         table = json.load(f)
     assert [int(k) for k in table] == sorted(int(k) for k in table)
-    for entry in table.values():
-        entry["model_file"] = weight_files["vgg19"]
+    for entry in table.values():   # (the last row - beyond what VGG-19 holds in 288 GB, 7168 pixels - is the reference's answer to that: NIN)
+        entry["model_file"] = weight_files["nin" if "nin" in entry["model_file"] else "vgg19"]
+    assert [k for k, e in table.items() if "nin" in e["model_file"]] == ["16384"] and int(list(table)[-2]) == 7168
     scaling = tmp_path / "scaling-img.json"
     scaling.write_text(json.dumps(table))
     out = tmp_path / "out"

@@ -290,3 +290,54 @@ def test_oracle_img_vid_trajectory(opt, avg):
     out32 = optimize_video(content, [style_video], init, 4, cfg, sd, 3, avg_frame_window=avg, dtype=torch.float32)
     floor = rel_l2(ref32, ref64)
     assert rel_l2(out32, ref64) <= max(1e-3, 2 * floor), (rel_l2(out32, ref64), floor)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The reference's other VGG stacks (models.py:134-137, chosen by the checkpoint's name, models.py:248-327): VGG-16 and the
+# channel-pruned VGG-16 with its widths of 24, 22, 41, 51, 108, 89, 111, 184, 276, 228
+# ---------------------------------------------------------------------------------------------------------
+VGG16_MODELS = {"vgg16": ("vgg16_synth.pth", synth.VGG16_CHANNELS), "vgg16prune": ("vgg16-prune_synth.pth", synth.VGG16P_CHANNELS)}
+VGG16_ALT = dict(use_covariance=True, pooling="avg", content_layers="relu3_3,relu5_1", style_layers="relu1_2,relu2_2,relu3_1,relu4_3")
+
+
+@pytest.mark.parametrize("tag", list(VGG16_MODELS))
+@pytest.mark.parametrize("name,S,over", [("S80_default", 80, {}), ("S72_covariance_avgpool_layers_alt", 72, VGG16_ALT)])
+def test_vgg16_and_pruned_vgg16_feval_matches_reference(tag, name, S, over):
+    g = gold(f"feval_{tag}_{name}")
+    path, channels = VGG16_MODELS[tag]
+    cfg = make_cfg(model_file=path, **over)
+    content, style, init = synth.images(S)
+    spec, net, total, losses, grad = run_feval(cfg, content, [style], init, synth.vgg19_state_dict(channels=channels))
+    assert [l.cout for l in spec if l.kind == "conv"] == [c for c in channels if c != "P"][:sum(1 for l in spec if l.kind == "conv")]
+    if "conv_channels" in g:
+        assert [l.cout for l in spec if l.kind == "conv"] == list(g["conv_channels"])
+    assert len(spec) == len(g["module_types"])
+    check_feval(g, spec, total, losses, grad)
+
+
+@pytest.mark.parametrize("tag", list(VGG16_MODELS))
+def test_vgg16_and_pruned_vgg16_fp64_arbiter_and_trajectories(tag):
+    path, channels = VGG16_MODELS[tag]
+    sd = synth.vgg19_state_dict(channels=channels)
+    g64 = gold(f"feval_{tag}_S80_default_f64")
+    content, style, init = synth.images(80)
+    spec, net, total, losses, grad = run_feval(make_cfg(model_file=path), content, [style], init, sd, dtype=torch.float64)
+    check_feval(g64, spec, total, losses, grad, tol_loss=1e-10, tol_grad=1e-10)
+    g = gold(f"traj_{tag}_S64")
+    content, style, init = synth.images(64)
+    for opt in ("lbfgs", "adam"):
+        out = optimize(content, [style], init, 6, make_cfg(model_file=path, optimizer=opt), sd, dtype=torch.float64)
+        assert rel_l2(out, g[f"{opt}_N6_f64"]) <= 1e-9, opt
+        out32 = optimize(content, [style], init, 6, make_cfg(model_file=path, optimizer=opt), sd)
+        ours, theirs = rel_l2(out32, g[f"{opt}_N6_f64"]), rel_l2(g[f"{opt}_N6_f32"], g[f"{opt}_N6_f64"])
+        assert ours <= max(2.0 * theirs, 1e-3), (opt, ours, theirs)   # (the bar of test_trajectory_vs_arbiter)
+
+
+def test_vgg_stack_is_chosen_by_the_checkpoint_name_like_the_reference():
+    from oracle.style_oracle import VGG16_CHANNELS, VGG16P_CHANNELS, VGG19_CHANNELS, _vgg_channels
+    for name, want in (("modelzoo/vgg16-prune.pth", VGG16P_CHANNELS), ("nyud-fcn32s-color-heavy.pth", VGG16_CHANNELS), ("fcn32s-heavy-pascal.pth", VGG16_CHANNELS),
+                       ("vgg16-sod.pth", VGG16_CHANNELS), ("vgg19.pth", VGG19_CHANNELS), ("vgg16.pth", VGG16_CHANNELS), ("vgg19-prune.pth", VGG16P_CHANNELS),
+                       ("nin.pth", None)):
+        assert _vgg_channels(name) is want, name
+    with pytest.raises(ValueError):
+        _vgg_channels("vgg11.pth")

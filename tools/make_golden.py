@@ -838,13 +838,38 @@ def gen_feval_odd():
             save(f"feval_vgg19_S{S}_default" + ("_f64" if double else ""), **out)
 
 
-GROUPS = {"feval_odd": gen_feval_odd, "imgvid": gen_imgvid, "traj_extra": gen_traj_extra, "batch": gen_batch, "vid": gen_vid, "temporal": gen_temporal, "cli": gen_cli, "traj64v": gen_traj_variants64, "feval": gen_feval, "traj": gen_traj, "nin": gen_nin, "hist": gen_hist, "host": gen_host}
+def gen_vgg16():
+    """The reference's other VGG stacks (models.py:134-137, selected by the checkpoint's NAME, models.py:248-327): VGG-16 and the
+    channel-pruned VGG-16 ("prun": 24, 22, 41, 51, 108, 89, 111, 184, 276, 228 channels - multiples of nothing).  Single evaluations at
+    S = 80 (planes 80 / 40 / 20 / 10 / 5), fp32 and the fp64 arbiter, and short trajectories of both optimisers at S = 64."""
+    print("[vgg16] VGG-16 and pruned VGG-16 fixtures")
+    paths = {"vgg16": (os.path.join(TMP, "vgg16_synth.pth"), synth.VGG16_CHANNELS),
+             "vgg16prune": (os.path.join(TMP, "vgg16-prune_synth.pth"), synth.VGG16P_CHANNELS)}
+    for tag, (path, channels) in paths.items():
+        torch.save(synth.vgg19_state_dict(channels=channels), path)
+        S = 80
+        content, style, init = synth.images(S)
+        for double in (False, True):
+            out, net = single_feval(get_args([], model=path, S=S), content, [style], init, double=double)
+            out["conv_channels"] = np.array([m.out_channels for m in net if isinstance(m, torch.nn.Conv2d)])
+            save(f"feval_{tag}_S{S}_default" + ("_f64" if double else ""), **out)
+        out, _ = single_feval(get_args(["--use_covariance", "--pooling", "avg", "--content_layers", "relu3_3,relu5_1", "--style_layers",
+                                        "relu1_2,relu2_2,relu3_1,relu4_3"], model=path, S=72), *[[t] if i == 1 else t for i, t in enumerate(synth.images(72))])
+        save(f"feval_{tag}_S72_covariance_avgpool_layers_alt", **out)
+        res = {}
+        for opt in ("lbfgs", "adam"):
+            for double in (False, True):
+                res[f"{opt}_N6_{'f64' if double else 'f32'}"] = run_traj(64, 6, opt, double, model=path).numpy()
+        save(f"traj_{tag}_S64", **res)
+
+
+GROUPS = {"vgg16": gen_vgg16, "feval_odd": gen_feval_odd, "imgvid": gen_imgvid, "traj_extra": gen_traj_extra, "batch": gen_batch, "vid": gen_vid, "temporal": gen_temporal, "cli": gen_cli, "traj64v": gen_traj_variants64, "feval": gen_feval, "traj": gen_traj, "nin": gen_nin, "hist": gen_hist, "host": gen_host}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     want = sys.argv[1:] or ["all"]
     if "all" in want:
-        want = [g for g in GROUPS if g not in ("traj64v", "cli", "vid", "feval_odd")] + ["cli", "vid"]
+        want = [g for g in GROUPS if g not in ("traj64v", "cli", "vid", "feval_odd", "vgg16")] + ["cli", "vid"]
     for gname in want:
         GROUPS[gname]()
     meta = {"torch": torch.__version__, "threads": 1, "numpy": np.__version__,
