@@ -207,7 +207,7 @@ def pmc_traffic_lbfgs():
     """Memory-side bytes of one maua_lbfgs_iterate at full history (its five launches added up) from the committed PMC pass of
     `bench.py --model nin` (profiles/pmc_r0N_traffic_nin.json, the newest: tools/profile_round.sh, the last four launches of each kernel)."""
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    path = next((os.path.join(here, f) for f in ("pmc_r05_traffic_nin.json", "pmc_r04_traffic_nin.json", "pmc_r03_traffic_nin.json")
+    path = next((os.path.join(here, f) for f in ("pmc_r06_traffic_nin.json", "pmc_r05_traffic_nin.json", "pmc_r04_traffic_nin.json", "pmc_r03_traffic_nin.json")
                  if os.path.exists(os.path.join(here, f))), None)
     if path is None:
         return None
