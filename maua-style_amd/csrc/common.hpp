@@ -123,6 +123,9 @@ struct ConvArgs {
     const unsigned char* in_codes;  // conv_x3w backward, nullable: `x` is the pooled map [Cin][H/2][W/2] of a 2x2 / 2 max pool and these are its
     int in_code_mask;               //   decision bytes; the kernel reads x as the pool's backward pass over them: element (y, x) =
                                     //   pooled[y/2][x/2] if (code & in_code_mask) == 2 (y & 1) + (x & 1) else 0  (mask 7: ReLU bit honoured, 3: not)
+    int cot_inner;       // conv_x3w / conv_x3q: 1 = the channel tiles of a pixel tile are neighbours in dispatch order on ONE XCD (they run at the
+                         //   same time and share the patch in that XCD's L2), 0 = blockIdx.y is the channel tile (a tile's channel tiles run gridDim.x
+                         //   workgroups apart).  Which workgroup computes which (pixel tile, channel tile) changes no bit.
     unsigned* arrive;    // split-K finished INSIDE the launch (conv_x3q / conv_x3w, round 6), nullable: one arrival counter per (image, channel
                          //   tile, pixel tile), all zero between launches; the workgroup that draws the last ticket of its tile adds the other
                          //   splits' slabs to its own sums in split order and runs the one-pass epilogue (no conv_splitk_finish launch)

@@ -26,7 +26,7 @@ namespace maua {
 // as the caller's default.  Process-wide, read at every use (a few string compares per launch), not thread-safe against concurrent sets.
 static const char* const g_tuning_names[] = {"conv_few_out", "few_out_ks4_below", "x3w_ks", "x3w_stagger", "x3q_ks", "x3q_min_fill", "x3q_min_chunks",
                                              "x3p_ks", "x3p_groups", "x3p_min_fill", "x3p_min_items", "x6_persist", "gram_x3", "gram_bwd_x3",
-                                             "gram_t128", "gram_t128_min_hw", "p1_order", "lbfgs_vec", "lbfgs_tri", "finish_in_launch_max_ks", "x3p_order"};
+                                             "gram_t128", "gram_t128_min_hw", "p1_order", "lbfgs_vec", "lbfgs_tri", "finish_in_launch_max_ks", "x3p_order", "cot_inner"};
 constexpr int kTunings = sizeof(g_tuning_names) / sizeof(g_tuning_names[0]);
 static double g_tuning_values[kTunings];
 static bool g_tuning_set[kTunings];

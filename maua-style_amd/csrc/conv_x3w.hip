@@ -204,9 +204,17 @@ __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_in
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
     const int n = blockIdx.z / ksplit, split = blockIdx.z - n * ksplit;
-    const int cotile = blockIdx.y;
-    const int co0 = cotile * XW_COT;
+    // XCD-aware order (conv_x6.hip): XCD k owns the k-th contiguous band of pixel tiles.  Workgroups go to the XCDs in turn in dispatch order
+    // (x fastest, gridDim.x % 8 == 0), so `slot` counts an XCD's workgroups in the order they start: with p.cot_inner the channel tiles of a
+    // pixel tile take consecutive slots - they run side by side on one XCD and the patch leaves memory once, not once per channel tile.
     const int ntile = gridDim.y;
+    const int tiles_total = p.tiles_x * ((p.OH + XW_ROWS - 1) / XW_ROWS);
+    const int per_xcd = (tiles_total + 7) >> 3;
+    const int xcd = blockIdx.x & 7;
+    const int slot = (int)((blockIdx.y * gridDim.x + blockIdx.x) >> 3);
+    const int cotile = p.cot_inner ? slot % ntile : (int)blockIdx.y;
+    const int tile = xcd * per_xcd + (p.cot_inner ? slot / ntile : (int)(blockIdx.x >> 3));
+    const int co0 = cotile * XW_COT;
     const int in_plane = p.H * p.W;
     const int64_t out_plane = (int64_t)p.OH * p.OW;
     const int st_w = UNPOOL ? p.W >> 1 : p.W;                              // row pitch and plane of the array the patch is staged from
@@ -214,11 +222,7 @@ __global__ void __launch_bounds__(256, 2) conv_x3w_kernel(ConvArgs p, float w_in
     const float* __restrict__ xin = p.x + (int64_t)n * p.Cin * st_plane;
     const unsigned char* __restrict__ xcodes = UNPOOL ? p.in_codes + (int64_t)n * p.Cin * st_plane : nullptr;
     const unsigned code_mask = (unsigned)p.in_code_mask;
-    // XCD-aware tile order (conv_x6.hip): XCD k owns the k-th contiguous band of tiles
-    const int tiles_total = p.tiles_x * ((p.OH + XW_ROWS - 1) / XW_ROWS);
-    const int per_xcd = (tiles_total + 7) >> 3;
-    const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (tile >= min(((int)(blockIdx.x & 7) + 1) * per_xcd, tiles_total)) return;  // whole workgroup leaves
+    if (tile >= min((xcd + 1) * per_xcd, tiles_total)) return;  // whole workgroup leaves
     const int x0 = (tile % p.tiles_x) * 32, y0 = (tile / p.tiles_x) * XW_ROWS;
     if (tid == 0) {  // for the in-launch finish of a split channel loop (behind the K loop; read there behind several barriers)
         reinterpret_cast<int*>(Ml)[5] = (n * ntile + cotile) * tiles_total + tile;
@@ -885,6 +889,7 @@ int conv_x3w_launch(const ConvArgs& a, int n, float w_scale, hipStream_t stream)
     p.mask = g_xw_stamp;
 #endif
     p.tiles_x = (a.OW + 31) / 32;
+    p.cot_inner = tuning("cot_inner", 0) != 0 ? 1 : 0;
     const int64_t tiles = (int64_t)p.tiles_x * ((a.OH + XW_ROWS - 1) / XW_ROWS);
     const int ks = a.ws ? x3w_choose_split(a, n) : 1;
     p.ksplit = ks;

@@ -63,6 +63,7 @@ FIELDS = {
     "x3q_min_fill": ("0.85", "lib", "conv_x3q_preferred: smallest grid fill x plane cover"),
     "x3q_min_chunks": ("4", "lib", "conv_x3q_preferred: smallest number of 32-channel chunks per workgroup"),
     "x3p_ks": ("0", "lib", "conv_x3p: force this K split (0: cost model)"),
+    "cot_inner": ("0", "lib", "conv_x3w / conv_x3q workgroup order: 1 = the channel tiles of a pixel tile start side by side on one XCD (shared patch in its L2), 0 = blockIdx.y is the channel tile"),
     "x3p_order": ("1", "lib", "conv_x3p's work list: 0 channel tile outermost (an XCD's band = part of one channel tile's plane), 1 pixel tile outermost (the channel tiles of a pixel tile side by side on an XCD's CUs: the plane leaves memory once)"),
     "x3p_groups": ("256", "lib", "conv_x3p: workgroups per launch (a multiple of 8)"),
     "x3p_min_fill": ("0.8", "lib", "conv_x3p_preferred: smallest list fill x plane cover"),
