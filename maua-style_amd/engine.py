@@ -476,7 +476,7 @@ class StyleEngine:
 
     def _x6_ok(self, s, produced_channels):
         """bf16x6 kernel: 3x3, stride 1, and enough produced channels to fill its 64-channel tile."""
-        return self.use_x6 and s.k == 3 and s.stride == 1 and s.pad <= 2 and produced_channels > 32
+        return self.use_x6 and s.k == 3 and s.stride == 1 and s.pad <= 2 and produced_channels >= plan.get_int("split_min_produced")
 
     def _run(self, x):
         hip.set_split_batch_hint(self.batch_hint)  # host-side setting read when a launch picks its split: nothing is enqueued

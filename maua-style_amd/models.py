@@ -361,7 +361,7 @@ class _ConvFn(torch.autograd.Function):
     def forward(ctx, x, mod):
         ctx.mod, ctx.in_shape = mod, x.shape
         k, stride, pad = mod.kernel_size[0], mod.stride[0], mod.padding[0]
-        if _x6_mode()[0] and k == 3 and stride == 1 and pad <= 2 and mod.out_channels > 32:
+        if _x6_mode()[0] and k == 3 and stride == 1 and pad <= 2 and mod.out_channels >= plan.get_int("split_min_produced"):
             return conv3x3_mfma(x.contiguous(), mod, False)
         if conv1x1_is_mfma(mod, False):
             return conv1x1_mfma(x.contiguous(), mod, False)
@@ -373,7 +373,7 @@ class _ConvFn(torch.autograd.Function):
     def backward(ctx, gy):
         mod = ctx.mod
         k, stride, pad = mod.kernel_size[0], mod.stride[0], mod.padding[0]
-        if _x6_mode()[1] and k == 3 and stride == 1 and pad <= 2 and mod.in_channels > 32:
+        if _x6_mode()[1] and k == 3 and stride == 1 and pad <= 2 and mod.in_channels >= plan.get_int("split_min_produced"):
             return conv3x3_mfma(gy.contiguous(), mod, True), None
         if conv1x1_is_mfma(mod, True):
             return conv1x1_mfma(gy.contiguous(), mod, True), None

@@ -29,6 +29,7 @@ FIELDS = {
     "conv_x3p_max": ("100000", "host", "largest consumed channel count for conv_x3p.hip"),
     "x3p_gram_min_mb": ("700", "host", "the Gram backward rides in conv_x3p's launch from this many MB of maps per launch (below: conv_x3w's fused form)"),
     "conv_image": ("1", "host", "the 3-channel image layer's forward pass on conv_img.hip"),
+    "split_min_produced": ("16", "host", "a 3x3 stride-1 pass runs the split-precision kernels (64-channel tiles) when it PRODUCES at least this many channels, else the fp32-MFMA / direct kernels (VGG-19 / NIN: only the 64 -> 3 image gradient is below; the pruned VGG-16 has widths of 22 and 24)"),
     "x3w_min_pixels": ("4096", "host", "planes smaller than this run conv_x3.hip's 4-row tiles"),
     "few_mfma": ("1", "host", "backward-data of the image layer (64 -> 3 channels) on the matrix cores (conv_few_mfma.hip) instead of conv3x3_few_out's vector-ALU kernel"),
     "strided_fwd_3x3": ("1", "host", "forward pass of a strided, unpadded layer (NIN's stem) as space to depth + a stride-1 3x3 convolution over sites (conv_x3w)"),

@@ -110,3 +110,23 @@ def test_image_layer_with_the_gram_matrix_along(hip, H, W):
     hip.conv3x3_image_gram(x.cuda(), bank, 1, torch.empty_like(y0), again)
     torch.cuda.synchronize()
     assert torch.equal(again[:, :32], slabs[:, :32]) and torch.equal(again[:, 32:, 32:], slabs[:, 32:, 32:])
+
+
+@pytest.mark.parametrize("cout", [22, 24, 32, 64, 96])
+def test_image_layer_writes_nothing_outside_its_output(hip, cout):
+    """The kernel masks channels past `cout` (and lanes past a row's end) by the range of its store descriptor: a 64-channel tile of which
+    only 22 - 32 exist (the pruned VGG-16's first layer has 24) must leave what lies behind the output tensor alone."""
+    H, W = 37, 50
+    x = rnd(1, 3, H, W, seed=5, scale=100.0).cuda()
+    w = rnd(cout, 3, 3, 3, seed=6, scale=0.3)
+    b = rnd(cout, seed=7, scale=1.0)
+    bank = hip.conv_pack_filters_image(w.cuda(), b.cuda())
+    n_out = cout * H * W
+    guard = 70 * H * W                      # more than a whole 64-channel tile on either side
+    buf = torch.full((guard + n_out + guard,), 12345.0, device="cuda")
+    out = buf[guard:guard + n_out].view(1, cout, H, W)
+    hip.conv3x3_image(x, bank, cout, 1, True, out=out)
+    torch.cuda.synchronize()
+    assert bool((buf[:guard] == 12345.0).all()) and bool((buf[guard + n_out:] == 12345.0).all())
+    want = torch.relu(torch.nn.functional.conv2d(x.cpu().double(), w.double(), b.double(), padding=1))
+    assert float((out.cpu().double() - want).norm() / want.norm()) <= 2e-6
