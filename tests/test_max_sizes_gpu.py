@@ -32,7 +32,14 @@ def big(request, weight_files):
     import engine
     import models
     import optim
+    import gc
     H, W = request.param
+    gc.collect()
+    torch.cuda.empty_cache()   # (earlier modules' cached blocks: a 5800 x 5800 evaluation holds ~160 GB)
+    need = 5.0e3 * H * W       # bytes: 4.95 KB per pixel measured at 6896 x 6896 (profiles/probe_r06_big_sizes.txt)
+    free = torch.cuda.mem_get_info()[0]
+    if free < 1.15 * need:
+        pytest.skip(f"{H} x {W} needs ~{need / 2**30:.0f} GiB of device memory, {free / 2**30:.0f} GiB are free")
     args = product_args(weight_files, ["--no_grad_norm"], optimizer="adam", S=max(H, W), N=4)
     content, style, init = synth.images(S, H=H, W=W)
     optim.set_model_args(args, S)
