@@ -310,7 +310,7 @@ def test_full_size_routes_are_the_documented_ones(setup):
     assert split == 24
 
 
-@pytest.mark.parametrize("layer", ["conv3_4", "conv4_3", "conv4_4", "conv5_1"])
+@pytest.mark.parametrize("layer", ["conv1_2", "conv2_2", "conv3_2", "conv3_4", "conv4_3", "conv4_4", "conv5_1"])
 def test_full_size_backward_pass_gradients_against_fp64(setup, layer):
     """The gradients the REAL 1024x1024 backward pass leaves in the engine's buffers - written by the launches the benchmark times, with
     the ReLU mask of the produced gradient applied in the convolution's epilogue (conv3_4: conv_x3p_kernel<OM, .., UNPOOL>; conv4_3 and
@@ -322,10 +322,15 @@ def test_full_size_backward_pass_gradients_against_fp64(setup, layer):
     import torch.nn.functional as F
     _, _, _, eng, x = setup
     rec = _routes_by_layer(eng, x)[layer][1]
-    assert rec["kernel"] == ("conv_x3p" if layer == "conv3_4" else "conv_x3q") and bool(rec.get("unpool")) == (layer in ("conv3_4", "conv4_4")), rec
+    gram = layer in ("conv1_2", "conv2_2", "conv3_2")   # (round 6) the three launches that carry the Gram backward of relu1_1 / 2_1 / 3_1 along:
+    # out = [F > 0] * (backward-data + D . F) in ONE conv_x3w launch (models.conv3x3_bwd_with_gram / conv3x3_bwd_from_pooled; reference: autograd of
+    # loss.py:91 `torch.mm(x, x.t())` and of models.py:129-130), conv1_2 / conv2_2 staged from the pooled map's gradient on top of that
+    assert rec["kernel"] == ("conv_x3w" if gram else "conv_x3p" if layer == "conv3_4" else "conv_x3q") and bool(rec.get("gram")) == gram and \
+        bool(rec.get("unpool")) == (layer in ("conv1_2", "conv2_2", "conv3_4", "conv4_4")), rec
     eng.feval(x)
     torch.cuda.synchronize()
-    want = {"conv3_4": (256, 256, 256, 3), "conv4_3": (512, 512, 128, 1), "conv4_4": (512, 512, 128, 2), "conv5_1": (512, 512, 64, 0)}[layer]
+    want = {"conv1_2": (64, 64, 1024, 0), "conv2_2": (128, 128, 512, 0), "conv3_2": (256, 256, 256, 0),
+            "conv3_4": (256, 256, 256, 3), "conv4_3": (512, 512, 128, 1), "conv4_4": (512, 512, 128, 2), "conv5_1": (512, 512, 64, 0)}[layer]
     cands = [s for s in eng.steps if s.kind == "conv" and (s.mod.in_channels, s.mod.out_channels) == want[:2] and eng.act[s.src].shape[2] == want[2]]
     step = cands[want[3]] if len(cands) > want[3] else cands[-1]
     mod = step.mod
@@ -340,6 +345,11 @@ def test_full_size_backward_pass_gradients_against_fp64(setup, layer):
             gw = float(eng._coefficients(s2)[1])  # (--no_grad_norm in this module's setup: the gradient weight is the strength itself)
             assert gw == float(s2.mod.strength)
             extra = (gw * 2.0 / a_in.nelement(), s2.mod.target)
+    dmat = None
+    if gram:
+        st = next(s2 for s2 in eng.steps if s2.kind == "style" and s2.src == step.src)
+        dmat = eng.dmat[id(st)].cpu()           # D of that style layer as the evaluation left it: the launch adds D . F
+        assert dmat.shape == (a_in.shape[1], a_in.shape[1]) and float(dmat.abs().max()) > 0
     side = a_in.shape[2]
     # the gradient of a conv + ReLU output is kept pre-masked by whoever writes it last; the gradient of a POOLED map is not (the pool's
     # backward pass applies the mask of its source while routing): conv5_1's input is pool4's output
@@ -353,6 +363,8 @@ def test_full_size_backward_pass_gradients_against_fp64(setup, layer):
             r = _crop_reference(g_out, w_eff, None, y0, x0, 64, 1, dt)
             if extra is not None:
                 r = r + extra[0] * (a_in[:, :, y0:y0 + 64, x0:x0 + 64].cpu().to(dt) - extra[1][:, :, y0:y0 + 64, x0:x0 + 64].cpu().to(dt))
+            if dmat is not None:
+                r = r + torch.einsum("ij,njyx->niyx", dmat.to(dt), a_in[:, :, y0:y0 + 64, x0:x0 + 64].cpu().to(dt))
             res[dt] = r * mask
         mine = g_in[:, :, y0:y0 + 64, x0:x0 + 64].cpu()
         floor = rel_l2(res[torch.float32], res[torch.float64])
