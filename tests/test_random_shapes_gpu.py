@@ -31,6 +31,9 @@ def hip():
 # A fuzzing campaign draws other cases from the same generators: RANDOM_SHAPES_BASE=k python -m pytest tests/test_random_shapes_gpu.py -m gpu
 # (k = 0: the committed cases; profiles/fuzz_r06_random_shapes.txt: k = 1 ... 6 on the final tree of round 6).
 BASE = 1000003 * int(os.environ.get("RANDOM_SHAPES_BASE", "0"))
+# ... and RANDOM_CONFIG_SCALE=k multiplies the image side of the random CONFIGURATIONS (k = 3: VGG-19 at 120 ... 600 pixels, where the wide
+# kernels, the pooling epilogues and the fused Gram backward are routed; NIN at 450 ... 1260)
+SCALE = float(os.environ.get("RANDOM_CONFIG_SCALE", "1"))
 
 
 def draw(seed):
@@ -175,6 +178,7 @@ def draw_config(seed):
     r = random.Random(9000 + seed + BASE)
     nin = seed >= 32   # (the last sixteen configurations: the alternative backbone, reference models.py:74-113)
     S = r.randint(150, 420) if nin else r.randint(40, 200)   # (NIN's stem divides the image by four; three ceil-mode pools follow)
+    S = int(S * SCALE)
     relus = [f"relu{i}" for i in range(1, 13)] if nin else \
         ["relu1_1", "relu1_2", "relu2_1", "relu2_2", "relu3_1", "relu3_2", "relu3_3", "relu3_4", "relu4_1", "relu4_2", "relu4_3", "relu4_4", "relu5_1"]
     style = sorted(r.sample(relus, r.randint(1, 5)), key=relus.index)
@@ -281,7 +285,8 @@ def test_random_configurations_against_the_cpu_oracle(weight_files, seed):
             if not src.is_meta:
                 eidx = F.max_pool2d(src.cpu(), l.k, l.stride, 0, ceil_mode=l.ceil, return_indices=True)[1]
             else:   # fused into the producing launch: byte = corner (2 dy + dx) | 4 where the maximum is not positive
-                codes = opt.engine.pool_codes[id(st)].cpu().long()
+                from conftest import planar_codes
+                codes = planar_codes(opt.engine.pool_codes[id(st)].cpu()).long()   # ([image][c / 8][pooled pixel][c % 8] in memory)
                 hp, wp = codes.shape[2:]
                 w_in = acts[i - 1].shape[3]
                 py = torch.arange(hp).view(1, 1, hp, 1)
