@@ -7,7 +7,9 @@ and per case the identities the kernels promise:
     of conv_x3q (its first chunk of an item folds once where conv_x3q folds twice: not the same bits);
   * the pooling form of conv_x3p and of conv_x3q == the plain form + maua_pool2x2_fwd_codes bit for bit (pooled map and decision bytes);
   * the unpooling form of both == maua_pool2x2_bwd_codes + the plain form (of the same kernel) bit for bit;
-  * conv_x3q against fp64 (F.conv2d on the CPU) on two random 48 x 48 output crops: 2e-6 rel-L2;  conv_x3w against conv_x3q: 1e-6.
+  * conv_x3q against fp64 (F.conv2d on the CPU) on two random 48 x 48 output crops: 2e-6 rel-L2;  conv_x3w against conv_x3q: 1e-6;
+  * (half of the cases) the Gram-carrying backward form [F > 0] (backward-data + D . F) of conv_x3w against fp64 crops and rerun bit for
+    bit, conv_x3p's against conv_x3w's: 1e-6.
 
     python tools/fuzz_wide_kernels.py [cases, default 150] [seed base, default 0]          (prints one line per failing case, then a summary)"""
 import math
@@ -135,6 +137,39 @@ for case in range(N):
                     torch.cuda.synchronize()
                     if not torch.equal(onep, twop):
                         fails.append(tag + f" x3p unpooling form != pool backward + its plain form (honour={honour}, masked={fm is not None})")
+        # Gram-carrying backward form (the style layers sit on 64 ... 512-channel maps): out = [F > 0] (backward-data + D . F) in one launch of
+        # conv_x3w / conv_x3p against fp64 on two crops, the two kernels against each other, a rerun bit for bit
+        if pad == 1 and cin % 16 == 0 and cin <= 512 and r.random() < 0.5:
+            c = cin                                              # channels of F = channels the backward pass produces
+            gy = torch.randn(n, cout, H, W, generator=g, device="cuda") * (torch.rand(n, cout, H, W, generator=g, device="cuda") > 0.5)
+            fmap = torch.relu(torch.randn(n, c, H, W, generator=g, device="cuda"))
+            D = torch.randn(c, c, generator=g, device="cuda") * 1e-3
+            D = D + D.t()
+            bank = hip.conv_x3w_dmat_bank(c, "cuda", n)
+            for f in range(n):
+                hip.conv_pack_dmat_x3w(D, bank[0][f], bank[1][f:f + 1])
+            _, bbw, wscw = hip.conv_pack_filters_x3w(w)
+            wsw = ws_for(hip.conv_x3w_workspace_bytes, n, cout, H, W, c, 1)
+            yw = hip.conv3x3_x3w_gram(gy, bbw, wscw, fmap, bank[0], bank[1], c, 1, workspace=wsw)
+            yw2 = hip.conv3x3_x3w_gram(gy, bbw, wscw, fmap, bank[0], bank[1], c, 1, workspace=wsw)
+            torch.cuda.synchronize()
+            if not torch.equal(yw, yw2):
+                fails.append(tag + " x3w Gram form: rerun differs")
+            wb = w.flip(2, 3).transpose(0, 1).contiguous()
+            for _ in range(2):
+                size = min(48, H, W)
+                y0, x0 = r.randint(0, H - size), r.randint(0, W - size)
+                fc = fmap[:, :, y0:y0 + size, x0:x0 + size].cpu().double()
+                ref = (crop_ref(gy, wb, None, y0, x0, size, 1) + torch.einsum("ij,njhw->nihw", D.cpu().double(), fc)) * (fc > 0)
+                e = rel_l2(yw[:, :, y0:y0 + size, x0:x0 + size].cpu(), ref)
+                if not e <= 2e-6:
+                    fails.append(tag + f" x3w Gram form vs fp64 at ({y0},{x0}): {e:.2e}")
+            if cout % 32 == 0 and c % 64 == 0 and hip.conv_x3p_supported(cout, H, W, c, 1):
+                yp = hip.conv3x3_x3p(gy, bank_b, wsc, None, c, 1, False, out=torch.full((n, c, H, W), float("nan"), device="cuda"), out_relu_mask=fmap,
+                                     dmat_bank=bank[0], dmat_inv_scale=bank[1], workspace=ws_for(hip.conv_x3p_workspace_bytes, n, cout, H, W, c, 1))
+                torch.cuda.synchronize()
+                if not rel_l2(yp, yw) <= 1e-6:
+                    fails.append(tag + f" x3p Gram form vs x3w's: {rel_l2(yp, yw):.2e}")
         done += 1
     except Exception as e:  # noqa: BLE001
         fails.append(tag + f" raised {type(e).__name__}: {str(e)[:200]}")
