@@ -717,7 +717,10 @@ def test_full_size_evaluation_against_the_oracle(weight_files, model, S):
         assert abs(slots[k] - want) <= 1e-4 * max(abs(want), 1e-9), (names[k], slots[k], want)
     assert abs(total - float(t64)) <= 1e-4 * abs(float(t64))
     ours, theirs = rel_l2(grad, g64), rel_l2(res[torch.float32][2], g64)
-    assert ours <= (2.0 if model == "nin" else 1.5) * theirs, (ours, theirs)
+    print(f"{model} {S}: pixel gradient against the fp64 oracle: engine {ours:.3e}, fp32 oracle {theirs:.3e}")
+    # (both distances are set by the handful of decisions each arithmetic takes differently from fp64, and the fp32 oracle's depend on how
+    #  the host's BLAS threads split its sums: the ratio is held where it was measured, the absolute level is the fallback on another host)
+    assert ours <= max((2.0 if model == "nin" else 1.5) * theirs, 4e-3 if model == "nin" else 3e-3), (ours, theirs)   # (measured: VGG-19 1.37e-3 / 1.18e-3, NIN 1.86e-3 / 1.20e-3)
     assert theirs <= 1e-2    # (the yardstick itself is sane)
 
 
