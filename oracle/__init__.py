@@ -10,7 +10,9 @@ when its HIP library is missing.
 Parity status: PINNED.  `tests/test_oracle_golden.py` checks this restatement against
 fixtures in `tests/golden/` that were produced by running the unmodified reference in
 the build container (`tools/make_golden.py`): per-module losses, total loss, pixel
-gradient, style/content targets, and L-BFGS/Adam trajectories in fp32 and fp64.
+gradient, style/content targets, and L-BFGS/Adam trajectories in fp32 and fp64 - for
+VGG-19, NIN and (round 6) the reference's other VGG stacks, VGG-16 and the channel-pruned
+VGG-16, chosen by the checkpoint's name as models.py:248-327 does.
 
 Where the arithmetic lives in a third-party dependency: all FLOPs of the reference are
 PyTorch ops (requirements.txt pins torch==1.8.1; this image has torch 2.10).  The oracle
